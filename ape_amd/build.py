@@ -1,0 +1,68 @@
+"""Build libape_hip.so (all HIP kernels + the C-ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU container; the resulting
+ape_amd/lib/libape_hip.so is git-ignored but travels to the GPU box with the snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libape_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _sources():
+    return sorted(
+        os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp")
+    )
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in _sources() + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ape_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "libape_hip.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    objs = []
+    procs = []
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if src.endswith(".cpp"):
+            cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if verbose:
+            print("[ape_amd.build]", " ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print("[ape_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

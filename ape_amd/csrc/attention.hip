@@ -1,0 +1,274 @@
+// Flash-style scaled-dot-product attention for gfx950 (non-causal, no mask, no dropout).
+//
+// Replaces F.scaled_dot_product_attention at ape/modeling/backbone/vit_eva_clip.py:261-263 (16 heads x 64;
+// 4 windows x 1024 tokens or 1 x 4096 tokens) and the attention core of nn.MultiheadAttention used by the
+// decoder self-attention (detrex MultiheadAttention built at deformable_transformer_vl.py:141-146; 8 x 32).
+//
+// bf16 kernel: one workgroup = 4 waves = 64 query rows of one (window, head); K and V^T tiles of 64 keys are
+// register-staged into XOR-swizzled LDS (double buffered, one barrier per tile).  The score MFMA is issued
+// "swapped" (S^T = K.Q^T) so that after it every lane holds, for ONE query (column lane&15), 4 consecutive
+// keys per 16-key tile; those registers are exactly the B operand of the P.V MFMA (O^T = V^T.P^T) under a
+// permuted k-order that is applied identically to the V^T operand -> no LDS round trip and no cross-lane
+// traffic for P.  Row max / row sum need only two xor-shuffles (lanes l, l^16, l^32, l^48 share a query).
+// V is consumed TRANSPOSED ([head*HD + d][token]); the producing GEMM writes it that way (trans_out).
+// f32 kernel: one query per lane, K / V tiles broadcast from LDS -- exact-math validation mode.
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+struct AttnParams {
+  const void* Q; const void* K; const void* Vt; void* O;
+  int ldq, ldk, ldvt, ldo;
+  int N, H;
+  float scale_log2;  // scale * log2(e)
+  float scale;
+};
+
+__device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
+  // element offset of 16-byte chunk c of `row`; rows are chunks_per_row*8 bf16 wide
+  if (chunks_per_row == 8) return row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
+  /* 4 chunks (64-byte rows) */ return row * 32 + ((c ^ (((row >> 3) & 1) << 1)) << 3);
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
+  constexpr int KC = HD / 8;        // 16-byte chunks per K row
+  constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
+  constexpr int DT = HD / 16;       // output d tiles
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][64 * HD + HD * 64];  // [buf][K tile | Vt tile]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int N = p.N;
+  const bf16_t* Qp = reinterpret_cast<const bf16_t*>(p.Q);
+  const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
+  const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.Vt);
+
+  // Q fragment (B operand of S^T = K.Q^T): query = frow, d = ks*32 + fq*8 .. +8
+  const int qrow = qblk * 64 + wave * 16 + frow;
+  const int qrow_c = qrow < N ? qrow : N - 1;
+  bf16x8_t qf[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+    qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * N + qrow_c) * p.ldq + h * HD + ks * 32 + fq * 8));
+
+  // staging assignment: K tile 64 rows x KC chunks, Vt tile HD rows x 8 chunks; both HD*8 chunks
+  constexpr int CH = HD * 8;
+  constexpr int PER = CH / 256;  // 2 (HD=64) or 1 (HD=32)
+  uint4 rk[PER], rv[PER];
+  auto gload = [&](int t) {
+    const int key0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + 256 * i;
+      {
+        const int row = cid / KC, c = cid % KC;
+        int key = key0 + row; key = key < N ? key : N - 1;
+        rk[i] = *reinterpret_cast<const uint4*>(Kp + ((size_t)b * N + key) * p.ldk + h * HD + c * 8);
+      }
+      {
+        const int row = cid >> 3, c = cid & 7;
+        rv[i] = *reinterpret_cast<const uint4*>(Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * N + key0 + c * 8);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cid = tid + 256 * i;
+      *reinterpret_cast<uint4*>(&smem[buf][swz_rows(cid / KC, cid % KC, KC)]) = rk[i];
+      *reinterpret_cast<uint4*>(&smem[buf][64 * HD + swz_rows(cid >> 3, cid & 7, 8)]) = rv[i];
+    }
+  };
+
+  f32x4_t oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int nt = (N + 63) / 64;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < nt) gload(t + 1);
+    const bf16_t* sK = &smem[buf][0];
+    const bf16_t* sV = &smem[buf][64 * HD];
+
+    // S^T[key][query] for the 64 keys of this tile: 4 key tiles x KSTEPS
+    f32x4_t sacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[swz_rows(i * 16 + frow, ks * 4 + fq, KC)]));
+        sacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[i], 0, 0, 0);
+      }
+    }
+    // scale (log2 domain), mask keys >= N, running max
+    float pv[4][4];
+    float mx = -INFINITY;
+    const int kbase = t * 64 + fq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = sacc[i][r] * p.scale_log2;
+        if (kbase + i * 16 + r >= N) s = -INFINITY;
+        pv[i][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(pv[i][r] - m_new);
+        pv[i][r] = e;
+        rs += e;
+      }
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      oacc[d][0] *= alpha; oacc[d][1] *= alpha; oacc[d][2] *= alpha; oacc[d][3] *= alpha;
+    }
+    // O^T[d][query] += Vt[d][key] P^T[key][query]; k-step s covers key tiles 2s, 2s+1 with the permuted
+    // in-step order e<4 -> key (2s)*16 + fq*4 + e ; e>=4 -> key (2s+1)*16 + fq*4 + (e-4)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 pk;
+      pk.x = pack2bf(pv[2 * s][0], pv[2 * s][1]);
+      pk.y = pack2bf(pv[2 * s][2], pv[2 * s][3]);
+      pk.z = pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]);
+      pk.w = pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3]);
+      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const int row = d * 16 + frow;
+        // keys (2s)*16 + fq*4 .. +4 : byte offset in the 128-byte row = s*64 + fq*8 -> chunk s*4 + (fq>>1)
+        const int o0 = swz_rows(row, s * 4 + (fq >> 1), 8) + (fq & 1) * 4;
+        const int o1 = swz_rows(row, s * 4 + 2 + (fq >> 1), 8) + (fq & 1) * 4;
+        uint4 vk;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(&sV[o0]);
+        const uint2 a1 = *reinterpret_cast<const uint2*>(&sV[o1]);
+        vk.x = a0.x; vk.y = a0.y; vk.z = a1.x; vk.w = a1.y;
+        oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), pf, oacc[d], 0, 0, 0);
+      }
+    }
+    if (t + 1 < nt) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // finish: total row sum over the 4 lanes sharing this query
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_run;
+  if (qrow < N) {
+    bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * N + qrow) * p.ldo + h * HD + fq * 4;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const float v[4] = {oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv};
+      st4<bf16_t>(o + d * 16, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 validation kernel: block = 64 lanes = 64 queries of one (window, head)
+// ------------------------------------------------------------------------------------------
+template <int HD>
+__global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
+  __shared__ float sK[64][HD];
+  __shared__ float sV[64][HD];
+  const int lane = threadIdx.x;
+  const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int N = p.N;
+  const float* Qp = reinterpret_cast<const float*>(p.Q);
+  const float* Kp = reinterpret_cast<const float*>(p.K);
+  const float* Vp = reinterpret_cast<const float*>(p.Vt);
+  const int qrow = qblk * 64 + lane;
+  const int qrow_c = qrow < N ? qrow : N - 1;
+  float q[HD], o[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { q[d] = Qp[((size_t)b * N + qrow_c) * p.ldq + h * HD + d] * p.scale; o[d] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+  const int nt = (N + 63) / 64;
+  for (int t = 0; t < nt; ++t) {
+    const int key0 = t * 64;
+    __syncthreads();
+    for (int idx = lane; idx < 64 * HD; idx += 64) {
+      const int row = idx / HD, d = idx % HD;
+      int key = key0 + row; key = key < N ? key : N - 1;
+      sK[row][d] = Kp[((size_t)b * N + key) * p.ldk + h * HD + d];
+    }
+    for (int idx = lane; idx < 64 * HD; idx += 64) {
+      const int d = idx / 64, kk = idx % 64;
+      const int key = key0 + kk;
+      sV[kk][d] = key < N ? Vp[(size_t)(h * HD + d) * p.ldvt + (size_t)b * N + key] : 0.f;
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < 64; c0 += 16) {
+      float s[16];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) a = fmaf(q[d], sK[c0 + kk][d], a);
+        if (key0 + c0 + kk >= N) a = -INFINITY;
+        s[kk] = a;
+        mx = fmaxf(mx, a);
+      }
+      const float m_new = fmaxf(m_run, mx);
+      if (m_new == -INFINITY) continue;
+      const float alpha = expf(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] *= alpha;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float e = expf(s[kk] - m_new);
+        l_run += e;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(e, sV[c0 + kk][d], o[d]);
+      }
+      m_run = m_new;
+    }
+  }
+  if (qrow < N) {
+    float* op = reinterpret_cast<float*>(p.O) + ((size_t)b * N + qrow) * p.ldo + h * HD;
+    const float inv = 1.f / l_run;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
+  }
+}
+
+extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                 int B, int N, int H, int HD, float scale, int dt, void* stream) {
+  APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
+  APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64), "ape_hip_attention: bad shape (HD must be 32 or 64)");
+  AttnParams p;
+  p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H;
+  p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ceil_div(N, 64), H, B);
+  if (dt == APE_DT_BF16) {
+    APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "ape_hip_attention(bf16): ld alignment");
+    APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 8 == 0,
+                  "ape_hip_attention(bf16): pointer alignment");
+    APE_CHECK_ARG(B == 1 || N % 8 == 0, "ape_hip_attention(bf16): batched windows need N %% 8 == 0");
+    if (HD == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(attn_bf16_kernel<32>, grid, dim3(256), 0, s, p);
+  } else {
+    if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
+  }
+  APE_CHECK_LAUNCH("ape_hip_attention");
+  return 0;
+}

@@ -1,0 +1,104 @@
+// Shared device/host helpers for the ape_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 storage
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+#define APE_DT_F32 0
+#define APE_DT_BF16 1
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16 cast)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 4 consecutive elements (p must be aligned to 4 elements)
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float v[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float v[4]) {
+  float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float v[4]) {
+  uint2 t = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float v[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float v[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+}
+// 8 consecutive elements (p aligned to 8 elements)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float v[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float v[8]) {
+  ld4<float>(p, v); ld4<float>(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float v[8]) {
+  uint4 t = *reinterpret_cast<const uint4*>(p);
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+  v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) {
+  st4<float>(p, v); st4<float>(p + 4, v + 4);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v[8]) {
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
+                                            pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- host side error plumbing (C-ABI: 0 = ok, negative = error, message via ape_hip_last_error) ----
+extern "C" const char* ape_hip_last_error(void);
+void ape_set_error(const char* fmt, ...);
+#define APE_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      ape_set_error(__VA_ARGS__);           \
+      return -1;                            \
+    }                                       \
+  } while (0)
+#define APE_CHECK_LAUNCH(name)                                                    \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      ape_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \
+      return -2;                                                                  \
+    }                                                                             \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,12 @@
+// Error string storage for the C-ABI (thread local; see include/ape_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+static thread_local char g_err[512] = "";
+extern "C" const char* ape_hip_last_error(void) { return g_err; }
+void ape_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" int ape_hip_abi_version(void) { return 1; }

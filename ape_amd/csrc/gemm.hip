@@ -1,0 +1,366 @@
+// GEMM family for the APE forward pass on gfx950:  C[M,N] = epi(alpha * A[M,K] . W[N,K]^T)
+//
+// Replaces every nn.Linear / 1x1-conv / patch-embed / deconv contraction on the hot path
+// (reference call sites: ape/modeling/backbone/vit_eva_clip.py:225-232,264-268,125-132;
+//  ape/layers/multi_scale_deform_attn.py:268-277,353; detrex FFN/MLP via
+//  ape/modeling/ape_deta/deformable_transformer_vl.py:45-54,140-167).
+//
+// bf16 path: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles,
+//   register-staged global->LDS double buffering (one barrier per K tile), XOR-swizzled LDS rows
+//   (conflict-free ds_read_b128 fragments), XCD-aware tile order.  The MFMA operands are swapped
+//   (D = W.A^T) so each lane owns 4 consecutive output columns -> 8/16-byte epilogue stores.
+// f32 path: plain LDS-tiled FMA kernel with the same epilogue (exact-math validation mode).
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+typedef ApeGemmArgs GemmParams;
+
+__device__ __forceinline__ float act_fn(float x, int act) {
+  if (act == APE_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == APE_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+  if (act == APE_ACT_SILU) return x / (1.f + __expf(-x));
+  return x;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_n(T* dst, const float* v, int cnt, bool vec) {
+  if (vec && cnt == 4) {
+    st4<T>(dst, v);
+  } else {
+    for (int r = 0; r < cnt; ++r) stf<T>(dst + r, v[r]);
+  }
+}
+
+// 4 consecutive output columns n0..n0+3 (n0 % 4 == 0) of row m.
+__device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float v[4]) {
+  if (m >= p.M || n0 >= p.N) return;
+  const bool masked = p.rowmask != nullptr && p.rowmask[m] != 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = v[r] * p.alpha;
+    if (masked && p.mask_mode == APE_MASK_ZERO_INPUT) x = 0.f;
+    if (p.bias != nullptr && n0 + r < p.N) x += p.bias[n0 + r];
+    v[r] = x;
+  }
+  if (p.rope_cos != nullptr && n0 < p.rope_cols) {
+    const int hd = p.rope_hd;
+    const int d0 = n0 % hd;
+    const size_t trow = (size_t)(m % p.rope_rows) * hd + d0;
+    const float c0 = p.rope_cos[trow], c1 = p.rope_cos[trow + 1], c2 = p.rope_cos[trow + 2], c3 = p.rope_cos[trow + 3];
+    const float s0 = p.rope_sin[trow], s1 = p.rope_sin[trow + 1], s2 = p.rope_sin[trow + 2], s3 = p.rope_sin[trow + 3];
+    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
+    // t*cos + rotate_half(t)*sin with rotate_half pairs (2i,2i+1) -> (-x[2i+1], x[2i])
+    v[0] = x0 * c0 - x1 * s0;
+    v[1] = x1 * c1 + x0 * s1;
+    v[2] = x2 * c2 - x3 * s2;
+    v[3] = x3 * c3 + x2 * s3;
+  }
+  if (p.act == APE_ACT_SWIGLU) {
+    // interleaved (gate, up) pairs -> N/2 output columns
+    float o[2];
+    o[0] = (v[0] / (1.f + __expf(-v[0]))) * v[1];
+    o[1] = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+    const int c0 = n0 >> 1;
+    const int nout = p.N >> 1;
+    const int cnt = (c0 + 1 < nout) ? 2 : 1;
+    const size_t off = (size_t)m * p.ldc + c0;
+    if (p.out_dt == APE_DT_F32) {
+      float* dst = reinterpret_cast<float*>(p.C) + off;
+      for (int r = 0; r < cnt; ++r) dst[r] = o[r];
+    } else {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
+      if (cnt == 2 && p.vec_ok) *reinterpret_cast<uint32_t*>(dst) = pack2bf(o[0], o[1]);
+      else for (int r = 0; r < cnt; ++r) dst[r] = f2bf(o[r]);
+    }
+    return;
+  }
+  const int cnt = (p.N - n0) < 4 ? (p.N - n0) : 4;
+  const bool vec = p.vec_ok != 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = act_fn(v[r], p.act);
+    if (p.clamp > 0.f) x = fminf(fmaxf(x, -p.clamp), p.clamp);
+    v[r] = x;
+  }
+  if (p.residual != nullptr) {
+    const size_t roff = (size_t)m * p.ldr + n0;
+    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.res_dt == APE_DT_F32) {
+      const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
+      if (vec && cnt == 4) ld4<float>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = rp[r];
+    } else {
+      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + roff;
+      if (vec && cnt == 4) ld4<bf16_t>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = bf2f(rp[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+  }
+  if (masked && p.mask_mode == APE_MASK_ZERO_OUTPUT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = 0.f;
+  }
+  const size_t off = (size_t)m * p.ldc + n0;
+  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, vec);
+  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, vec);
+}
+
+// transposed output C^T[n][m0..m0+3]  (bias by n, activation, no residual/rope/mask)
+__device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float v[4]) {
+  if (n >= p.N || m0 >= p.M) return;
+  const float b = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r] * p.alpha + b, p.act);
+  const int cnt = (p.M - m0) < 4 ? (p.M - m0) : 4;
+  const size_t off = (size_t)n * p.ldc + m0;
+  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, p.vec_ok != 0);
+  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, p.vec_ok != 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel
+// ------------------------------------------------------------------------------------------
+#define GB_M 128
+#define GB_N 128
+#define GB_K 64
+
+__device__ __forceinline__ int swz128(int row, int c) {  // 128-byte rows (8 chunks of 16 B)
+  return row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][GB_M * GB_K];  // [buf][A|W] 64 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap: each XCD (blockIdx % 8) walks a contiguous range of tiles so that
+  // the A rows it streams stay in its private L2.
+  const int tiles_n = (p.N + GB_N - 1) / GB_N;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+
+  // staging: 1024 16-byte chunks per operand tile, 4 per thread
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cid = tid + 256 * i;
+    const int row = cid >> 3, c = cid & 7;
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    ga[i] = A + (size_t)gm * p.lda + c * 8;
+    gw[i] = W + (size_t)gn * p.ldw + c * 8;
+    soff[i] = swz128(row, c);
+  }
+  uint4 ra[4], rw[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const uint4*>(ga[i] + kt * GB_K);
+      rw[i] = *reinterpret_cast<const uint4*>(gw[i] + kt * GB_K);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(&smem[buf][0][soff[i]]) = ra[i];
+      *reinterpret_cast<uint4*>(&smem[buf][1][soff[i]]) = rw[i];
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&smem[buf][0][swz128(row, ks * 4 + fq)]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + frow;
+        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&smem[buf][1][swz128(row, ks * 4 + fq)]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = p.K / GB_K;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(buf);
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (TRANS) {
+        // D[i = m_local = fq*4 + r][j = n_local = frow]
+        epi_m4(p, m0 + wm * 64 + i * 16 + fq * 4, n0 + wn * 64 + j * 16 + frow, v);
+      } else {
+        // D[i = n_local = fq*4 + r][j = m_local = frow]
+        epi_n4(p, m0 + wm * 64 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, v);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32 kernel (validation mode): 64x64x16 tile, 256 threads, 4x4 outputs / thread
+// ------------------------------------------------------------------------------------------
+template <bool TRANS>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
+  __shared__ float sA[16][64 + 4];
+  __shared__ float sW[16][64 + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int tiles_n = (p.N + 63) / 64;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  const float* __restrict__ A = reinterpret_cast<const float*>(p.A);
+  const float* __restrict__ W = reinterpret_cast<const float*>(p.W);
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, kk = idx & 15;
+      const int gm = m0 + row, gn = n0 + row, gk = k0 + kk;
+      sA[kk][row] = (gm < p.M && gk < p.K) ? A[(size_t)gm * p.lda + gk] : 0.f;
+      sW[kk][row] = (gn < p.N && gk < p.K) ? W[(size_t)gn * p.ldw + gk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], w[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = sA[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = sW[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  if (TRANS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+      epi_m4(p, m0 + ty * 4, n0 + tx * 4 + j, v);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) epi_n4(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMV (M small): out[m][n] = alpha * sum_k x[m][k] * W[n][k] + bias[n]; one wave per n
+// ------------------------------------------------------------------------------------------
+template <typename TW>
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, int ldx, const TW* __restrict__ W,
+                                                   int ldw, const float* __restrict__ bias, float* __restrict__ out,
+                                                   int ldo, int M, int N, int K, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  for (int m = 0; m < M; ++m) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(x[(size_t)m * ldx + k], ldf<TW>(W + (size_t)n * ldw + k), s);
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)m * ldo + n] = s * alpha + (bias != nullptr ? bias[n] : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// C-ABI launchers
+// ------------------------------------------------------------------------------------------
+extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
+  APE_CHECK_ARG(a != nullptr, "ape_hip_gemm: null args");
+  ApeGemmArgs p = *a;
+  APE_CHECK_ARG(p.A && p.W && p.C, "ape_hip_gemm: null pointer");
+  APE_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "ape_hip_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+  APE_CHECK_ARG(p.in_dt == APE_DT_F32 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: bad in_dt %d", p.in_dt);
+  APE_CHECK_ARG(p.act != APE_ACT_SWIGLU || (p.N % 4 == 0 && !p.trans_out), "ape_hip_gemm: swiglu needs N%%4==0, no transpose");
+  APE_CHECK_ARG(!p.trans_out || (p.residual == nullptr && p.rope_cos == nullptr && p.rowmask == nullptr),
+                "ape_hip_gemm: transposed output supports bias/act only");
+  APE_CHECK_ARG(p.rope_cos == nullptr || (p.rope_sin != nullptr && p.rope_rows > 0 && p.rope_hd > 0 && p.rope_hd % 4 == 0),
+                "ape_hip_gemm: bad rope args");
+  const int esz_out = p.out_dt == APE_DT_F32 ? 4 : 2;
+  const int esz_res = p.res_dt == APE_DT_F32 ? 4 : 2;
+  int vec = (p.ldc % 4 == 0) && (((uintptr_t)p.C) % 16 == 0);
+  if (p.residual) vec = vec && (p.ldr % 4 == 0) && (((uintptr_t)p.residual) % 16 == 0);
+  (void)esz_out; (void)esz_res;
+  p.vec_ok = vec;
+  hipStream_t s = (hipStream_t)stream;
+  if (p.in_dt == APE_DT_BF16) {
+    APE_CHECK_ARG(p.K % GB_K == 0, "ape_hip_gemm(bf16): K=%d must be a multiple of %d (pad the operands)", p.K, GB_K);
+    APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
+    APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
+    const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);
+    if (p.trans_out) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(nblk), dim3(256), 0, s, p);
+  } else {
+    const int nblk = ceil_div(p.M, 64) * ceil_div(p.N, 64);
+    if (p.trans_out) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(nblk), dim3(256), 0, s, p);
+  }
+  APE_CHECK_LAUNCH("ape_hip_gemm");
+  return 0;
+}
+
+extern "C" int ape_hip_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out,
+                            int ldo, int M, int N, int K, float alpha, void* stream) {
+  APE_CHECK_ARG(x && W && out && M > 0 && N > 0 && K > 0, "ape_hip_gemv: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  const int nblk = ceil_div(N, 4);
+  if (w_dt == APE_DT_BF16)
+    hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha);
+  else
+    hipLaunchKernelGGL(gemv_kernel<float>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)W, ldw, bias, out, ldo, M, N, K, alpha);
+  APE_CHECK_LAUNCH("ape_hip_gemv");
+  return 0;
+}

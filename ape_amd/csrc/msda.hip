@@ -1,0 +1,217 @@
+// Multi-scale deformable attention sampler (forward only) for gfx950.
+//
+// Replaces ms_deformable_im2col_gpu_kernel (ape/layers/csrc/MsDeformAttn/ms_deform_im2col_cuda.cuh:237-299,
+// bilinear helper :33-84) -- which does not even build for ROCm in the reference (ms_deform_attn.h:32-39)
+// -- and the grid_sample path multi_scale_deformable_attn_pytorch (ape/layers/multi_scale_deform_attn.py:84-124).
+//
+// Thread mapping (M = 8 heads x D = 32 channels, P = 4 points):
+//   one 64-lane wave = 2 queries x 8 heads x 4 lanes; each lane owns 8 consecutive channels of one head,
+//   so every bilinear corner is ONE 16-byte (bf16) load and a wave touches 4 full 64-byte head rows per
+//   corner.  The value tensor (44.7 MB bf16 at 1024^2) is served from L2 / Infinity Cache: query chunks
+//   are assigned to XCDs contiguously so one XCD's L2 only sees one band of every level.
+// The fused variant also does the softmax over the L*P logits and the sampling-location arithmetic
+// (multi_scale_deform_attn.py:278-311) in registers, so locations / weights never touch HBM.
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+#define MS_HEADS 8
+#define MS_D 32
+#define MS_P 4
+
+struct MsdaParams {
+  const void* value; int ldv;
+  const void* loc;      // plain: [Q, M, L, P, 2]
+  const void* attn;     // plain: [Q, M, L, P]
+  const float* offw; int ldoffw;   // fused
+  const float* ref; int refdim;    // fused
+  void* out; int ldout;
+  int S, Q;             // per batch element
+  int H[8], W[8], start[8];
+};
+
+template <typename TV>
+__device__ __forceinline__ void corner_acc(const TV* __restrict__ vbase, int ldv, int idx, float wgt, float acc[8]) {
+  float v[8];
+  ld8<TV>(vbase + (size_t)idx * ldv, v);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = fmaf(wgt, v[c], acc[c]);
+}
+
+// bilinear sample at (x, y) in normalised [0,1] coords of an H x W level (align_corners=False, zero pad),
+// weighted by aw and accumulated into acc
+template <typename TV>
+__device__ __forceinline__ void sample_acc(const TV* __restrict__ vlvl, int ldv, int H, int W, float lx, float ly,
+                                           float aw, float acc[8]) {
+  const float h_im = ly * (float)H - 0.5f;
+  const float w_im = lx * (float)W - 0.5f;
+  if (!(h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W)) return;
+  const float hf = floorf(h_im), wf = floorf(w_im);
+  const int h_low = (int)hf, w_low = (int)wf;
+  const int h_high = h_low + 1, w_high = w_low + 1;
+  const float lh = h_im - hf, lw = w_im - wf;
+  const float hh = 1.f - lh, hw = 1.f - lw;
+  if (h_low >= 0 && w_low >= 0) corner_acc<TV>(vlvl, ldv, h_low * W + w_low, aw * hh * hw, acc);
+  if (h_low >= 0 && w_high <= W - 1) corner_acc<TV>(vlvl, ldv, h_low * W + w_high, aw * hh * lw, acc);
+  if (h_high <= H - 1 && w_low >= 0) corner_acc<TV>(vlvl, ldv, h_high * W + w_low, aw * lh * hw, acc);
+  if (h_high <= H - 1 && w_high <= W - 1) corner_acc<TV>(vlvl, ldv, h_high * W + w_high, aw * lh * lw, acc);
+}
+
+template <typename TV, typename TO, int L, bool FUSED>
+__global__ __launch_bounds__(256) void msda_kernel(const MsdaParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // XCD-aware chunk order: blocks of one XCD (blockIdx % 8) take a contiguous range of query chunks
+  int chunk;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    chunk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int batch = blockIdx.y;
+  const int g = lane >> 2, sub = lane & 3;
+  const int qi = chunk * 8 + wave * 2 + (g >> 3);
+  const int h = g & 7;
+  if (qi >= p.Q) return;
+  const size_t qg = (size_t)batch * p.Q + qi;  // global query row
+  const TV* vb = reinterpret_cast<const TV*>(p.value) + (size_t)batch * p.S * p.ldv + h * MS_D + sub * 8;
+
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+
+  constexpr int LP = L * MS_P;
+  if (FUSED) {
+    // logits + softmax over the L*P samples of this (query, head)
+    const float* lg = p.offw + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
+    float w[LP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < LP; s += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(lg + s);
+      w[s] = t.x; w[s + 1] = t.y; w[s + 2] = t.z; w[s + 3] = t.w;
+      mx = fmaxf(mx, fmaxf(fmaxf(t.x, t.y), fmaxf(t.z, t.w)));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < LP; ++s) { w[s] = expf(w[s] - mx); sum += w[s]; }
+    const float inv = 1.f / sum;
+    const float* of = p.offw + qg * p.ldoffw + h * LP * 2;
+    const float* rf = p.ref + qg * L * p.refdim;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = p.H[l], W = p.W[l];
+      const TV* vl = vb + (size_t)p.start[l] * p.ldv;
+      const float4 o01 = *reinterpret_cast<const float4*>(of + l * 8);
+      const float4 o23 = *reinterpret_cast<const float4*>(of + l * 8 + 4);
+      const float ox[4] = {o01.x, o01.z, o23.x, o23.z};
+      const float oy[4] = {o01.y, o01.w, o23.y, o23.w};
+      const float rx = rf[l * p.refdim], ry = rf[l * p.refdim + 1];
+      float sx, sy;
+      if (p.refdim == 2) {
+        // loc = ref + off / (W, H)                       (multi_scale_deform_attn.py:298-303)
+        sx = 1.f / (float)W; sy = 1.f / (float)H;
+#pragma unroll
+        for (int pt = 0; pt < MS_P; ++pt)
+          sample_acc<TV>(vl, p.ldv, H, W, rx + ox[pt] / (float)W, ry + oy[pt] / (float)H, w[l * MS_P + pt] * inv, acc);
+        (void)sx; (void)sy;
+      } else {
+        // loc = ref_xy + off / P * ref_wh * 0.5          (multi_scale_deform_attn.py:304-311)
+        const float rw = rf[l * p.refdim + 2], rh = rf[l * p.refdim + 3];
+#pragma unroll
+        for (int pt = 0; pt < MS_P; ++pt)
+          sample_acc<TV>(vl, p.ldv, H, W, rx + ox[pt] / (float)MS_P * rw * 0.5f, ry + oy[pt] / (float)MS_P * rh * 0.5f,
+                         w[l * MS_P + pt] * inv, acc);
+      }
+    }
+  } else {
+    const TV* loc = reinterpret_cast<const TV*>(p.loc) + (qg * MS_HEADS + h) * LP * 2;
+    const TV* aw = reinterpret_cast<const TV*>(p.attn) + (qg * MS_HEADS + h) * LP;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      const int H = p.H[l], W = p.W[l];
+      const TV* vl = vb + (size_t)p.start[l] * p.ldv;
+#pragma unroll
+      for (int pt = 0; pt < MS_P; ++pt) {
+        const float lx = ldf<TV>(loc + (l * MS_P + pt) * 2), ly = ldf<TV>(loc + (l * MS_P + pt) * 2 + 1);
+        sample_acc<TV>(vl, p.ldv, H, W, lx, ly, ldf<TV>(aw + l * MS_P + pt), acc);
+      }
+    }
+  }
+  TO* o = reinterpret_cast<TO*>(p.out) + qg * p.ldout + h * MS_D + sub * 8;
+  st8<TO>(o, acc);
+}
+
+template <typename TV, typename TO, bool FUSED>
+static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
+  const dim3 grid(ceil_div(p.Q, 8), B), block(256);
+  switch (L) {
+    case 1: hipLaunchKernelGGL((msda_kernel<TV, TO, 1, FUSED>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((msda_kernel<TV, TO, 2, FUSED>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((msda_kernel<TV, TO, 3, FUSED>), grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((msda_kernel<TV, TO, 4, FUSED>), grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((msda_kernel<TV, TO, 5, FUSED>), grid, block, 0, s, p); break;
+    default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
+  }
+  return 0;
+}
+
+// spatial_shapes / level_start_index are DEVICE int64 tensors in the reference operator; they are tiny and
+// constant per resolution, so the C-ABI takes HOST pointers (the Python shim keeps CPU copies) and bakes
+// them into the kernel argument block -- no dependent device loads in the inner loop.
+static int fill_levels(MsdaParams& p, const int64_t* shapes, const int64_t* starts, int L, int S) {
+  if (L < 1 || L > 5) { ape_set_error("msda: num_levels %d not in 1..5", L); return -1; }
+  int64_t tot = 0;
+  for (int l = 0; l < L; ++l) {
+    p.H[l] = (int)shapes[2 * l]; p.W[l] = (int)shapes[2 * l + 1]; p.start[l] = (int)starts[l];
+    if (p.H[l] <= 0 || p.W[l] <= 0 || starts[l] != tot) { ape_set_error("msda: inconsistent level %d (h=%d w=%d start=%lld)", l, p.H[l], p.W[l], (long long)starts[l]); return -1; }
+    tot += (int64_t)p.H[l] * p.W[l];
+  }
+  if (tot != S) { ape_set_error("msda: sum(h*w)=%lld != num_value=%d", (long long)tot, S); return -1; }
+  return 0;
+}
+
+extern "C" int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const int64_t* spatial_shapes,
+                                              const int64_t* level_start_index, const void* sampling_loc,
+                                              const void* attn_weight, void* out, int ldout, int B, int S, int Q, int L,
+                                              int dt, void* stream) {
+  APE_CHECK_ARG(value && spatial_shapes && level_start_index && sampling_loc && attn_weight && out, "ms_deform_attn_forward: null pointer");
+  APE_CHECK_ARG(B > 0 && S > 0 && Q > 0, "ms_deform_attn_forward: bad sizes");
+  APE_CHECK_ARG(ldv % 8 == 0 && ldout % 8 == 0 && ((uintptr_t)value) % 16 == 0 && ((uintptr_t)out) % 16 == 0,
+                "ms_deform_attn_forward: value/out must be 16-byte aligned with ld %% 8 == 0");
+  MsdaParams p;
+  memset(&p, 0, sizeof(p));
+  p.value = value; p.ldv = ldv; p.loc = sampling_loc; p.attn = attn_weight; p.out = out; p.ldout = ldout; p.S = S; p.Q = Q;
+  if (fill_levels(p, spatial_shapes, level_start_index, L, S)) return -1;
+  int rc;
+  if (dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, false>(p, B, L, (hipStream_t)stream);
+  else rc = launch_msda<float, float, false>(p, B, L, (hipStream_t)stream);
+  if (rc) return rc;
+  APE_CHECK_LAUNCH("ape_hip_ms_deform_attn_forward");
+  return 0;
+}
+
+extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* offw, int ldoffw, const float* ref,
+                                  int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream) {
+  APE_CHECK_ARG(value && spatial_shapes && level_start_index && offw && ref && out, "msda_fused: null pointer");
+  APE_CHECK_ARG(refdim == 2 || refdim == 4, "msda_fused: reference points must have 2 or 4 coordinates, got %d", refdim);
+  APE_CHECK_ARG(B > 0 && S > 0 && Q > 0, "msda_fused: bad sizes");
+  APE_CHECK_ARG(ldv % 8 == 0 && ldout % 8 == 0 && ldoffw % 4 == 0 && ((uintptr_t)value) % 16 == 0 &&
+                    ((uintptr_t)out) % 16 == 0 && ((uintptr_t)offw) % 16 == 0,
+                "msda_fused: alignment (value/out 16 B, ld %% 8; offw 16 B, ld %% 4)");
+  MsdaParams p;
+  memset(&p, 0, sizeof(p));
+  p.value = value; p.ldv = ldv; p.offw = offw; p.ldoffw = ldoffw; p.ref = ref; p.refdim = refdim;
+  p.out = out; p.ldout = ldout; p.S = S; p.Q = Q;
+  if (fill_levels(p, spatial_shapes, level_start_index, L, S)) return -1;
+  int rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (v_dt == APE_DT_BF16 && out_dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, true>(p, B, L, s);
+  else if (v_dt == APE_DT_BF16 && out_dt == APE_DT_F32) rc = launch_msda<bf16_t, float, true>(p, B, L, s);
+  else if (v_dt == APE_DT_F32 && out_dt == APE_DT_F32) rc = launch_msda<float, float, true>(p, B, L, s);
+  else { ape_set_error("msda_fused: unsupported dtype combination v=%d out=%d", v_dt, out_dt); return -1; }
+  if (rc) return rc;
+  APE_CHECK_LAUNCH("ape_hip_msda_fused");
+  return 0;
+}

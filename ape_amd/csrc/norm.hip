@@ -1,0 +1,263 @@
+// LayerNorm / GroupNorm kernels (wave-shuffle reductions, fp32 statistics, two-pass variance).
+//
+// LayerNorm replaces nn.LayerNorm call sites on the hot path (vit_eva_clip.py:29-35,129,264,509,522;
+// detectron2 channel-LN used by SimpleFeaturePyramid vit_eva_clip.py:829-842 -- in our NHWC layout a
+// channel-LN is a row LayerNorm; fuse_helper.py:224-225; detrex BaseTransformerLayer norms;
+// deformable_transformer_vl.py:366,635,644).
+// GroupNorm(32) replaces the neck / mask-head norms (detrex ChannelMapper, config
+// ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py:42-55; deformable_detr_segm_vl.py:115-135)
+// on token-major [HW, C] tensors: statistics over HW x (C/32) per group.
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+__device__ __forceinline__ float ln_act(float x, int act) {
+  if (act == APE_ACT_RELU) return fmaxf(x, 0.f);
+  if (act == APE_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+  return x;
+}
+
+// One wave per row.  NV4 > 0: row cached in registers (C <= NV4*256, C % 4 == 0); NV4 == 0: generic 3-pass.
+template <typename TX, typename TY, typename TA, int NV4>
+__global__ __launch_bounds__(256) void layernorm_kernel(const ApeLayerNormArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const TX* x = reinterpret_cast<const TX*>(p.x) + (size_t)row * p.ldx;
+  TY* y = reinterpret_cast<TY*>(p.y) + (size_t)row * p.ldy;
+  const TA* add = p.add ? reinterpret_cast<const TA*>(p.add) + (size_t)row * p.ldadd : nullptr;
+  TY* y2 = p.y2 ? reinterpret_cast<TY*>(p.y2) + (size_t)row * p.ldy2 : nullptr;
+  const int C = p.C;
+  const float invC = 1.f / (float)C;
+
+  if (NV4 > 0) {
+    float v[NV4 > 0 ? NV4 : 1][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        ld4<TX>(x + c, v[i]);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      } else {
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+      }
+    }
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q = fmaf(d, d, q); }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c < C) {
+        float w4[4], b4[4], o[4];
+        ld4<float>(p.w + c, w4);
+        ld4<float>(p.b + c, b4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ln_act((v[i][r] - mean) * rstd * w4[r] + b4[r], p.act);
+        st4<TY>(y + c, o);
+        if (y2 != nullptr) {
+          float a4[4];
+          ld4<TA>(add + c, a4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a4[r] += o[r];
+          st4<TY>(y2 + c, a4);
+        }
+      }
+    }
+  } else {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ldf<TX>(x + c);
+    const float mean = wave_sum(s) * invC;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = ldf<TX>(x + c) - mean; q = fmaf(d, d, q); }
+    const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+    for (int c = lane; c < C; c += 64) {
+      const float o = ln_act((ldf<TX>(x + c) - mean) * rstd * p.w[c] + p.b[c], p.act);
+      stf<TY>(y + c, o);
+      if (y2 != nullptr) stf<TY>(y2 + c, o + ldf<TA>(add + c));
+    }
+  }
+  for (int c = C + lane; c < p.Cpad; c += 64) {
+    stf<TY>(y + c, 0.f);
+    if (y2 != nullptr) stf<TY>(y2 + c, 0.f);
+  }
+}
+
+template <typename TX, typename TY, typename TA>
+static int launch_ln(const ApeLayerNormArgs& p, hipStream_t s) {
+  const dim3 grid(ceil_div(p.M, 4)), block(256);
+  const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) &&
+                   (((uintptr_t)p.y) % 16 == 0) && (((uintptr_t)p.w) % 16 == 0) && (((uintptr_t)p.b) % 16 == 0) &&
+                   (!p.y2 || ((p.ldadd % 4 == 0) && (p.ldy2 % 4 == 0) && (((uintptr_t)p.add) % 16 == 0) &&
+                              (((uintptr_t)p.y2) % 16 == 0)));
+  if (vec && p.C <= 256) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 1>), grid, block, 0, s, p);
+  else if (vec && p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 2>), grid, block, 0, s, p);
+  else if (vec && p.C <= 1024) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 4>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 0>), grid, block, 0, s, p);
+  return 0;
+}
+
+extern "C" int ape_hip_layernorm(const ApeLayerNormArgs* a, void* stream) {
+  APE_CHECK_ARG(a && a->x && a->y && a->w && a->b, "ape_hip_layernorm: null pointer");
+  APE_CHECK_ARG(a->M > 0 && a->C > 0 && a->Cpad >= a->C, "ape_hip_layernorm: bad shape");
+  APE_CHECK_ARG((a->add == nullptr) == (a->y2 == nullptr), "ape_hip_layernorm: add and y2 go together");
+  const ApeLayerNormArgs p = *a;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = p.x_dt * 4 + p.y_dt * 2 + (p.add ? p.add_dt : p.y_dt);
+  switch (key) {
+    case 0: launch_ln<float, float, float>(p, s); break;
+    case 1: launch_ln<float, float, bf16_t>(p, s); break;
+    case 2: launch_ln<float, bf16_t, float>(p, s); break;
+    case 3: launch_ln<float, bf16_t, bf16_t>(p, s); break;
+    case 4: launch_ln<bf16_t, float, float>(p, s); break;
+    case 5: launch_ln<bf16_t, float, bf16_t>(p, s); break;
+    case 6: launch_ln<bf16_t, bf16_t, float>(p, s); break;
+    case 7: launch_ln<bf16_t, bf16_t, bf16_t>(p, s); break;
+    default: ape_set_error("ape_hip_layernorm: bad dtypes"); return -1;
+  }
+  APE_CHECK_LAUNCH("ape_hip_layernorm");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm(G groups) over token-major x[HW, C]:
+//   pass 1 (gn_partial): per row-chunk (mean, M2) for each group            -> partial[nchunk][G][2]
+//   pass 2 (gn_apply)  : every block re-combines the partials (Chan et al.), normalises its rows,
+//                        optional ReLU, optional residual add AFTER the norm/act is NOT needed by the
+//                        reference; an optional `add` tensor is added BEFORE storing (lateral + memory).
+// C <= 256, C % G == 0, channels per group cg = C/G (8 for the reference), block = 256 threads:
+// thread t owns channel t (C == 256) so loads are fully coalesced (each row = 512 B bf16).
+// ------------------------------------------------------------------------------------------
+#define GN_ROWS_PER_BLOCK 128
+
+template <typename TX>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const TX* __restrict__ x, int ldx, int HW, int C, int G,
+                                                         float* __restrict__ partial) {
+  __shared__ float sh[256];
+  __shared__ float smean[64];
+  const int t = threadIdx.x;
+  const int cg = C / G;
+  const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
+  const int nrows = r1 - r0;
+  float s = 0.f;
+  if (t < C) for (int r = r0; r < r1; ++r) s += ldf<TX>(x + (size_t)r * ldx + t);
+  sh[t] = s;
+  __syncthreads();
+  if (t < G) {
+    float a = 0.f;
+    for (int j = 0; j < cg; ++j) a += sh[t * cg + j];
+    smean[t] = a / (float)(nrows * cg);
+  }
+  __syncthreads();
+  float q = 0.f;
+  if (t < C) {
+    const float m = smean[t / cg];
+    for (int r = r0; r < r1; ++r) { const float d = ldf<TX>(x + (size_t)r * ldx + t) - m; q = fmaf(d, d, q); }
+  }
+  sh[t] = q;
+  __syncthreads();
+  if (t < G) {
+    float a = 0.f;
+    for (int j = 0; j < cg; ++j) a += sh[t * cg + j];
+    partial[((size_t)blockIdx.x * G + t) * 2 + 0] = smean[t];
+    partial[((size_t)blockIdx.x * G + t) * 2 + 1] = a;
+  }
+}
+
+// one 64-lane block per group: lanes stride over the row chunks, Chan-combine, then butterfly-combine
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, int HW, int cg,
+                                                         int G, float eps, float* __restrict__ stats) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  for (int k = lane; k < nchunk; k += 64) {
+    const int rows = min(GN_ROWS_PER_BLOCK, HW - k * GN_ROWS_PER_BLOCK);
+    const float nb = (float)(rows * cg);
+    const float mb = partial[((size_t)k * G + g) * 2 + 0];
+    const float qb = partial[((size_t)k * G + g) * 2 + 1];
+    const float nt = n + nb;
+    const float delta = mb - mean;
+    mean += delta * (nb / nt);
+    m2 += qb + delta * delta * (n * nb / nt);
+    n = nt;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
+    const float nt = n + nb;
+    if (nt > 0.f) {
+      const float delta = mb - mean;
+      // symmetric form so both partners compute the same result
+      mean = (n * mean + nb * mb) / nt;
+      m2 = m2 + qb + delta * delta * (n * nb / nt);
+    }
+    n = nt;
+  }
+  if (lane == 0) {
+    stats[g * 2 + 0] = mean;
+    stats[g * 2 + 1] = rsqrtf(m2 / n + eps);
+  }
+}
+
+template <typename TX, typename TY, typename TA>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TX* __restrict__ x, int ldx, int HW, int C, int G,
+                                                       const float* __restrict__ stats, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int act, const TA* __restrict__ add,
+                                                       int ldadd, TY* __restrict__ y, int ldy) {
+  const int t = threadIdx.x;
+  const int cg = C / G;
+  if (t >= C) return;
+  const float m = stats[(t / cg) * 2 + 0], rs = stats[(t / cg) * 2 + 1];
+  const float wt = w[t] * rs, bt = b[t] - m * rs * w[t];
+  const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
+  for (int r = r0; r < r1; ++r) {
+    float v = fmaf(ldf<TX>(x + (size_t)r * ldx + t), wt, bt);
+    if (add != nullptr) v += ldf<TA>(add + (size_t)r * ldadd + t);
+    if (act == APE_ACT_RELU) v = fmaxf(v, 0.f);
+    stf<TY>(y + (size_t)r * ldy + t, v);
+  }
+}
+
+template <typename TX, typename TY, typename TA>
+static void launch_gn(const ApeGroupNormArgs& p, hipStream_t s) {
+  const int nchunk = ceil_div(p.HW, GN_ROWS_PER_BLOCK);
+  float* stats = p.workspace + (size_t)nchunk * p.G * 2;
+  hipLaunchKernelGGL((gn_partial_kernel<TX>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
+                     p.workspace);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G), dim3(64), 0, s, p.workspace, nchunk, p.HW, p.C / p.G, p.G, p.eps, stats);
+  hipLaunchKernelGGL((gn_apply_kernel<TX, TY, TA>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
+                     stats, p.w, p.b, p.act, (const TA*)p.add, p.ldadd, (TY*)p.y, p.ldy);
+}
+
+extern "C" int ape_hip_groupnorm_workspace_floats(int HW, int G) { return ceil_div(HW, GN_ROWS_PER_BLOCK) * G * 2 + G * 2; }
+
+extern "C" int ape_hip_groupnorm(const ApeGroupNormArgs* a, void* stream) {
+  APE_CHECK_ARG(a && a->x && a->y && a->w && a->b && a->workspace, "ape_hip_groupnorm: null pointer");
+  APE_CHECK_ARG(a->C > 0 && a->C <= 256 && a->G > 0 && a->G <= 64 && a->C % a->G == 0 && a->HW > 0,
+                "ape_hip_groupnorm: need C <= 256, G <= 64, C %% G == 0");
+  const ApeGroupNormArgs p = *a;
+  hipStream_t s = (hipStream_t)stream;
+  const int key = p.x_dt * 4 + p.y_dt * 2 + (p.add ? p.add_dt : p.y_dt);
+  switch (key) {
+    case 0: launch_gn<float, float, float>(p, s); break;
+    case 1: launch_gn<float, float, bf16_t>(p, s); break;
+    case 2: launch_gn<float, bf16_t, float>(p, s); break;
+    case 3: launch_gn<float, bf16_t, bf16_t>(p, s); break;
+    case 4: launch_gn<bf16_t, float, float>(p, s); break;
+    case 5: launch_gn<bf16_t, float, bf16_t>(p, s); break;
+    case 6: launch_gn<bf16_t, bf16_t, float>(p, s); break;
+    case 7: launch_gn<bf16_t, bf16_t, bf16_t>(p, s); break;
+    default: ape_set_error("ape_hip_groupnorm: bad dtypes"); return -1;
+  }
+  APE_CHECK_LAUNCH("ape_hip_groupnorm");
+  return 0;
+}

@@ -1,0 +1,238 @@
+"""Tensor-level wrappers around the C-ABI (include/ape_hip.h): torch tensors in, device pointers out.
+
+PyTorch is used here only as the allocator / stream provider.  Every function launches on
+`torch.cuda.current_stream()`, never synchronises, and raises if a tensor is not on a HIP device or
+the library is missing -- there is no CPU or PyTorch fallback in the product path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, ACT_SWIGLU, DT_BF16, DT_F32, MASK_NONE,  # noqa: F401
+                   MASK_ZERO_INPUT, MASK_ZERO_OUTPUT)
+
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"ape_amd: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ape_amd.ops: tensor is not on a HIP device; the HIP path has no CPU fallback")
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor(t, name):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"ape_amd.ops: {name} must be 2-D with unit inner stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t
+
+
+def _f32vec(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f"ape_amd.ops: {name} must be a contiguous float32 tensor")
+    return t
+
+
+def _ld(t):
+    # leading dimension of a 2-D row-major view (a single row may report any stride)
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None):
+    """C = epi(alpha * a @ w.T); see ApeGemmArgs in include/ape_hip.h for the epilogue order.
+
+    a [M,K], w [N,K] (same dtype).  rope = (cos, sin, rows, head_dim, cols).  trans_out returns C^T as
+    [N, m_pad or M].  act=ACT_SWIGLU expects interleaved (gate, up) rows in w and returns N/2 columns.
+    """
+    _dev(a, w, bias, out, residual, rowmask)
+    _rowmajor(a, "a"), _rowmajor(w, "w")
+    if a.dtype != w.dtype:
+        raise TypeError("ape_amd.ops.gemm: a and w must share a dtype")
+    M, K = a.shape
+    N, Kw = w.shape
+    if K != Kw:
+        raise ValueError(f"ape_amd.ops.gemm: K mismatch {K} vs {Kw}")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out is None:
+        odt = out_dtype or a.dtype
+        if trans_out:
+            ld = m_pad or M
+            out = torch.zeros((N, ld), dtype=odt, device=a.device) if ld != M else torch.empty((N, M), dtype=odt, device=a.device)
+        else:
+            out = torch.empty((M, n_out), dtype=odt, device=a.device)
+    _rowmajor(out, "out")
+    args = _lib.GemmArgs()
+    args.A, args.W, args.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = _f32vec(bias, "bias").data_ptr() if bias is not None else None
+    args.M, args.N, args.K = M, N, K
+    args.lda, args.ldw, args.ldc = _ld(a), _ld(w), _ld(out)
+    args.in_dt, args.out_dt = _dt(a), _dt(out)
+    if residual is not None:
+        _rowmajor(residual, "residual")
+        args.residual, args.ldr, args.res_dt = residual.data_ptr(), _ld(residual), _dt(residual)
+    if rowmask is not None:
+        if rowmask.dtype not in (torch.uint8, torch.bool) or not rowmask.is_contiguous() or rowmask.numel() != M:
+            raise ValueError("ape_amd.ops.gemm: rowmask must be a contiguous uint8/bool [M] tensor")
+        args.rowmask = rowmask.data_ptr()
+    args.mask_mode = mask_mode if rowmask is not None else MASK_NONE
+    args.act, args.trans_out = act, 1 if trans_out else 0
+    if rope is not None:
+        cos, sin, rows, hd, cols = rope
+        _dev(cos, sin)
+        args.rope_cos, args.rope_sin = _f32vec(cos, "rope cos").data_ptr(), _f32vec(sin, "rope sin").data_ptr()
+        args.rope_rows, args.rope_hd, args.rope_cols = rows, hd, cols
+    args.alpha, args.clamp = float(alpha), float(clamp)
+    _lib.check(_lib.load().ape_hip_gemm(ctypes.byref(args), _stream()), "ape_hip_gemm")
+    return out
+
+
+def gemv(x, w, bias=None, alpha=1.0):
+    """out[m,n] = alpha * x[m,:] . w[n,:] + bias[n]; x fp32 [M,K] (M small), w f32/bf16 [N,K] -> fp32 [M,N]."""
+    _dev(x, w, bias)
+    _rowmajor(x, "x"), _rowmajor(w, "w")
+    if x.dtype != torch.float32:
+        raise TypeError("ape_amd.ops.gemv: x must be float32")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    rc = _lib.load().ape_hip_gemv(_p(x), _ld(x), _p(w), _ld(w), _dt(w), _p(_f32vec(bias, "bias")), _p(out), N, M, N, K,
+                                 float(alpha), _stream())
+    _lib.check(rc, "ape_hip_gemv")
+    return out
+
+
+def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None, add=None, out2=None):
+    """Row LayerNorm; returns y, or (y, y + add) when `add` is given.  Columns C..cpad-1 of y are zeroed."""
+    _dev(x, w, b, out, add, out2)
+    _rowmajor(x, "x")
+    M, C = x.shape
+    cpad = cpad or C
+    odt = out_dtype or x.dtype
+    if out is None:
+        out = torch.empty((M, cpad), dtype=odt, device=x.device)
+    args = _lib.LayerNormArgs()
+    args.x, args.w, args.b, args.y = x.data_ptr(), _f32vec(w, "w").data_ptr(), _f32vec(b, "b").data_ptr(), out.data_ptr()
+    args.M, args.C, args.Cpad = M, C, cpad
+    args.ldx, args.ldy = _ld(x), _ld(out)
+    args.x_dt, args.y_dt, args.act, args.eps = _dt(x), _dt(out), act, float(eps)
+    if add is not None:
+        _rowmajor(add, "add")
+        if out2 is None:
+            out2 = torch.empty((M, cpad), dtype=out.dtype, device=x.device)
+        args.add, args.y2, args.ldadd, args.ldy2, args.add_dt = add.data_ptr(), out2.data_ptr(), _ld(add), _ld(out2), _dt(add)
+    _lib.check(_lib.load().ape_hip_layernorm(ctypes.byref(args), _stream()), "ape_hip_layernorm")
+    return (out, out2) if add is not None else out
+
+
+def groupnorm(x, w, b, groups, eps, *, act=ACT_NONE, add=None, out=None, out_dtype=None):
+    """GroupNorm over a token-major map x[HW, C]: y = act(GN(x) * w + b + add)."""
+    _dev(x, w, b, add, out)
+    _rowmajor(x, "x")
+    HW, C = x.shape
+    if out is None:
+        out = torch.empty((HW, C), dtype=out_dtype or x.dtype, device=x.device)
+    lib = _lib.load()
+    ws = torch.empty((lib.ape_hip_groupnorm_workspace_floats(HW, groups),), dtype=torch.float32, device=x.device)
+    args = _lib.GroupNormArgs()
+    args.x, args.w, args.b, args.y = x.data_ptr(), _f32vec(w, "w").data_ptr(), _f32vec(b, "b").data_ptr(), out.data_ptr()
+    args.workspace = ws.data_ptr()
+    args.HW, args.C, args.G = HW, C, groups
+    args.ldx, args.ldy = _ld(x), _ld(out)
+    args.x_dt, args.y_dt, args.act, args.eps = _dt(x), _dt(out), act, float(eps)
+    if add is not None:
+        _rowmajor(add, "add")
+        args.add, args.ldadd, args.add_dt = add.data_ptr(), _ld(add), _dt(add)
+    _lib.check(lib.ape_hip_groupnorm(ctypes.byref(args), _stream()), "ape_hip_groupnorm")
+    return out
+
+
+def _levels(spatial_shapes, level_start_index):
+    if torch.is_tensor(spatial_shapes):
+        spatial_shapes = spatial_shapes.detach().cpu().tolist()
+    if torch.is_tensor(level_start_index):
+        level_start_index = level_start_index.detach().cpu().tolist()
+    L = len(spatial_shapes)
+    flat = [int(v) for hw in spatial_shapes for v in hw]
+    shp = (ctypes.c_int64 * (2 * L))(*flat)
+    st = (ctypes.c_int64 * L)(*[int(v) for v in level_start_index])
+    return shp, st, L
+
+
+def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step=64):
+    """Drop-in for torch.ops.ape.ms_deform_attn_forward (ape/layers/csrc/vision.cpp:76-79).
+
+    value [B,S,8,32], sampling_loc [B,Q,8,L,4,2], attn_weight [B,Q,8,L,4] (same dtype) -> [B,Q,256].
+    """
+    _dev(value, sampling_loc, attn_weight)
+    if not (value.is_contiguous() and sampling_loc.is_contiguous() and attn_weight.is_contiguous()):
+        raise ValueError("ms_deform_attn_forward: inputs must be contiguous")  # ms_deform_attn_cuda.cu:29-33
+    if not (value.dtype == sampling_loc.dtype == attn_weight.dtype):
+        raise TypeError("ms_deform_attn_forward: value / sampling_loc / attn_weight must share a dtype")
+    B, S, M, D = value.shape
+    Q = sampling_loc.shape[1]
+    if M != 8 or D != 32 or sampling_loc.shape[4] != 4:
+        raise ValueError("ms_deform_attn_forward: built for 8 heads x 32 channels x 4 points")
+    shp, st, L = _levels(spatial_shapes, level_start_index)
+    if sampling_loc.shape[3] != L:
+        raise ValueError("ms_deform_attn_forward: num_levels mismatch")
+    out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
+    rc = _lib.load().ape_hip_ms_deform_attn_forward(_p(value), M * D, shp, st, _p(sampling_loc), _p(attn_weight), _p(out),
+                                                   M * D, B, S, Q, L, _dt(value), _stream())
+    _lib.check(rc, "ape_hip_ms_deform_attn_forward")
+    return out
+
+
+def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, out_dtype=None, out=None):
+    """Fused softmax + sampling-location + bilinear gather (multi_scale_deform_attn.py:278-348).
+
+    value [batch*S, >=256] (row-major view), offw [batch*Q, 8*L*4*3] fp32 (offsets then logits),
+    ref [batch*Q, L, 2|4] fp32 -> [batch*Q, 256].
+    """
+    _dev(value, offw, ref, out)
+    _rowmajor(value, "value"), _rowmajor(offw, "offw")
+    if offw.dtype != torch.float32 or ref.dtype != torch.float32 or not ref.is_contiguous():
+        raise TypeError("ape_amd.ops.msda_fused: offw / ref must be float32 (ref contiguous)")
+    shp, st, L = _levels(spatial_shapes, level_start_index)
+    S = value.shape[0] // batch
+    Q = offw.shape[0] // batch
+    if offw.shape[1] != 8 * L * 4 * 3 or ref.shape[-2] != L:
+        raise ValueError("ape_amd.ops.msda_fused: offw/ref shape mismatch")
+    if out is None:
+        out = torch.empty((batch * Q, 256), dtype=out_dtype or value.dtype, device=value.device)
+    rc = _lib.load().ape_hip_msda_fused(_p(value), _ld(value), _dt(value), shp, st, _p(offw), _ld(offw), _p(ref),
+                                       ref.shape[-1], _p(out), _ld(out), _dt(out), batch, S, Q, L, _stream())
+    _lib.check(rc, "ape_hip_msda_fused")
+    return out
+
+
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None):
+    """softmax(scale * q k^T) v per (window, head).  q,k: [batch*n, >=heads*head_dim] views; vt: V transposed
+    [heads*head_dim, >= round_up(batch*n, 64)] (finite padding); returns [batch*n, heads*head_dim]."""
+    _dev(q, k, vt, out)
+    _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(vt, "vt")
+    if not (q.dtype == k.dtype == vt.dtype):
+        raise TypeError("ape_amd.ops.attention: q/k/vt must share a dtype")
+    if out is None:
+        out = torch.empty((batch * n, heads * head_dim), dtype=q.dtype, device=q.device)
+    rc = _lib.load().ape_hip_attention(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, heads,
+                                      head_dim, float(scale), _dt(q), _stream())
+    _lib.check(rc, "ape_hip_attention")
+    return out

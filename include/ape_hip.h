@@ -1,0 +1,163 @@
+/*
+ * ape_hip.h -- C-ABI of libape_hip.so: the MI355X (gfx950) kernels behind the APE-L_D forward pass.
+ *
+ * This is the drop-in boundary for the hot path named in BASELINE.json.
+ * Every entry point takes plain device pointers + sizes + a hipStream_t (passed as void*), never
+ * allocates, never synchronises, never takes ownership.  Return value: 0 = launched, negative =
+ * argument/launch error with a message available from ape_hip_last_error() (thread local).
+ *
+ * dtype codes: APE_DT_F32 = 0, APE_DT_BF16 = 1 (raw bfloat16 bits, uint16_t).
+ * All tensors are row-major with an explicit leading dimension in ELEMENTS.
+ *
+ * The reference interface each entry point replaces is cited next to it (paths relative to the
+ * reference repository shenyunhang/APE).
+ */
+#ifndef APE_HIP_H
+#define APE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APE_DT_F32 0
+#define APE_DT_BF16 1
+
+#define APE_ACT_NONE 0
+#define APE_ACT_RELU 1
+#define APE_ACT_GELU 2   /* exact erf GELU (nn.GELU default) */
+#define APE_ACT_SWIGLU 3 /* interleaved (gate,up) columns -> silu(gate)*up, N/2 outputs */
+#define APE_ACT_SILU 4
+
+#define APE_MASK_NONE 0
+#define APE_MASK_ZERO_INPUT 1  /* masked rows behave as if the A row were zero (out = bias) */
+#define APE_MASK_ZERO_OUTPUT 2 /* masked rows are written as zero (value.masked_fill)      */
+
+const char* ape_hip_last_error(void);
+int ape_hip_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM:  C[M,N] = epi(alpha * A[M,K] . W[N,K]^T)     (nn.Linear weight layout, K contiguous)
+ * Replaces F.linear / nn.Linear / 1x1 Conv2d / PatchEmbed / ConvTranspose2d(k2,s2) contractions:
+ *   ape/modeling/backbone/vit_eva_clip.py:125-132 (SwiGLU), :225-232 (q/k/v), :264-268 (proj),
+ *   ape/modeling/backbone/utils_eva02.py:212-216 (PatchEmbed), vit_eva_clip.py:806-842 (FPN convs),
+ *   ape/layers/multi_scale_deform_attn.py:268-277,353 (value/offset/weight/output proj),
+ *   ape/layers/fuse_helper.py:70-73 (VL projections), ape/layers/vision_language_align.py:36-49.
+ * epilogue order: x = alpha*acc ; rowmask(ZERO_INPUT) ; + bias[n] ; RoPE (pairs) ; act ;
+ *                 clamp(+-clamp) ; + residual[m,n] ; rowmask(ZERO_OUTPUT) ; store (out_dt).
+ * bf16 inputs: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W.  trans_out writes C^T[N][M]
+ * (ldc = leading dimension of C^T) and supports bias + activation only.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ApeGemmArgs {
+  const void* A;          /* [M, lda] in_dt                               */
+  const void* W;          /* [N, ldw] in_dt                               */
+  void* C;                /* [M, ldc] (or [N, ldc] if trans_out) out_dt   */
+  const float* bias;      /* [N] fp32 or NULL                             */
+  const void* residual;   /* [M, ldr] res_dt or NULL                      */
+  const uint8_t* rowmask; /* [M] or NULL                                  */
+  const float* rope_cos;  /* [rope_rows, rope_hd] fp32 or NULL            */
+  const float* rope_sin;
+  int32_t M, N, K;
+  int32_t lda, ldw, ldc, ldr;
+  int32_t in_dt, out_dt, res_dt;
+  int32_t act;
+  int32_t mask_mode;
+  int32_t trans_out;
+  int32_t rope_rows, rope_hd, rope_cols; /* rotate columns n < rope_cols; table row = m % rope_rows */
+  int32_t vec_ok;                        /* filled by the launcher */
+  float alpha;
+  float clamp; /* <= 0: no clamp */
+} ApeGemmArgs;
+int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
+
+/* out[m][n] = alpha * x[m,:] . W[n,:] + bias[n], fp32 x/out, W f32 or bf16; for M <= a few rows
+ * (the L=1 language side of ape/layers/fuse_helper.py:70-73,160-161). */
+int ape_hip_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out, int ldo,
+                 int M, int N, int K, float alpha, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim: y = (x-mean)/sqrt(var+eps)*w + b  [act]  ; optional y2 = y + add
+ * Replaces nn.LayerNorm / detectron2 channel-LN / ffn_ln / inner_attn_ln:
+ *   vit_eva_clip.py:29-35,509,264,129 ; detectron2 get_norm("LN") used at vit_eva_clip.py:829-842;
+ *   fuse_helper.py:224-225 ; detrex BaseTransformerLayer norms.
+ * Columns C..Cpad-1 of y are written as zero (K padding for the next GEMM).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ApeLayerNormArgs {
+  const void* x; /* [M, ldx] x_dt */
+  const float* w; /* [C] */
+  const float* b; /* [C] */
+  void* y;       /* [M, ldy] y_dt */
+  const void* add; /* optional [M, ldadd] add_dt: y2 = y + add */
+  void* y2;        /* optional [M, ldy2] y_dt */
+  int32_t M, C, Cpad;
+  int32_t ldx, ldy, ldadd, ldy2;
+  int32_t x_dt, y_dt, add_dt;
+  int32_t act;
+  float eps;
+} ApeLayerNormArgs;
+int ape_hip_layernorm(const ApeLayerNormArgs* args, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm(G) on a token-major map x[HW, C] (NHWC): y = act(GN(x)*w + b + add)
+ * Replaces nn.GroupNorm(32, 256) in detrex ChannelMapper (neck; config
+ * ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py:42-55) and detectron2 get_norm("GN") in the
+ * mask head (ape/modeling/ape_deta/deformable_detr_segm_vl.py:115-135, used at :741-747).
+ * workspace: ape_hip_groupnorm_workspace_floats(HW, G) fp32 scratch.  C <= 256.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ApeGroupNormArgs {
+  const void* x;   /* [HW, ldx] x_dt */
+  const float* w;  /* [C] */
+  const float* b;  /* [C] */
+  void* y;         /* [HW, ldy] y_dt */
+  const void* add; /* optional [HW, ldadd] add_dt, added after the affine, before the activation */
+  float* workspace;
+  int32_t HW, C, G;
+  int32_t ldx, ldy, ldadd;
+  int32_t x_dt, y_dt, add_dt;
+  int32_t act; /* APE_ACT_NONE or APE_ACT_RELU */
+  float eps;
+} ApeGroupNormArgs;
+int ape_hip_groupnorm_workspace_floats(int HW, int G);
+int ape_hip_groupnorm(const ApeGroupNormArgs* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward only.
+ * ape_hip_ms_deform_attn_forward is the replacement for the reference operator
+ *   torch.ops.ape.ms_deform_attn_forward  (ape/layers/csrc/vision.cpp:76-79,
+ *   ape/layers/csrc/MsDeformAttn/ms_deform_attn.h:22-40, ms_deform_attn_cuda.cu:21-81,
+ *   kernel ms_deform_im2col_cuda.cuh:237-299) and of the pure-PyTorch path
+ *   multi_scale_deformable_attn_pytorch (ape/layers/multi_scale_deform_attn.py:84-124).
+ *   value [B, S, M, D] (row stride ldv elements per spatial position), spatial_shapes [L,2] int64
+ *   (h,w), level_start_index [L] int64, sampling_loc [B,Q,M,L,P,2] (x,y in [0,1]),
+ *   attn_weight [B,Q,M,L,P]  ->  out [B,Q,M*D].   M = 8 heads, D = 32, P = 4, L <= 8.
+ *   value/sampling_loc/attn_weight/out share `dt`.
+ * ape_hip_msda_fused additionally folds multi_scale_deform_attn.py:278-311 (softmax over L*P,
+ *   sampling-location arithmetic for 2-d and 4-d reference points) into the sampler:
+ *   offw [B*Q, ldoffw] fp32: columns [0, M*L*P*2) raw sampling offsets, then M*L*P raw logits;
+ *   ref [B*Q, L, refdim] fp32.
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const int64_t* spatial_shapes,
+                                   const int64_t* level_start_index, const void* sampling_loc,
+                                   const void* attn_weight, void* out, int ldout, int B, int S, int Q, int L,
+                                   int dt, void* stream);
+int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const float* offw, int ldoffw, const float* ref,
+                       int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scaled-dot-product attention (non causal, no mask): O = softmax(scale * Q K^T) V
+ * Replaces F.scaled_dot_product_attention at vit_eva_clip.py:261-263 (16 heads x 64, windows of
+ * 1024 tokens or 4096 global) and nn.MultiheadAttention's core in the decoder self-attention
+ * (detrex MultiheadAttention, deformable_transformer_vl.py:141-146; 8 heads x 32, 900 queries).
+ *   Q,K: [B*N, ld] with head h at columns h*HD..; Vt: [H*HD, ldvt] = V transposed (token index
+ *   b*N + key along the contiguous axis; must be readable and finite up to the next multiple of 64
+ *   keys); O: [B*N, ldo].  HD in {32, 64}.
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                      int B, int N, int H, int HD, float scale, int dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APE_HIP_H */

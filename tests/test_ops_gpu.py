@@ -1,0 +1,232 @@
+"""-m gpu parity tests: every HIP kernel (through the C-ABI) vs its torch fp32 definition (tests/ref_ops.py)."""
+import math
+
+import pytest
+import torch
+
+import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+import os
+
+# APE_TEST_SELFCHECK=1 runs this file on CPU with ops := ref_ops (validates the test harness itself)
+SELF = os.environ.get("APE_TEST_SELFCHECK") == "1"
+DEV = "cpu" if SELF else "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if SELF:
+        return ref_ops
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import ape_amd.ops as ops
+    from ape_amd import _lib
+
+    _lib.load()
+    return ops
+
+
+def relerr(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def rnd(*shape, dtype=torch.float32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+TOL = {torch.bfloat16: 6e-3, torch.float32: 2e-5}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (4096, 1024, 1024), (900, 2048, 256), (1000, 130, 64), (333, 8, 256), (87296, 480, 256)])
+def test_gemm_plain(ops, dtype, M, N, K):
+    if dtype == torch.float32 and M * N * K > 2e9:
+        pytest.skip("f32 validation kernel: keep the case small")
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias = rnd(N, seed=3)
+    for odt in (dtype, torch.float32):
+        got = ops.gemm(a, w, bias, out_dtype=odt)
+        ref = ref_ops.gemm(a, w, bias, out_dtype=odt)
+        e = relerr(got, ref)
+        print(f"gemm {dtype} M{M} N{N} K{K} out={odt}: relerr {e:.3e}")
+        assert e < (TOL[torch.bfloat16] if odt == torch.bfloat16 else 2e-4 if dtype == torch.bfloat16 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 1100, 384, 320 if dtype == torch.float32 else 320 + 0
+    K = 320
+    a, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, scale=K ** -0.5, seed=2)
+    bias = rnd(N, seed=3)
+    res32, res16 = rnd(M, N, seed=4), rnd(M, N, dtype=torch.bfloat16, seed=5)
+    mask = (torch.arange(M) % 7 == 3).to(DEV)
+    cases = {
+        "relu": dict(act=ref_ops.ACT_RELU),
+        "gelu": dict(act=ref_ops.ACT_GELU),
+        "res32": dict(residual=res32, out_dtype=torch.float32),
+        "res16": dict(residual=res16, out_dtype=torch.bfloat16),
+        "alpha_clamp": dict(alpha=0.37, clamp=0.8, out_dtype=torch.float32),
+        "mask_in": dict(rowmask=mask, mask_mode=ref_ops.MASK_ZERO_INPUT, out_dtype=torch.float32),
+        "mask_out": dict(rowmask=mask, mask_mode=ref_ops.MASK_ZERO_OUTPUT, out_dtype=torch.float32),
+        "swiglu": dict(act=ref_ops.ACT_SWIGLU, out_dtype=torch.float32),
+        "trans": dict(trans_out=True, m_pad=1152, out_dtype=dtype),
+        "nobias_trans_gelu": dict(trans_out=True, act=ref_ops.ACT_GELU, out_dtype=torch.float32),
+    }
+    if dtype == torch.float32:
+        cases.pop("res16")
+    for name, kw in cases.items():
+        b = None if name.startswith("nobias") else bias
+        got = ops.gemm(a, w, b, **kw)
+        ref = ref_ops.gemm(a, w, b, **kw)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        e = relerr(got, ref)
+        print(f"gemm[{name}] {dtype}: relerr {e:.3e}")
+        odt = kw.get("out_dtype", dtype)
+        assert e < (TOL[torch.bfloat16] if odt == torch.bfloat16 else 3e-4 if dtype == torch.bfloat16 else 2e-5), name
+    # RoPE epilogue: 2048 rotated columns of 3072, table rows cycle every 100 rows
+    N2 = 3 * 256
+    w2 = rnd(N2, K, dtype=dtype, scale=K ** -0.5, seed=6)
+    cos, sin = rnd(100, 64, seed=7), rnd(100, 64, seed=8)
+    kw = dict(rope=(cos, sin, 100, 64, 512), out_dtype=torch.float32)
+    e = relerr(ops.gemm(a, w2, rnd(N2, seed=9), **kw), ref_ops.gemm(a, w2, rnd(N2, seed=9), **kw))
+    print(f"gemm[rope] {dtype}: relerr {e:.3e}")
+    assert e < 3e-4
+
+
+def test_gemm_into_view(ops):
+    """write into a column slice of a wider buffer (ldc > N) and read A from a strided view"""
+    M, N, K = 512, 256, 128
+    big = rnd(M, 3 * K, dtype=torch.bfloat16, seed=1)
+    a = big[:, K:2 * K]
+    w = rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=2)
+    out = torch.zeros(M, 1024, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, w, None, out=out[:, 256:512])
+    ref = ref_ops.gemm(a, w, None)
+    assert relerr(out[:, 256:512], ref) < TOL[torch.bfloat16]
+    assert out[:, :256].abs().max().item() == 0 and out[:, 512:].abs().max().item() == 0
+
+
+def test_gemv(ops):
+    x = rnd(3, 1024, seed=1)
+    for dt in (torch.float32, torch.bfloat16):
+        w = rnd(2048, 1024, dtype=dt, scale=1 / 32, seed=2)
+        b = rnd(2048, seed=3)
+        e = relerr(ops.gemv(x, w, b, alpha=0.5), ref_ops.gemv(x, w, b, alpha=0.5))
+        print(f"gemv {dt}: {e:.3e}")
+        assert e < 2e-5
+
+
+@pytest.mark.parametrize("C,cpad", [(256, 256), (512, 512), (1024, 1024), (2730, 2752), (100, 104)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+def test_layernorm(ops, C, cpad, xdt, ydt):
+    M = 1037
+    buf = rnd(M, cpad + 8, dtype=xdt, seed=1) * 2 + 0.5
+    x = buf[:, :C]
+    w, b = rnd(C, seed=2) + 1, rnd(C, seed=3)
+    for act in (ref_ops.ACT_NONE, ref_ops.ACT_GELU):
+        got = ops.layernorm(x, w, b, 1e-6, out_dtype=ydt, cpad=cpad, act=act)
+        ref = ref_ops.layernorm(x, w, b, 1e-6, out_dtype=ydt, cpad=cpad, act=act)
+        e = relerr(got, ref)
+        print(f"layernorm C{C} {xdt}->{ydt} act{act}: {e:.3e}")
+        assert got.shape == (M, cpad) and e < TOL[ydt] * 1.5
+        if cpad > C:
+            assert got[:, C:].abs().max().item() == 0
+    add = rnd(M, C, dtype=ydt, seed=4)
+    g1, g2 = ops.layernorm(x, w, b, 1e-5, out_dtype=ydt, cpad=cpad, add=add)
+    r1, r2 = ref_ops.layernorm(x, w, b, 1e-5, out_dtype=ydt, cpad=cpad, add=add)
+    assert relerr(g1, r1) < TOL[ydt] * 1.5 and relerr(g2, r2) < TOL[ydt] * 1.5
+
+
+@pytest.mark.parametrize("HW", [256, 5000, 65536])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+def test_groupnorm(ops, HW, xdt, ydt):
+    x = rnd(HW, 256, dtype=xdt, seed=1) * 1.7 + 3.0  # large mean: exercises the two-pass statistics
+    w, b = rnd(256, seed=2) + 1, rnd(256, seed=3)
+    add = rnd(HW, 256, dtype=ydt, seed=4)
+    for kw in (dict(), dict(act=ref_ops.ACT_RELU), dict(add=add)):
+        got = ops.groupnorm(x, w, b, 32, 1e-5, out_dtype=ydt, **kw)
+        ref = ref_ops.groupnorm(x, w, b, 32, 1e-5, out_dtype=ydt, **kw)
+        e = relerr(got, ref)
+        print(f"groupnorm HW{HW} {xdt}->{ydt} {list(kw)}: {e:.3e}")
+        assert e < TOL[ydt] * 1.5
+
+
+def _msda_inputs(shapes, Q, refdim, dtype, seed=0, batch=1):
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+    value = rnd(batch * S, 256, dtype=dtype, seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    offw = torch.cat([torch.randn(batch * Q, 8 * L * 4 * 2, generator=g) * 3.0, torch.randn(batch * Q, 8 * L * 4, generator=g) * 2.0], 1).to(DEV)
+    if refdim == 2:
+        ref = torch.rand(batch * Q, L, 2, generator=g) * 1.2 - 0.1  # some out-of-range points
+    else:
+        ref = torch.cat([torch.rand(batch * Q, L, 2, generator=g), torch.rand(batch * Q, L, 2, generator=g) * 0.5], -1)
+    return value, shapes, starts, offw, ref.to(DEV).contiguous(), S
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("refdim", [2, 4])
+@pytest.mark.parametrize("shapes,Q", [([(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], 341), ([(32, 20), (16, 10), (8, 5), (4, 3)], 900),
+                                      ([(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)], 20000)])
+def test_msda_fused(ops, dtype, refdim, shapes, Q):
+    value, shapes, starts, offw, ref, S = _msda_inputs(shapes, Q, refdim, dtype)
+    got = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=torch.float32 if dtype == torch.float32 else dtype)
+    want = ref_ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=torch.float32)
+    e = relerr(got, want)
+    print(f"msda_fused {dtype} refdim{refdim} L{len(shapes)} Q{Q}: {e:.3e}")
+    assert e < (TOL[torch.bfloat16] if dtype == torch.bfloat16 else 1e-4)
+    if dtype == torch.bfloat16:
+        got32 = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=torch.float32)
+        assert relerr(got32, want) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_ms_deform_attn_forward_operator(ops, dtype):
+    """the reference operator signature (ape/layers/csrc/vision.cpp:76-79) incl. batch > 1"""
+    shapes = [(24, 32), (12, 16), (6, 8), (3, 4), (2, 2)]
+    B, Q = 2, 517
+    S = sum(h * w for h, w in shapes)
+    value = rnd(B, S, 8, 32, dtype=dtype, seed=1)
+    g = torch.Generator().manual_seed(3)
+    loc = (torch.rand(B, Q, 8, 5, 4, 2, generator=g) * 1.2 - 0.1).to(dtype).to(DEV)
+    aw = torch.rand(B, Q, 8, 20, generator=g).softmax(-1).reshape(B, Q, 8, 5, 4).to(dtype).to(DEV)
+    ss = torch.tensor(shapes, dtype=torch.long, device=DEV)
+    lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+    got = ops.ms_deform_attn_forward(value, ss, lsi, loc, aw, 64)
+    want = ref_ops.ms_deform_attn_forward(value, ss, lsi, loc, aw, 64)
+    e = relerr(got, want)
+    print(f"ms_deform_attn_forward {dtype}: {e:.3e}")
+    assert got.shape == (B, Q, 256) and e < (TOL[torch.bfloat16] if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,N,H,HD", [(4, 1024, 16, 64), (1, 4096, 16, 64), (1, 900, 8, 32), (2, 200, 3, 64), (1, 77, 2, 32)])
+def test_attention(ops, dtype, B, N, H, HD):
+    if dtype == torch.float32 and N > 2048:
+        pytest.skip("f32 validation kernel: keep the case small")
+    E = H * HD
+    qk = rnd(B * N, 2 * E + 64, dtype=dtype, seed=1)
+    q, k = qk[:, :E], qk[:, E:2 * E]
+    npad = (B * N + 63) // 64 * 64
+    vt = torch.zeros(E, npad, dtype=dtype, device=DEV)
+    vt[:, : B * N] = rnd(E, B * N, dtype=dtype, seed=2)
+    scale = HD ** -0.5
+    got = ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
+    want = ref_ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
+    e = relerr(got, want)
+    print(f"attention {dtype} B{B} N{N} H{H} HD{HD}: {e:.3e}")
+    assert e < (1e-2 if dtype == torch.bfloat16 else 2e-5)
+    # peaked softmax (forces the online-softmax rescale path): one dominant key per query row
+    qs = q.clone()
+    qs[::3] *= 12.0
+    got = ops.attention(qs, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
+    want = ref_ops.attention(qs, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
+    e = relerr(got, want)
+    print(f"attention(peaked) {dtype}: {e:.3e}")
+    assert e < (2e-2 if dtype == torch.bfloat16 else 2e-5)
