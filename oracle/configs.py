@@ -1,0 +1,29 @@
+"""Model-size configurations shared by the oracle, the reference runner and the tests.
+
+"L_D" is APE-L_D (configs/common/backbone/vitl_eva02_clip.py:9-48 + the ape_deta L_D config); "tiny" and
+"small" keep every structural feature (windowed + global RoPE attention, sub-LN, SwiGLU, SimpleFPN, 5 levels,
+VL fusion, two-stage selection with ambiguous heads, 8x32 deformable attention) at sizes a CPU finishes in
+seconds.
+"""
+
+CONFIGS = {
+    # 16x16 tokens, windows of 8x8, 5456 encoder tokens
+    "tiny": dict(img_size=256, embed_dim=128, depth=3, num_heads=2, window_size=8, pretrain_img_size=112,
+                 enc_layers=2, dec_layers=2, num_queries=300, topk_eval=50),
+    # 32x32 tokens, windows of 16x16, 21824 encoder tokens
+    "small": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224,
+                  enc_layers=3, dec_layers=3, num_queries=900, topk_eval=100),
+    "L_D": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
+                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=100),
+    "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
+                     enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
+}
+
+
+def window_block_indexes(depth):
+    """every third block is global: windowed = {0,1,3,4,...} (vitl_eva02_clip.py:21-28)"""
+    return [i for i in range(depth) if i % 3 != 2]
+
+
+def swiglu_hidden(embed_dim):
+    return int(embed_dim * (4 * 2 / 3))  # vit_eva_clip.py:450: int(dim * mlp_ratio) -> 2730 for 1024

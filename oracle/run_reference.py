@@ -1,0 +1,115 @@
+"""Execute the reference model (its own source files under oracle/refshim.py) and capture per-stage tensors.
+
+TEST INFRASTRUCTURE (oracle); this container only (needs /root/reference).  Used by
+tests/test_oracle_vs_reference.py and tests/golden/make_golden.py.
+"""
+import sys
+
+import torch
+
+from . import ref_model, refshim, weights
+from .ape_oracle import stable_topk
+from .configs import CONFIGS
+
+
+class _TorchProxy:
+    """`torch` as seen by deformable_transformer_vl.py: topk gets the oracle's defined tie rule
+    (value desc, index asc -- the reference leaves ties to torch.topk's unspecified order), and the
+    proposal gather is recorded so topk_proposals can be compared."""
+
+    def __init__(self, rec, stable_ties):
+        self._rec, self._stable = rec, stable_ties
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def topk(self, x, k, dim=-1, **kw):
+        if not self._stable or x.dim() != 1:
+            return torch.topk(x, k, dim=dim, **kw)
+        idx = stable_topk(x, k)
+        return x[idx], idx
+
+    def gather(self, inp, dim, index, **kw):
+        if index.dim() == 3 and index.shape[-1] == 4 and dim == 1:
+            self._rec["topk_proposals"] = index[..., 0].clone()
+        return torch.gather(inp, dim, index, **kw)
+
+
+def spec_of(model):
+    return [(k, list(v.shape)) for k, v in model.state_dict().items()]
+
+
+def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True):
+    """returns (stages dict, instances dict, spec)"""
+    cfg = CONFIGS[cfg_name]
+    model = ref_model.build_reference(cfg, text_feats)
+    spec = spec_of(model)
+    sd = weights.make_state_dict(spec, seed)
+    weights.load_into(model, sd)
+    mv = model.model_vision
+    S = {}
+    hooks = []
+
+    def hook(mod, name, fn=lambda o: o):
+        hooks.append(mod.register_forward_hook(lambda m, i, o: S.__setitem__(name, fn(o))))
+
+    net = mv.backbone.net
+    for i, blk in enumerate(net.blocks):
+        hook(blk, f"vit_block{i}")
+    hook(net, "last_feat", lambda o: o["last_feat"])
+    hooks.append(mv.backbone.register_forward_hook(lambda m, i, o: S.update({k: v for k, v in o.items()})))
+    enc = mv.transformer.encoder
+    for i in range(len(enc.layers)):
+        hooks.append(enc.vl_layers[i].register_forward_hook(
+            lambda m, inp, o, i=i: S.update({f"enc{i}_fused_v": o[0], f"enc{i}_fused_l": o[1]})))
+        hook(enc.layers[i], f"enc{i}_out")
+    hooks.append(mv.transformer.register_forward_hook(lambda m, i, o: S.update({
+        "inter_states": o[0], "init_reference": o[1], "inter_references": o[2], "enc_class": o[3],
+        "enc_coord_unact": o[4], "memory": o[6], "query_l": o[7]})))
+    hooks.append(mv.transformer.decoder.register_forward_pre_hook(
+        lambda m, a, kw: S.update({"query_init": kw["query"], "query_pos": kw["query_pos"]}), with_kwargs=True))
+    hook(mv.transformer.enc_output_norm, "output_memory")
+    hook(mv.mask_embed, "mask_embed")
+
+    tmod = sys.modules["ape.modeling.ape_deta.deformable_transformer_vl"]
+    smod = sys.modules["ape.modeling.ape_deta.deformable_detr_segm_vl"]
+    old_torch = tmod.torch
+    tmod.torch = _TorchProxy(S, stable_ties)
+    old_mf = mv.maskdino_mask_features
+    old_inf = mv.inference
+    old_retry = smod.retry_if_cuda_oom
+
+    def mf(*a, **k):
+        out = old_mf(*a, **k)
+        S["mask_features"] = out
+        return out
+
+    def inf(box_cls, box_pred, image_sizes, use_sigmoid=True):
+        S["pred_logits"], S["pred_boxes"] = box_cls, box_pred
+        res, filt = old_inf(box_cls, box_pred, image_sizes, use_sigmoid=use_sigmoid)
+        S["det_boxes"], S["det_scores"] = res[0].pred_boxes.tensor, res[0].scores
+        S["det_classes"], S["det_query"] = res[0].pred_classes, filt[0]
+        return res, filt
+
+    def retry(func):
+        def wrapped(x, **kw):
+            S["pred_masks"] = x
+            return func(x, **kw)
+        return wrapped
+
+    mv.maskdino_mask_features, mv.inference, smod.retry_if_cuda_oom = mf, inf, retry
+    try:
+        h, w = image.shape[-2:]
+        inputs = {"image": image, "height": height or h, "width": width or w, "prompt": "text",
+                  "text_prompt": ",".join(f"c{i}" for i in range(text_feats.shape[0]))}
+        with torch.no_grad():
+            out = model([inputs])[0]
+    finally:
+        tmod.torch = old_torch
+        mv.maskdino_mask_features, mv.inference, smod.retry_if_cuda_oom = old_mf, old_inf, old_retry
+        for hk in hooks:
+            hk.remove()
+    inst = out["instances"]
+    instances = {"pred_boxes": inst.pred_boxes.tensor, "scores": inst.scores, "pred_classes": inst.pred_classes,
+                 "pred_masks": inst.pred_masks if inst.has("pred_masks") else None}
+    return S, instances, spec, sd

@@ -1,0 +1,75 @@
+"""Generate tests/golden/* by EXECUTING THE REFERENCE (oracle/refshim.py + /root/reference) on seeded inputs.
+
+Run in the build container only:  python tests/golden/make_golden.py
+Outputs (small, committed):
+  state_spec_<cfg>.json   -- the reference model's state_dict() names/shapes (checkpoint-key contract)
+  ref_<case>.pt           -- per-stage fingerprints (shape, moments, 512 seeded samples) + the small head /
+                             detection tensors in full, for the cases in CASES
+Weights are NOT stored: oracle/weights.py regenerates them from (spec, seed) bit-identically.
+"""
+import json
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import ref_model, run_reference as rr  # noqa: E402
+from oracle.configs import CONFIGS  # noqa: E402
+
+CASES = {
+    # name: (cfg, weight seed, image seed, (h, w), K classes, text seed)
+    "tiny_square": ("tiny", 0, 2, (256, 256), 10, 3),
+    "tiny_padded": ("tiny", 1, 5, (200, 144), 7, 6),
+    "small_padded": ("small", 0, 2, (384, 512), 10, 3),
+}
+FULL = ("pred_logits", "pred_boxes", "topk_proposals", "det_boxes", "det_scores", "det_classes", "det_query",
+        "init_reference", "enc_class")
+
+
+def make_inputs(case):
+    cfg, wseed, iseed, (h, w), K, tseed = CASES[case]
+    image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
+    text = torch.randn(K, 1024, generator=torch.Generator().manual_seed(tseed))
+    return cfg, wseed, image, text
+
+
+def fingerprint(t, nsamp=512):
+    t = t.detach()
+    flat = t.reshape(-1)
+    idx = torch.randint(0, flat.numel(), (min(nsamp, flat.numel()),), generator=torch.Generator().manual_seed(flat.numel() % 9973))
+    f = flat.float()
+    fin = torch.isfinite(f)
+    return {"shape": list(t.shape), "dtype": str(t.dtype), "idx": idx, "samples": flat[idx].clone(),
+            "mean": f[fin].mean().item() if fin.any() else 0.0, "absmax": f[fin].abs().max().item() if fin.any() else 0.0,
+            "n_nonfinite": int((~fin).sum())}
+
+
+def main():
+    torch.set_num_threads(8)
+    for case in CASES:
+        cfg, wseed, image, text = make_inputs(case)
+        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text)
+        with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
+            json.dump(spec, fh)
+        gold = {"case": CASES[case], "stages": {}, "full": {}}
+        for k, v in S.items():
+            if torch.is_tensor(v):
+                gold["stages"][k] = fingerprint(v)
+                if k in FULL:
+                    gold["full"][k] = v.clone()
+        gold["instances"] = {"pred_boxes": inst["pred_boxes"], "scores": inst["scores"], "pred_classes": inst["pred_classes"],
+                             "mask_area": inst["pred_masks"].flatten(1).sum(1), "mask_shape": list(inst["pred_masks"].shape),
+                             "mask_rowsum0": inst["pred_masks"][0].sum(1) if len(inst["pred_masks"]) else None}
+        torch.save(gold, os.path.join(HERE, f"ref_{case}.pt"))
+        print(case, "->", len(gold["stages"]), "stages,", len(inst["scores"]), "instances")
+    # checkpoint-key contract of the full-size model (no forward: 1-2 min/image on CPU)
+    m = ref_model.build_reference(CONFIGS["L_D"], torch.zeros(1, 1024))
+    with open(os.path.join(HERE, "state_spec_L_D.json"), "w") as fh:
+        json.dump(rr.spec_of(m), fh)
+    print("L_D spec:", len(m.state_dict()), "tensors,", sum(v.numel() for v in m.state_dict().values()) / 1e6, "M values")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,84 @@
+"""The oracle (oracle/ape_oracle.py) against (a) the committed outputs of the reference's own code
+(tests/golden/ref_*.pt, made by tests/golden/make_golden.py) and (b) the live reference when /root/reference
+is present.  CPU only."""
+import os
+
+import pytest
+import torch
+
+import oracle_util as U
+from oracle import ape_oracle, weights
+from oracle.configs import CONFIGS
+
+FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order)
+
+
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded"])
+def test_oracle_matches_reference_golden(case):
+    gold = U.load_golden(case)
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+    orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
+    ref_topk = gold["full"]["topk_proposals"]
+    out = orc.forward(image, text)
+    S = orc.stages
+    # stages upstream of the proposal selection: elementwise
+    upstream = [k for k in gold["stages"] if k.startswith(("vit_block", "last_feat", "p", "enc", "memory", "query_l",
+                                                           "output_memory", "mask_features")) and not k.startswith("pred")]
+    for k in upstream:
+        if k in S:
+            U.check_fingerprint(S[k], gold["stages"][k], FP32_TOL, k)
+    # the selected proposals: same SET (near-equal scores may swap places between two fp32 implementations)
+    assert set(S["topk_proposals"][0].tolist()) == set(ref_topk[0].tolist())
+    # downstream with the reference's proposal order injected
+    out = orc.forward(image, text, forced_topk=ref_topk)
+    S = orc.stages
+    for k in ("query_init", "query_pos", "init_reference", "inter_states", "inter_references", "pred_masks"):
+        U.check_fingerprint(S[k], gold["stages"][k], 5e-4, k)
+    assert U.relerr(S["pred_logits"], gold["full"]["pred_logits"]) < 1e-3
+    assert U.relerr(S["pred_boxes"], gold["full"]["pred_boxes"]) < 1e-3
+    frac = U.match_detections(S["det_boxes"], S["det_scores"], S["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97, f"only {frac:.2%} of the reference detections reproduced"
+    gi = gold["instances"]
+    oi = out["instances"]
+    frac = U.match_detections(oi["pred_boxes"], oi["scores"], oi["pred_classes"], gi["pred_boxes"], gi["scores"], gi["pred_classes"])
+    assert frac >= 0.97
+    assert list(oi["pred_masks"].shape[1:]) == gi["mask_shape"][1:]
+
+
+def test_state_spec_contract():
+    """checkpoint-key contract of the full-size model, as enumerated by the reference itself"""
+    spec = dict(U.load_spec("L_D"))
+    assert spec["model_vision.backbone.net.blocks.23.mlp.w1.weight"] == (2730, 1024)
+    assert spec["model_vision.backbone.net.pos_embed"] == (1, 442, 1024)
+    assert spec["model_vision.transformer.encoder.vl_layers.5.b_attn.attn.values_l_proj.weight"] == (2048, 1024)
+    assert spec["model_vision.transformer.decoder.class_embed.6.weight"] == (1, 256)
+    assert spec["model_vision.class_embed.6.weight"] == (1, 256)
+    assert spec["model_vision.transformer.encoder.layers.0.attentions.0.sampling_offsets.weight"] == (320, 256)
+    sd = weights.make_state_dict(U.load_spec("tiny"), 0)
+    a = sd["model_vision.class_embed.0.bias_lang"]
+    assert a is sd["model_vision.transformer.decoder.class_embed.0.bias_lang"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ape"), reason="needs the reference checkout (build container only)")
+def test_oracle_matches_live_reference():
+    from oracle import run_reference as rr
+
+    image = torch.randint(0, 256, (3, 176, 256), generator=torch.Generator().manual_seed(11)).float()
+    text = torch.randn(5, 1024, generator=torch.Generator().manual_seed(12))
+    S, inst, spec, sd = rr.run_reference("tiny", 7, image, text, height=352, width=512)
+    orc = ape_oracle.ApeOracle(CONFIGS["tiny"], sd)
+    out = orc.forward(image, text, height=352, width=512, forced_topk=S["topk_proposals"])
+    O = orc.stages
+    for k in ("vit_block2", "p2", "p6", "enc1_out", "enc1_fused_l", "enc_class", "enc_coord_unact", "inter_states",
+              "pred_logits", "pred_boxes", "pred_masks", "mask_features"):
+        assert U.relerr(O[k], S[k]) < 5e-4, k
+    oi = out["instances"]
+    assert U.match_detections(oi["pred_boxes"], oi["scores"], oi["pred_classes"], inst["pred_boxes"], inst["scores"],
+                              inst["pred_classes"]) >= 0.97
+    assert oi["pred_masks"].shape == inst["pred_masks"].shape
+    assert (oi["pred_masks"] != inst["pred_masks"]).float().mean().item() < 2e-3
+    # RoPE tables are persistent buffers of the reference model: the oracle recomputes them
+    m_sd = dict(spec)
+    assert "model_vision.backbone.net.rope_win.freqs_cos" in m_sd
