@@ -64,6 +64,20 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ape_hip_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p]),
+    "ape_hip_patchify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p,
+                                 c_int, c_int, c_void_p]),
+    "ape_hip_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_maxpool2x2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_nms_mask_words": (c_int, [c_int]),
+    "ape_hip_nms_mask": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
+    "ape_hip_nms_scan_segments": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_nms_scan_classes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_vl_pool_workspace_floats": (c_int, [c_int, c_int]),
+    "ape_hip_vl_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_mask_upsample_bits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ape_hip_roi_align_bits": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ape_hip_paste_bits": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,110 @@
+// Instance-mask post-processing for the kept detections only (bilinear interpolation is per channel, so
+// upsampling just the kept queries gives the same result as the reference's 900-channel upsample).
+//   mask_upsample_bits : F.interpolate(mask_pred, size=(S,S), bilinear, align_corners=False) then sigmoid > 0.5
+//                        (deformable_detr_segm_vl.py:569-572, 605)  -> uint8 bitmask [n,S,S]
+//   roi_align_bits     : detectron2 BitMasks.crop_and_resize(boxes, 128) = torchvision roi_align(aligned=True,
+//                        sampling_ratio=0) of the bitmask, >= 0.5   (deformable_detr_segm_vl.py:606-608)
+//   paste_bits         : detectron2 paste_masks_in_image / _do_paste_mask (F.grid_sample, align_corners=False,
+//                        zeros) at the output resolution, >= 0.5 (deformable_detr_segm_vl.py:869-871)
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_upsample_bits_kernel(const T* __restrict__ logits, int ldl, int h0, int w0, int S,
+                                                                 int n, uint8_t* __restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)n * S * S) return;
+  const int x = (int)(gid % S), y = (int)((gid / S) % S), q = (int)(gid / ((size_t)S * S));
+  const float sy = (float)h0 / (float)S, sx = (float)w0 / (float)S;
+  float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0), x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const T* p = logits + (size_t)q * ldl;
+  const float v00 = ldf<T>(p + y0 * w0 + x0), v01 = ldf<T>(p + y0 * w0 + x1);
+  const float v10 = ldf<T>(p + y1 * w0 + x0), v11 = ldf<T>(p + y1 * w0 + x1);
+  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+  out[gid] = v > 0.f ? 1 : 0;
+}
+
+extern "C" int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, int h0, int w0, int S, int n, uint8_t* out,
+                                          void* stream) {
+  APE_CHECK_ARG(logits && out && h0 > 0 && w0 > 0 && S > 0 && n > 0, "ape_hip_mask_upsample_bits: bad args");
+  const size_t total = (size_t)n * S * S;
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  if (dt == APE_DT_BF16) hipLaunchKernelGGL(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
+  else hipLaunchKernelGGL(mask_upsample_bits_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, ldl, h0, w0, S, n, out);
+  APE_CHECK_LAUNCH("ape_hip_mask_upsample_bits");
+  return 0;
+}
+
+__device__ __forceinline__ float roi_bilinear(const uint8_t* __restrict__ img, int H, int W, float y, float x) {
+  if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int y_low = (int)y, x_low = (int)x, y_high, x_high;
+  if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+  if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+  const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+  return hy * hx * (float)img[y_low * W + x_low] + hy * lx * (float)img[y_low * W + x_high] +
+         ly * hx * (float)img[y_high * W + x_low] + ly * lx * (float)img[y_high * W + x_high];
+}
+
+__global__ __launch_bounds__(256) void roi_align_bits_kernel(const uint8_t* __restrict__ bits, int H, int W, const float* __restrict__ boxes,
+                                                             int n, int P, uint8_t* __restrict__ out) {
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= n * P * P) return;
+  const int pw = gid % P, ph = (gid / P) % P, q = gid / (P * P);
+  const float x1 = boxes[q * 4 + 0], y1 = boxes[q * 4 + 1], x2 = boxes[q * 4 + 2], y2 = boxes[q * 4 + 3];
+  const float sw = x1 - 0.5f, sh = y1 - 0.5f;
+  const float rw = (x2 - 0.5f) - sw, rh = (y2 - 0.5f) - sh;
+  const float bw = rw / (float)P, bh = rh / (float)P;
+  const int gh = (int)ceilf(rh / (float)P), gw = (int)ceilf(rw / (float)P);
+  const float count = (float)max(gh * gw, 1);
+  const uint8_t* img = bits + (size_t)q * H * W;
+  float sum = 0.f;
+  for (int iy = 0; iy < gh; ++iy) {
+    const float y = sh + (float)ph * bh + ((float)iy + 0.5f) * bh / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float x = sw + (float)pw * bw + ((float)ix + 0.5f) * bw / (float)gw;
+      sum += roi_bilinear(img, H, W, y, x);
+    }
+  }
+  out[gid] = (sum / count) >= 0.5f ? 1 : 0;
+}
+
+extern "C" int ape_hip_roi_align_bits(const uint8_t* bits, int H, int W, const float* boxes, int n, int P, uint8_t* out, void* stream) {
+  APE_CHECK_ARG(bits && boxes && out && n > 0 && P > 0, "ape_hip_roi_align_bits: bad args");
+  hipLaunchKernelGGL(roi_align_bits_kernel, dim3(ceil_div(n * P * P, 256)), dim3(256), 0, (hipStream_t)stream, bits, H, W, boxes, n, P, out);
+  APE_CHECK_LAUNCH("ape_hip_roi_align_bits");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void paste_bits_kernel(const uint8_t* __restrict__ m, int P, const float* __restrict__ boxes, int n,
+                                                         int Ho, int Wo, uint8_t* __restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)n * Ho * Wo) return;
+  const int x = (int)(gid % Wo), y = (int)((gid / Wo) % Ho), q = (int)(gid / ((size_t)Wo * Ho));
+  const float x0 = boxes[q * 4 + 0], y0 = boxes[q * 4 + 1], x1 = boxes[q * 4 + 2], y1 = boxes[q * 4 + 3];
+  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
+  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+  // grid_sample, align_corners=False: ix = ((g + 1) * size - 1) / 2 ; zeros padding
+  const float fx = ((gx + 1.f) * (float)P - 1.f) * 0.5f, fy = ((gy + 1.f) * (float)P - 1.f) * 0.5f;
+  const float flx = floorf(fx), fly = floorf(fy);
+  const int ix0 = (int)flx, iy0 = (int)fly, ix1 = ix0 + 1, iy1 = iy0 + 1;
+  const float lx = fx - flx, ly = fy - fly;
+  const uint8_t* img = m + (size_t)q * P * P;
+  auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < P && xx >= 0 && xx < P) ? (float)img[yy * P + xx] : 0.f; };
+  const float v = at(iy0, ix0) * (1.f - lx) * (1.f - ly) + at(iy0, ix1) * lx * (1.f - ly) + at(iy1, ix0) * (1.f - lx) * ly +
+                  at(iy1, ix1) * lx * ly;
+  out[gid] = v >= 0.5f ? 1 : 0;
+}
+
+extern "C" int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxes, int n, int Ho, int Wo, uint8_t* out, void* stream) {
+  APE_CHECK_ARG(masks && boxes && out && n > 0 && P > 0 && Ho > 0 && Wo > 0, "ape_hip_paste_bits: bad args");
+  const size_t total = (size_t)n * Ho * Wo;
+  hipLaunchKernelGGL(paste_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks, P, boxes, n, Ho, Wo, out);
+  APE_CHECK_LAUNCH("ape_hip_paste_bits");
+  return 0;
+}

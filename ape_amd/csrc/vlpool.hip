@@ -1,0 +1,126 @@
+// Language-side of the bi-directional vision-language attention for a SINGLE text token (name-prompt mode,
+// L = 1: deformable_detr_segm_vl.py:349-352 feeds one zero token; ape/layers/fuse_helper.py:67-166).
+//
+// With one text token the [8, T, 1] score tensor is a [T, 8] matrix S, the vision side's softmax over L is
+// identically 1, and the language side is an attention POOL over all T vision tokens per head:
+//     p[t,h]   = softmax_t( clamp( clamp(S - max(S)) - max_t(...) ) )          (fuse_helper.py:89-111, 116)
+//     pooled_h = sum_t p[t,h] * x[t,:]                                           (bmm at :140, before values_v_proj,
+//                                                                                 which is linear and applied after)
+// i.e. a [8,T] x [T,256] reduction: three small kernels (chunk maxima, chunk partial sums with the shared
+// maxima, final combine).  Vision padding is NOT masked (use_attention_mask_v=False), exactly like the reference.
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+#define VL_CHUNK 512
+#define VL_H 8
+
+__global__ __launch_bounds__(256) void vl_smax_partial_kernel(const float* __restrict__ S, int lds, int T, float* __restrict__ pmax) {
+  __shared__ float sh[256];
+  const int t = threadIdx.x, h = t & 7;
+  const int base = blockIdx.x * VL_CHUNK;
+  float m = -INFINITY;
+  for (int k = 0; k < VL_CHUNK / 32; ++k) {
+    const int tok = base + k * 32 + (t >> 3);
+    if (tok < T) m = fmaxf(m, S[(size_t)tok * lds + h]);
+  }
+  sh[t] = m;
+  __syncthreads();
+  if (t < VL_H) {
+    float a = -INFINITY;
+    for (int j = t; j < 256; j += 8) a = fmaxf(a, sh[j]);
+    pmax[blockIdx.x * VL_H + t] = a;
+  }
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void vl_pool_partial_kernel(const float* __restrict__ S, int lds, const TX* __restrict__ x, int ldx,
+                                                              int T, int C, const float* __restrict__ pmax, int nchunk,
+                                                              float* __restrict__ pacc, float* __restrict__ psum) {
+  __shared__ float hmax[VL_H];
+  __shared__ float gmax_s;
+  __shared__ float P[VL_CHUNK][VL_H];
+  const int t = threadIdx.x;
+  if (t < VL_H) {
+    float a = -INFINITY;
+    for (int k = 0; k < nchunk; ++k) a = fmaxf(a, pmax[k * VL_H + t]);
+    hmax[t] = a;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float g = hmax[0];
+    for (int h = 1; h < VL_H; ++h) g = fmaxf(g, hmax[h]);
+    gmax_s = g;
+  }
+  __syncthreads();
+  const float gmax = gmax_s;
+  const int base = blockIdx.x * VL_CHUNK;
+  const int cnt = min(VL_CHUNK, T - base);
+  // probabilities (unnormalised) for this chunk, reference clamp sequence
+  for (int idx = t; idx < VL_CHUNK * VL_H; idx += 256) {
+    const int r = idx >> 3, h = idx & 7;
+    float p = 0.f;
+    if (r < cnt) {
+      float a = S[(size_t)(base + r) * lds + h] - gmax;
+      a = fminf(fmaxf(a, -50000.f), 50000.f);
+      const float mh = fminf(fmaxf(hmax[h] - gmax, -50000.f), 50000.f);
+      float b = a - mh;
+      b = fminf(fmaxf(b, -50000.f), 50000.f);
+      p = expf(b);
+    }
+    P[r][h] = p;
+  }
+  __syncthreads();
+  if (t < VL_H) {
+    float s = 0.f;
+    for (int r = 0; r < cnt; ++r) s += P[r][t];
+    psum[blockIdx.x * VL_H + t] = s;
+  }
+  for (int c = t; c < C; c += 256) {
+    float acc[VL_H];
+#pragma unroll
+    for (int h = 0; h < VL_H; ++h) acc[h] = 0.f;
+    for (int r = 0; r < cnt; ++r) {
+      const float xv = ldf<TX>(x + (size_t)(base + r) * ldx + c);
+#pragma unroll
+      for (int h = 0; h < VL_H; ++h) acc[h] = fmaf(P[r][h], xv, acc[h]);
+    }
+#pragma unroll
+    for (int h = 0; h < VL_H; ++h) pacc[((size_t)blockIdx.x * VL_H + h) * C + c] = acc[h];
+  }
+}
+
+__global__ __launch_bounds__(256) void vl_pool_final_kernel(const float* __restrict__ pacc, const float* __restrict__ psum, int nchunk,
+                                                            int C, float* __restrict__ out) {
+  const int h = blockIdx.x;
+  float l = 0.f;
+  for (int k = 0; k < nchunk; ++k) l += psum[k * VL_H + h];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f;
+    for (int k = 0; k < nchunk; ++k) a += pacc[((size_t)k * VL_H + h) * C + c];
+    out[h * C + c] = a / l;
+  }
+}
+
+extern "C" int ape_hip_vl_pool_workspace_floats(int T, int C) {
+  const int nchunk = ceil_div(T, VL_CHUNK);
+  return nchunk * VL_H * (C + 2);
+}
+
+// S [T, 8] fp32 scores (already scaled), x [T, C] -> out [8, C] fp32: softmax-over-T weighted mean of x per head
+extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace,
+                               float* out, void* stream) {
+  APE_CHECK_ARG(S && x && workspace && out && T > 0 && C > 0, "ape_hip_vl_pool: bad args");
+  const int nchunk = ceil_div(T, VL_CHUNK);
+  float* pmax = workspace;
+  float* psum = pmax + nchunk * VL_H;
+  float* pacc = psum + nchunk * VL_H;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(vl_smax_partial_kernel, dim3(nchunk), dim3(256), 0, s, S, lds, T, pmax);
+  if (x_dt == APE_DT_BF16)
+    hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  else
+    hipLaunchKernelGGL(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H), dim3(256), 0, s, pacc, psum, nchunk, C, out);
+  APE_CHECK_LAUNCH("ape_hip_vl_pool");
+  return 0;
+}

@@ -236,3 +236,148 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None):
                                       head_dim, float(scale), _dt(q), _stream())
     _lib.check(rc, "ape_hip_attention")
     return out
+
+
+def _i32(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or not t.is_contiguous():
+        raise ValueError(f"ape_amd.ops: {name} must be a contiguous int32 tensor")
+    return t
+
+
+def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype):
+    """(img - mean)/std, zero pad to the token grid, 16x16 patch rows [ht*wt, 768] in token order."""
+    _dev(img, tok2raster)
+    if img.dtype != torch.float32 or img.dim() != 3 or img.shape[0] != 3 or not img.is_contiguous():
+        raise ValueError("ape_amd.ops.patchify: img must be contiguous float32 [3,h,w]")
+    out = torch.empty((ht * wt, 768), dtype=out_dtype, device=img.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    rc = _lib.load().ape_hip_patchify(_p(img), img.shape[1], img.shape[2], _p(_i32(tok2raster, "tok2raster")), ht, wt, m, s,
+                                     _p(out), 768, _dt(out), _stream())
+    _lib.check(rc, "ape_hip_patchify")
+    return out
+
+
+def im2col3x3(x, perm, h, w, *, out=None):
+    """[h*w, C] (rows addressed through perm: raster index -> row) -> [h*w, 9*C] operand of a 3x3/pad-1 conv."""
+    _dev(x, perm, out)
+    _rowmajor(x, "x")
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty((h * w, 9 * C), dtype=x.dtype, device=x.device)
+    rc = _lib.load().ape_hip_im2col3x3(_p(x), _ld(x), _p(_i32(perm, "perm")), h, w, C, _p(out), _ld(out), _dt(x), _stream())
+    _lib.check(rc, "ape_hip_im2col3x3")
+    return out
+
+
+def maxpool2x2(x, perm, h, w):
+    _dev(x, perm)
+    _rowmajor(x, "x")
+    C = x.shape[1]
+    out = torch.empty(((h // 2) * (w // 2), C), dtype=x.dtype, device=x.device)
+    rc = _lib.load().ape_hip_maxpool2x2(_p(x), _ld(x), _p(_i32(perm, "perm")), h, w, C, _p(out), C, _dt(x), _stream())
+    _lib.check(rc, "ape_hip_maxpool2x2")
+    return out
+
+
+def gather_rows(x, idx, *, out=None):
+    _dev(x, idx, out)
+    _rowmajor(x, "x")
+    n, C = idx.numel(), x.shape[1]
+    if out is None:
+        out = torch.empty((n, C), dtype=x.dtype, device=x.device)
+    rc = _lib.load().ape_hip_gather_rows(_p(x), _ld(x), _p(_i32(idx, "idx")), n, C, _p(out), _ld(out), _dt(x), _stream())
+    _lib.check(rc, "ape_hip_gather_rows")
+    return out
+
+
+def _boxes(b):
+    if b.dtype != torch.float32 or not b.is_contiguous() or b.dim() != 2 or b.shape[1] != 4:
+        raise ValueError("ape_amd.ops: boxes must be contiguous float32 [n,4]")
+    return b
+
+
+def _u8(t, name):
+    if t is None:
+        return None
+    if t.dtype not in (torch.uint8, torch.bool) or not t.is_contiguous():
+        raise ValueError(f"ape_amd.ops: {name} must be contiguous uint8/bool")
+    return t
+
+
+def nms_segments(boxes, groups, seg_offsets, max_segment, iou_thr, valid=None):
+    """Greedy NMS inside each contiguous segment (candidates sorted by descending score within a segment).
+    boxes [n,4] xyxy, groups int32 [n], seg_offsets int32 [G+1] (device) -> keep uint8 [n]."""
+    _dev(boxes, groups, seg_offsets, valid)
+    n = boxes.shape[0]
+    lib = _lib.load()
+    mask = torch.empty((n, lib.ape_hip_nms_mask_words(n)), dtype=torch.int64, device=boxes.device)
+    keep = torch.zeros((n,), dtype=torch.uint8, device=boxes.device)
+    _lib.check(lib.ape_hip_nms_mask(_p(_boxes(boxes)), _p(_i32(groups, "groups")), n, float(iou_thr), _p(mask), _stream()), "ape_hip_nms_mask")
+    rc = lib.ape_hip_nms_scan_segments(_p(mask), n, _p(_i32(seg_offsets, "seg_offsets")), seg_offsets.numel() - 1, int(max_segment),
+                                       _p(_u8(valid, "valid")), _p(keep), _stream())
+    _lib.check(rc, "ape_hip_nms_scan_segments")
+    return keep
+
+
+def nms_classes(boxes, order, iou_thr, valid=None):
+    """Class-wise greedy NMS over class-agnostic boxes: class c visits boxes order[c, :] (descending score).
+    boxes [n,4], order int32 [K,n], valid uint8 [K,n] -> keep uint8 [K,n] (in visiting order)."""
+    _dev(boxes, order, valid)
+    n = boxes.shape[0]
+    K = order.shape[0]
+    lib = _lib.load()
+    mask = torch.empty((n, lib.ape_hip_nms_mask_words(n)), dtype=torch.int64, device=boxes.device)
+    keep = torch.zeros((K, n), dtype=torch.uint8, device=boxes.device)
+    _lib.check(lib.ape_hip_nms_mask(_p(_boxes(boxes)), None, n, float(iou_thr), _p(mask), _stream()), "ape_hip_nms_mask")
+    rc = lib.ape_hip_nms_scan_classes(_p(mask), n, _p(_i32(order, "order")), K, _p(_u8(valid, "valid")), _p(keep), _stream())
+    _lib.check(rc, "ape_hip_nms_scan_classes")
+    return keep
+
+
+def vl_pool(scores, x):
+    """out[h,:] = sum_t softmax_t(scores[t,h]) x[t,:]  (single-text-token language side, fuse_helper.py:89-116,140)."""
+    _dev(scores, x)
+    _rowmajor(scores, "scores"), _rowmajor(x, "x")
+    if scores.dtype != torch.float32 or scores.shape[1] != 8:
+        raise ValueError("ape_amd.ops.vl_pool: scores must be float32 [T,8]")
+    T, C = x.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.ape_hip_vl_pool_workspace_floats(T, C),), dtype=torch.float32, device=x.device)
+    out = torch.empty((8, C), dtype=torch.float32, device=x.device)
+    rc = lib.ape_hip_vl_pool(_p(scores), _ld(scores), _p(x), _ld(x), _dt(x), T, C, _p(ws), _p(out), _stream())
+    _lib.check(rc, "ape_hip_vl_pool")
+    return out
+
+
+def mask_upsample_bits(logits, h0, w0, size):
+    """bilinear (align_corners=False) upsample of n mask-logit rows [n, h0*w0] to size x size, thresholded at 0."""
+    _dev(logits)
+    _rowmajor(logits, "logits")
+    n = logits.shape[0]
+    out = torch.empty((n, size, size), dtype=torch.uint8, device=logits.device)
+    rc = _lib.load().ape_hip_mask_upsample_bits(_p(logits), _ld(logits), _dt(logits), h0, w0, size, n, _p(out), _stream())
+    _lib.check(rc, "ape_hip_mask_upsample_bits")
+    return out
+
+
+def roi_align_bits(bits, boxes, p):
+    """BitMasks.crop_and_resize: bits uint8 [n,H,W], boxes [n,4] -> uint8 [n,p,p]."""
+    _dev(bits, boxes)
+    n, H, W = bits.shape
+    out = torch.empty((n, p, p), dtype=torch.uint8, device=bits.device)
+    rc = _lib.load().ape_hip_roi_align_bits(_p(_u8(bits, "bits")), H, W, _p(_boxes(boxes)), n, p, _p(out), _stream())
+    _lib.check(rc, "ape_hip_roi_align_bits")
+    return out
+
+
+def paste_bits(masks, boxes, ho, wo):
+    """paste_masks_in_image: masks uint8 [n,P,P], boxes [n,4] (output frame) -> uint8 [n,ho,wo]."""
+    _dev(masks, boxes)
+    n, P, _ = masks.shape
+    out = torch.empty((n, ho, wo), dtype=torch.uint8, device=masks.device)
+    rc = _lib.load().ape_hip_paste_bits(_p(_u8(masks, "masks")), P, _p(_boxes(boxes)), n, ho, wo, _p(out), _stream())
+    _lib.check(rc, "ape_hip_paste_bits")
+    return out

@@ -129,7 +129,8 @@ int ape_hip_groupnorm(const ApeGroupNormArgs* args, void* stream);
  *   kernel ms_deform_im2col_cuda.cuh:237-299) and of the pure-PyTorch path
  *   multi_scale_deformable_attn_pytorch (ape/layers/multi_scale_deform_attn.py:84-124).
  *   value [B, S, M, D] (row stride ldv elements per spatial position), spatial_shapes [L,2] int64
- *   (h,w), level_start_index [L] int64, sampling_loc [B,Q,M,L,P,2] (x,y in [0,1]),
+ *   (h,w), level_start_index [L] int64 -- HOST pointers here (tiny, constant per resolution; baked into the
+ *   kernel argument block), device tensors in the reference operator, sampling_loc [B,Q,M,L,P,2] (x,y in [0,1]),
  *   attn_weight [B,Q,M,L,P]  ->  out [B,Q,M*D].   M = 8 heads, D = 32, P = 4, L <= 8.
  *   value/sampling_loc/attn_weight/out share `dt`.
  * ape_hip_msda_fused additionally folds multi_scale_deform_attn.py:278-311 (softmax over L*P,
@@ -156,6 +157,63 @@ int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spat
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                       int B, int N, int H, int HD, float scale, int dt, void* stream);
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Spatial gathers that keep the whole hot path token-major (NHWC) -- csrc/spatial.hip.
+ * patchify   : (image - mean)/std, zero pad, 16x16 patch rows in token order tok2raster (NULL = raster):
+ *              DeformableDETRSegmVL.preprocess_image (deformable_detr_segm_vl.py:846-855) + the im2col of
+ *              PatchEmbed (utils_eva02.py:208-216).  img [3,h,w] fp32, out [Ht*Wt, 768].
+ * im2col3x3  : operand of a 3x3/pad-1 conv, column (ky*3+kx)*C + c; `perm` maps raster index -> source row
+ *              (SimpleFeaturePyramid vit_eva_clip.py:835-842; output_conv deformable_detr_segm_vl.py:122-131).
+ * maxpool2x2 : nn.MaxPool2d(2,2) (vit_eva_clip.py:822-823);  gather_rows: out[r] = x[idx[r]]
+ *              (LastLevelMaxPool stride-2 subsample vit_eva_clip.py:907-912; proposal gathers
+ *              deformable_transformer_vl.py:641-644).
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_patchify(const float* img, int h, int w, const int32_t* tok2raster, int Ht, int Wt, const float* mean3,
+                     const float* std3, void* out, int ldo, int out_dt, void* stream);
+int ape_hip_im2col3x3(const void* x, int ldx, const int32_t* perm, int H, int W, int C, void* out, int ldo, int dt, void* stream);
+int ape_hip_maxpool2x2(const void* x, int ldx, const int32_t* perm, int H, int W, int C, void* out, int ldo, int dt, void* stream);
+int ape_hip_gather_rows(const void* x, int ldx, const int32_t* idx, int n, int C, void* out, int ldo, int dt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Greedy NMS (torchvision.ops.nms / batched_nms semantics) -- csrc/select.hip.
+ * Replaces torchvision batched_nms at deformable_transformer_vl.py:592-597 and detectron2 batched_nms at
+ * ape/modeling/ape_deta/fast_rcnn.py:192.
+ *   nms_mask          : bit matrix mask[n][ceil(n/64)] of "i suppresses j" (IoU > thr, same group)
+ *   nms_scan_segments : independent scans over contiguous segments [seg[g], seg[g+1]) of candidates that
+ *                       are already sorted by descending score inside each segment
+ *   nms_scan_classes  : class-agnostic boxes, per-class visiting order[c][0..n): one scan per class
+ * `valid` (optional uint8) marks candidates that take part at all (score threshold).
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_nms_mask_words(int n);
+int ape_hip_nms_mask(const float* boxes_xyxy, const int32_t* groups, int n, float iou_thr, uint64_t* mask, void* stream);
+int ape_hip_nms_scan_segments(const uint64_t* mask, int n, const int32_t* seg_offsets, int num_segments, int max_segment,
+                              const uint8_t* valid, uint8_t* keep, void* stream);
+int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int32_t* order, int num_classes, const uint8_t* valid,
+                             uint8_t* keep, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Language side of BiMultiHeadAttention for one text token (ape/layers/fuse_helper.py:89-116,140):
+ * out[h,:] = sum_t softmax_t(S[t,h]) * x[t,:]   with the reference's global-max / clamp sequence.
+ * S [T, 8] fp32, x [T, C]; workspace ape_hip_vl_pool_workspace_floats(T, C) fp32.  -- csrc/vlpool.hip
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_vl_pool_workspace_floats(int T, int C);
+int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace, float* out,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instance-mask post-processing of the kept detections -- csrc/masks.hip
+ *   mask_upsample_bits: bilinear (align_corners=False) h0 x w0 -> S x S of n mask-logit rows, then > 0
+ *                       (F.interpolate + sigmoid > 0.5, deformable_detr_segm_vl.py:569-572,605)
+ *   roi_align_bits    : BitMasks.crop_and_resize(boxes, P) (roi_align aligned=True, adaptive sampling, >= 0.5)
+ *                       (deformable_detr_segm_vl.py:606-608)
+ *   paste_bits        : detectron2 paste_masks_in_image at the output resolution, threshold 0.5
+ *                       (detector_postprocess, deformable_detr_segm_vl.py:869-871)
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, int h0, int w0, int S, int n, uint8_t* out, void* stream);
+int ape_hip_roi_align_bits(const uint8_t* bits, int H, int W, const float* boxes, int n, int P, uint8_t* out, void* stream);
+int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxes, int n, int Ho, int Wo, uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

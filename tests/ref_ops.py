@@ -185,3 +185,114 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None):
         out.copy_(o.to(out.dtype))
         return out
     return o.to(q.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# spatial gathers
+# ------------------------------------------------------------------------------------------------
+def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype):
+    h, w = img.shape[1:]
+    m = torch.tensor(mean, dtype=torch.float32, device=img.device).view(3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32, device=img.device).view(3, 1, 1)
+    x = F.pad((img.float() - m) / s, (0, wt * 16 - w, 0, ht * 16 - h))
+    p = x.view(3, ht, 16, wt, 16).permute(1, 3, 0, 2, 4).reshape(ht * wt, 768)
+    if tok2raster is not None:
+        p = p[tok2raster.long()]
+    return p.to(out_dtype).contiguous()
+
+
+def im2col3x3(x, perm, h, w, *, out=None):
+    C = x.shape[1]
+    src = x[perm.long()] if perm is not None else x[: h * w]
+    img = src.float().reshape(h, w, C).permute(2, 0, 1)[None]
+    cols = F.unfold(img, kernel_size=3, padding=1)  # [1, C*9, h*w] with index c*9 + tap
+    cols = cols.view(C, 9, h * w).permute(2, 1, 0).reshape(h * w, 9 * C).to(x.dtype)
+    if out is not None:
+        out.copy_(cols)
+        return out
+    return cols.contiguous()
+
+
+def maxpool2x2(x, perm, h, w):
+    C = x.shape[1]
+    src = x[perm.long()] if perm is not None else x[: h * w]
+    img = src.float().reshape(h, w, C).permute(2, 0, 1)[None]
+    y = F.max_pool2d(img, 2, 2)[0].permute(1, 2, 0).reshape(-1, C)
+    return y.to(x.dtype).contiguous()
+
+
+def gather_rows(x, idx, *, out=None):
+    y = x[idx.long()]
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS (greedy, IoU > thr suppresses), VL pooling, mask post-processing
+# ------------------------------------------------------------------------------------------------
+def _greedy(boxes, order_idx, valid, thr):
+    """visit boxes[order_idx[k]] in order k; returns keep flags per visiting position"""
+    from oracle import thirdparty as tp  # test infrastructure only
+
+    b = boxes.float().cpu()[order_idx.cpu().long()]
+    n = b.shape[0]
+    v = torch.ones(n, dtype=torch.bool) if valid is None else valid.cpu().bool()
+    keep = torch.zeros(n, dtype=torch.uint8)
+    if v.any():
+        pos = v.nonzero().flatten()
+        # tp.nms sorts by score: give strictly decreasing scores in visiting order
+        kept = tp.nms(b[pos], torch.arange(len(pos), 0, -1).float(), thr)
+        keep[pos[kept]] = 1
+    return keep
+
+
+def nms_segments(boxes, groups, seg_offsets, max_segment, iou_thr, valid=None):
+    n = boxes.shape[0]
+    keep = torch.zeros(n, dtype=torch.uint8)
+    so = seg_offsets.cpu().tolist()
+    g = groups.cpu()
+    for s0, s1 in zip(so[:-1], so[1:]):
+        if s1 <= s0:
+            continue
+        idx = torch.arange(s0, s1)
+        # groups may still differ inside a segment: suppression only within equal group ids
+        for gid in torch.unique(g[idx]):
+            sub = idx[g[idx] == gid]
+            keep[sub] = _greedy(boxes, sub, None if valid is None else valid[sub], iou_thr)
+    return keep.to(boxes.device)
+
+
+def nms_classes(boxes, order, iou_thr, valid=None):
+    K, n = order.shape
+    keep = torch.zeros((K, n), dtype=torch.uint8)
+    for c in range(K):
+        keep[c] = _greedy(boxes, order[c], None if valid is None else valid[c], iou_thr)
+    return keep.to(boxes.device)
+
+
+def vl_pool(scores, x):
+    w = scores.float()
+    w = (w - w.max()).clamp(-50000, 50000)
+    wl = (w - w.max(dim=0, keepdim=True)[0]).clamp(-50000, 50000).softmax(dim=0)  # over tokens
+    return wl.t() @ x.float()
+
+
+def mask_upsample_bits(logits, h0, w0, size):
+    n = logits.shape[0]
+    up = F.interpolate(logits.float().reshape(1, n, h0, w0), size=(size, size), mode="bilinear", align_corners=False)[0]
+    return (up > 0).to(torch.uint8)
+
+
+def roi_align_bits(bits, boxes, p):
+    from oracle import thirdparty as tp
+
+    return tp.bitmasks_crop_and_resize(bits.cpu().bool(), boxes.cpu(), p).to(torch.uint8).to(bits.device)
+
+
+def paste_bits(masks, boxes, ho, wo):
+    from oracle import thirdparty as tp
+
+    out = [tp.paste_mask(masks[i].cpu().float(), boxes[i].cpu(), ho, wo).to(torch.uint8) for i in range(masks.shape[0])]
+    return torch.stack(out).to(masks.device)

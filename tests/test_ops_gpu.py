@@ -230,3 +230,122 @@ def test_attention(ops, dtype, B, N, H, HD):
     e = relerr(got, want)
     print(f"attention(peaked) {dtype}: {e:.3e}")
     assert e < (2e-2 if dtype == torch.bfloat16 else 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ set 2
+def _wm_perm(ht, wt, ws):
+    """window-major token order: tok -> raster index, and the inverse"""
+    r = torch.arange(ht * wt).view(ht // ws, ws, wt // ws, ws).permute(0, 2, 1, 3).reshape(-1)
+    inv = torch.empty_like(r)
+    inv[r] = torch.arange(ht * wt)
+    return r.int(), inv.int()
+
+
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_patchify(ops, odt):
+    ht = wt = 16
+    img = torch.randint(0, 256, (3, 200, 144), generator=torch.Generator().manual_seed(1)).float().to(DEV)
+    t2r, _ = _wm_perm(ht, wt, 8)
+    mean, std = (123.675, 116.28, 103.53), (58.395, 57.12, 57.375)
+    for perm in (None, t2r.to(DEV)):
+        got = ops.patchify(img, perm, ht, wt, mean, std, out_dtype=odt)
+        ref = ref_ops.patchify(img, perm, ht, wt, mean, std, out_dtype=odt)
+        assert got.shape == (256, 768) and relerr(got, ref) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_spatial_gathers(ops, dt):
+    H = W = 32
+    C = 64
+    x = rnd(H * W, C, dtype=dt, seed=1)
+    _, r2t = _wm_perm(H, W, 8)
+    for perm in (None, r2t.to(DEV)):
+        assert torch.equal(ops.im2col3x3(x, perm, H, W).float(), ref_ops.im2col3x3(x, perm, H, W).float())
+        assert torch.equal(ops.maxpool2x2(x, perm, H, W).float(), ref_ops.maxpool2x2(x, perm, H, W).float())
+    idx = torch.randint(0, H * W, (777,), generator=torch.Generator().manual_seed(2)).int().to(DEV)
+    assert torch.equal(ops.gather_rows(x, idx).float(), ref_ops.gather_rows(x, idx).float())
+
+
+def _rand_boxes(n, seed, size=1.0, jitter=0.02):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.rand(n // 4 + 1, 2, generator=g)
+    c = c[torch.randint(0, len(c), (n,), generator=g)] + torch.randn(n, 2, generator=g) * jitter  # clustered -> overlaps
+    wh = (torch.rand(n, 2, generator=g) * 0.2 + 0.05)
+    return (torch.cat([c - wh / 2, c + wh / 2], 1) * size).float().contiguous()
+
+
+def test_nms_segments(ops):
+    g = torch.Generator().manual_seed(5)
+    n = 3000
+    boxes = _rand_boxes(n, 1)
+    scores = torch.rand(n, generator=g)
+    levels = torch.randint(0, 5, (n,), generator=g)
+    order = torch.argsort(scores, descending=True, stable=True)
+    order = order[torch.argsort(levels[order], stable=True)]  # group-major, score-descending inside
+    b, lv = boxes[order].contiguous().to(DEV), levels[order].int().to(DEV)
+    counts = torch.bincount(levels, minlength=5)
+    seg = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).int().to(DEV)
+    valid = (torch.rand(n, generator=g) > 0.1).to(torch.uint8).to(DEV)
+    for v in (None, valid):
+        got = ops.nms_segments(b, lv, seg, int(counts.max()), 0.6, v)
+        ref = ref_ops.nms_segments(b, lv, seg, int(counts.max()), 0.6, v)
+        print("nms_segments kept", int(got.sum()), "of", n)
+        assert torch.equal(got.cpu(), ref.cpu())
+    # one segment holding mixed groups (the p6 "extras" case): suppression must respect group ids
+    seg1 = torch.tensor([0, n], dtype=torch.int32).to(DEV)
+    o2 = torch.argsort(scores, descending=True, stable=True)
+    b2, lv2 = boxes[o2].contiguous().to(DEV), levels[o2].int().to(DEV)
+    assert torch.equal(ops.nms_segments(b2, lv2, seg1, n, 0.6).cpu(), ref_ops.nms_segments(b2, lv2, seg1, n, 0.6).cpu())
+
+
+def test_nms_classes(ops):
+    g = torch.Generator().manual_seed(6)
+    n, K = 900, 37
+    boxes = _rand_boxes(n, 2, size=1024.0).to(DEV)
+    scores = torch.rand(n, K, generator=g)
+    order = torch.argsort(scores, dim=0, descending=True, stable=True).t().contiguous().int().to(DEV)
+    valid = (torch.gather(scores.t(), 1, order.cpu().long()) > 0.05).to(torch.uint8).contiguous().to(DEV)
+    got = ops.nms_classes(boxes, order, 0.7, valid)
+    ref = ref_ops.nms_classes(boxes, order, 0.7, valid)
+    print("nms_classes kept", int(got.sum()), "of", n * K)
+    assert torch.equal(got.cpu(), ref.cpu())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_vl_pool(ops, dt):
+    T = 5456
+    S = rnd(T, 8, seed=1) * 3.0
+    x = rnd(T, 256, dtype=dt, seed=2)
+    e = relerr(ops.vl_pool(S, x), ref_ops.vl_pool(S, x))
+    print("vl_pool", dt, e)
+    assert e < 2e-5
+
+
+def test_mask_postprocess(ops):
+    n, h0, S = 7, 64, 256
+    logits = rnd(n, h0 * h0, seed=1)
+    # smooth the logits so masks have structure
+    logits = F_avg(logits.view(n, 1, h0, h0)).reshape(n, h0 * h0).contiguous()
+    bits = ops.mask_upsample_bits(logits, h0, h0, S)
+    ref = ref_ops.mask_upsample_bits(logits, h0, h0, S)
+    mism = (bits != ref).float().mean().item()
+    print("upsample mismatch", mism)
+    assert mism < 1e-5
+    boxes = _rand_boxes(n, 3, size=200.0).to(DEV) + 10
+    boxes[0] = torch.tensor([-5.0, 3.0, 300.0, 100.0])  # partly outside
+    r = ops.roi_align_bits(ref.contiguous(), boxes, 128)
+    rr_ = ref_ops.roi_align_bits(ref, boxes, 128)
+    mism = (r != rr_).float().mean().item()
+    print("roi_align mismatch", mism)
+    assert mism < 1e-4
+    ob = boxes * 1.5
+    p = ops.paste_bits(rr_.contiguous(), ob.contiguous(), 300, 420)
+    pr = ref_ops.paste_bits(rr_, ob, 300, 420)
+    mism = (p != pr).float().mean().item()
+    print("paste mismatch", mism)
+    assert mism < 1e-4
+
+
+def F_avg(t):
+    import torch.nn.functional as F
+    return F.avg_pool2d(F.pad(t, (2, 2, 2, 2), mode="replicate"), 5, 1)
