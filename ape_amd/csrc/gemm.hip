@@ -168,11 +168,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     soff[i] = swz128(row, c);
   }
   uint4 ra[4], rw[4];
+  const int kchunk = (tid & 7) * 8;  // same 16-byte chunk column for all 4 staged rows of this thread
   auto gload = [&](int kt) {
+    const bool kin = kt * GB_K + kchunk < p.K;  // K tail (K % 8 == 0): chunks past K read as zeros
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const uint4*>(ga[i] + kt * GB_K);
-      rw[i] = *reinterpret_cast<const uint4*>(gw[i] + kt * GB_K);
+      ra[i] = kin ? *reinterpret_cast<const uint4*>(ga[i] + kt * GB_K) : make_uint4(0u, 0u, 0u, 0u);
+      rw[i] = kin ? *reinterpret_cast<const uint4*>(gw[i] + kt * GB_K) : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto sstore = [&](int buf) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
   };
 
-  const int nk = p.K / GB_K;
+  const int nk = (p.K + GB_K - 1) / GB_K;
   gload(0);
   sstore(0);
   __syncthreads();
@@ -337,7 +339,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   p.vec_ok = vec;
   hipStream_t s = (hipStream_t)stream;
   if (p.in_dt == APE_DT_BF16) {
-    APE_CHECK_ARG(p.K % GB_K == 0, "ape_hip_gemm(bf16): K=%d must be a multiple of %d (pad the operands)", p.K, GB_K);
+    APE_CHECK_ARG(p.K % 8 == 0, "ape_hip_gemm(bf16): K=%d must be a multiple of 8 (pad the operands)", p.K);
     APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
     APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
     const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);

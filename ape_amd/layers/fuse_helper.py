@@ -1,0 +1,107 @@
+"""Bi-directional vision<->language attention block -- mirror of ape/layers/fuse_helper.py
+(BiMultiHeadAttention :8-166, BiAttentionBlock :178-232): same constructor kwargs and parameter names.
+
+Implemented path: ONE language token (name-prompt mode: deformable_detr_segm_vl.py:349-352 passes a single zero
+token).  With L = 1 the softmax over the language axis is identically 1, so
+    delta_v = out_v_proj(values_l_proj(LN_l(l)))                              (a per-layer vector)
+and the language update is an attention pool over all vision tokens,
+    S[t,h]  = scale * (LN_v(v)[t] . (W_v,h^T k_h) + b_v,h . k_h)             ([T,8], one skinny GEMM)
+    delta_l = out_l_proj( concat_h( (sum_t softmax_t(S)[t,h] LN_v(v)[t]) W_vv,h^T + b_vv,h ) )
+which removes the three 256->2048 projections over 87k tokens (1.66 of the model's 6.95 TFLOP) while keeping
+the reference's global-max subtraction, +-5e4 clamps, unmasked padding and residual-on-the-normalised-tensor
+(fuse_helper.py:89-111, 224-231).  The reassociation changes summation order only.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..packing import attach_cache, f32, pack_matrix
+
+
+class BiMultiHeadAttention(nn.Module):
+    def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, stable_softmax_2d=False,
+                 clamp_min_for_underflow=True, clamp_max_for_overflow=True, use_attention_mask_v=False):
+        super().__init__()
+        self.embed_dim, self.num_heads, self.head_dim = embed_dim, num_heads, embed_dim // num_heads
+        self.v_dim, self.l_dim = v_dim, l_dim
+        assert self.head_dim * num_heads == embed_dim
+        self.scale = self.head_dim ** (-0.5)
+        self.dropout = dropout
+        self.v_proj = nn.Linear(v_dim, embed_dim)
+        self.l_proj = nn.Linear(l_dim, embed_dim)
+        self.values_v_proj = nn.Linear(v_dim, embed_dim)
+        self.values_l_proj = nn.Linear(l_dim, embed_dim)
+        self.out_v_proj = nn.Linear(embed_dim, v_dim)
+        self.out_l_proj = nn.Linear(embed_dim, l_dim)
+        self.stable_softmax_2d = stable_softmax_2d
+        self.clamp_min_for_underflow = clamp_min_for_underflow
+        self.clamp_max_for_overflow = clamp_max_for_overflow
+        self.use_attention_mask_v = use_attention_mask_v
+
+
+class BiAttentionBlock(nn.Module):
+    def __init__(self, v_dim, l_dim, embed_dim, num_heads, dropout=0.1, drop_path=0.0, init_values=1e-4,
+                 stable_softmax_2d=False, clamp_min_for_underflow=True, clamp_max_for_overflow=True,
+                 use_attention_mask_v=False):
+        super().__init__()
+        if num_heads != 8:
+            raise ValueError("ape_amd VL fusion kernels are built for 8 heads (APE configs)")
+        if not (stable_softmax_2d and clamp_min_for_underflow and clamp_max_for_overflow) or use_attention_mask_v:
+            raise ValueError("ape_amd VL fusion implements the APE configuration: stable_softmax_2d + both clamps, "
+                             "vision padding unmasked")
+        self.layer_norm_v = nn.LayerNorm(v_dim)
+        self.layer_norm_l = nn.LayerNorm(l_dim)
+        self.attn = BiMultiHeadAttention(v_dim, l_dim, embed_dim, num_heads, dropout, stable_softmax_2d,
+                                         clamp_min_for_underflow, clamp_max_for_overflow, use_attention_mask_v)
+        self.gamma_v = nn.Parameter(init_values * torch.ones((v_dim)), requires_grad=True)
+        self.gamma_l = nn.Parameter(init_values * torch.ones((l_dim)), requires_grad=True)
+        attach_cache(self)
+
+    def packed(self, dt):
+        def build(dt):
+            a = self.attn
+            nh, hd, vd = a.num_heads, a.head_dim, a.v_dim
+            return dict(
+                lnv=(f32(self.layer_norm_v.weight), f32(self.layer_norm_v.bias), self.layer_norm_v.eps),
+                lnl=(f32(self.layer_norm_l.weight), f32(self.layer_norm_l.bias), self.layer_norm_l.eps),
+                wl=f32(a.l_proj.weight), bl=f32(a.l_proj.bias), wvl=f32(a.values_l_proj.weight), bvl=f32(a.values_l_proj.bias),
+                wov=f32(a.out_v_proj.weight), bov=f32(a.out_v_proj.bias), wol=f32(a.out_l_proj.weight), bol=f32(a.out_l_proj.bias),
+                wv=f32(a.v_proj.weight).view(nh, hd, vd), bv=f32(a.v_proj.bias).view(nh, hd),
+                wvv=f32(a.values_v_proj.weight).view(nh, hd, vd), bvv=f32(a.values_v_proj.bias).view(nh, hd),
+                gv=f32(self.gamma_v), gl=f32(self.gamma_l))
+        return self._pack.get(self, dt, build)
+
+    def forward_tokens_single(self, x, lvl_pos, l, dt):
+        """x [T,256] vision tokens, lvl_pos [T,256], l [1, l_dim] fp32 ->
+        (v_new [T,256], v_new + lvl_pos [T,256], l_new [1, l_dim])"""
+        P = self.packed(dt)
+        a = self.attn
+        l_n = ops.layernorm(l, P["lnl"][0], P["lnl"][1], P["lnl"][2], out_dtype=torch.float32)
+        k = ops.gemv(l_n, P["wl"], P["bl"])                      # l_proj            [1, E]
+        vl = ops.gemv(l_n, P["wvl"], P["bvl"])                   # values_l_proj     [1, E]
+        dv = ops.gemv(vl, P["wov"], P["bov"])                    # out_v_proj (softmax over one token == 1)
+        gdv = (P["gv"] * dv[0]).contiguous()                     # gamma_v * delta_v [v_dim]
+        v_new, qp = ops.layernorm(x, P["lnv"][0], (P["lnv"][1] + gdv).contiguous(), P["lnv"][2], out_dtype=dt, add=lvl_pos)
+        kh = k.view(a.num_heads, a.head_dim)
+        u = torch.einsum("hd,hdi->hi", kh, P["wv"])              # W_v,h^T k_h       [8, v_dim]
+        c = (P["bv"] * kh).sum(-1)                               # b_v,h . k_h       [8]
+        sbias = (a.scale * (c - u @ gdv)).contiguous()           # scores are taken on LN_v(v) = v_new - gdv
+        S = ops.gemm(v_new, u.to(dt).contiguous(), sbias, alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
+        pooled = ops.vl_pool(S, v_new) - gdv[None, :]            # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
+        ol = torch.einsum("hi,hdi->hd", pooled, P["wvv"]) + P["bvv"]   # values_v_proj per head   [8, hd]
+        dl = ops.gemv(ol.reshape(1, -1).contiguous(), P["wol"], P["bol"])
+        l_new = l_n + P["gl"] * dl
+        return v_new, qp, l_new
+
+    def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
+        """reference signature (fuse_helper.py:221-232) for a single language token"""
+        if l.shape[1] != 1 or attention_mask_l is not None:
+            raise NotImplementedError("ape_amd BiAttentionBlock: only the single-text-token (name prompt) path is implemented")
+        dt = getattr(self, "compute_dtype", torch.bfloat16)
+        vs, ls = [], []
+        for b in range(v.shape[0]):
+            zeros = torch.zeros_like(v[b], dtype=dt)
+            vn, _, ln = self.forward_tokens_single(v[b].to(dt).contiguous(), zeros, l[b].float().contiguous(), dt)
+            vs.append(vn.to(v.dtype))
+            ls.append(ln.to(l.dtype))
+        return torch.stack(vs), torch.stack(ls)

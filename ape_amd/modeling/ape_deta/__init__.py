@@ -1,0 +1,5 @@
+"""Mirror of ape/modeling/ape_deta/__init__.py:1-16 for the VL (APE-*_D) model family."""
+from .ape_deta import SomeThing  # noqa: F401
+from .deformable_detr_segm_vl import DeformableDETRSegmVL  # noqa: F401
+from .deformable_transformer_vl import (DeformableDetrTransformerDecoderVL,  # noqa: F401
+                                        DeformableDetrTransformerEncoderVL, DeformableDetrTransformerVL)

@@ -1,0 +1,324 @@
+"""APE meta-architecture (inference forward) on the HIP kernels.
+
+Mirror of ape/modeling/ape_deta/deformable_detr_segm_vl.py (DeformableDETRSegmVL.forward :166-726,
+maskdino_mask_features :728-750, inference :759-810, preprocess_image :846-855, _postprocess_instance :857-872) and
+of the constructor in ape/modeling/ape_deta/deformable_detr.py:52-296 (heads :100-215): same class name, constructor
+kwargs and state-dict keys.  Training branches, the phrase/expression prompt modes (dense multi-token fusion) and
+the semantic / panoptic tails are outside this round's hot path and raise NotImplementedError.
+
+Per image (batch 1, like the reference's evaluation) the whole forward is a fixed sequence of HIP kernel launches
+on the current stream with no host synchronisation until the final device->host copy of the detections.
+"""
+import copy
+import math
+import time
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...layers import VisionLanguageAlign
+from ...packing import attach_cache, f32, pack_matrix
+from . import geometry as G
+from ._containers import MLP
+
+
+class _ConvGN(nn.Module):
+    """detectron2 Conv2d(bias=False[, norm=GN]) parameter holder: weight [Cout,Cin,k,k] (+ norm.{weight,bias})"""
+
+    def __init__(self, cin, cout, k, norm=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=1)
+        if norm:
+            self.norm = nn.GroupNorm(32, cout)
+
+
+class DeformableDETRSegmVL(nn.Module):
+    def __init__(self, backbone, position_embedding, neck, transformer, embed_dim, num_classes, num_queries, criterion,
+                 pixel_mean, pixel_std, aux_loss=True, with_box_refine=False, as_two_stage=False,
+                 select_box_nums_for_evaluation=100, select_box_nums_for_evaluation_list: list = None,
+                 input_format: Optional[str] = None, vis_period: int = 0, output_dir: Optional[str] = None,
+                 dataset_names: List[str] = [], dataset_metas: List[str] = [], dataset_prompts: List[str] = None,
+                 embed_dim_language: int = 512, text_feature_batch_repeat: bool = True, text_feature_bank: bool = False,
+                 text_feature_bank_reset: bool = False, text_feature_bank_random_size: bool = False,
+                 text_feature_reduce_type: str = "last", text_feature_reduce_before_fusion: bool = True,
+                 expression_cumulative_gt_class: bool = True, test_nms_thresh: float = 0.7, test_score_thresh: float = 0.0,
+                 last_class_embed_use_mlp: bool = False, openset_classifier: str = "VisionLanguageAlign",
+                 # DeformableDETRSegmVL's own kwargs (deformable_detr_segm_vl.py:63-88)
+                 instance_on: bool = True, semantic_on: bool = False, panoptic_on: bool = False, freeze_detr=False,
+                 input_shapes=[], mask_in_features=[], mask_encode_level=0, stuff_dataset_learn_thing: bool = True,
+                 stuff_prob_thing: float = -1.0, name_prompt_fusion_type: str = "none", name_prompt_fusion_text: bool = None,
+                 test_mask_on: bool = True, semantic_post_nms: bool = True, panoptic_post_nms: bool = True,
+                 aux_mask: bool = False, panoptic_configs: dict = None):
+        super().__init__()
+        assert with_box_refine and as_two_stage and openset_classifier == "VisionLanguageAlign" and not aux_mask, \
+            "ape_amd implements the two-stage, box-refine, VisionLanguageAlign configuration of the APE-*_D models"
+        self.backbone, self.position_embedding, self.neck, self.transformer = backbone, position_embedding, neck, transformer
+        self.num_queries, self.num_classes = num_queries, num_classes
+        self.aux_loss, self.with_box_refine, self.as_two_stage = aux_loss, with_box_refine, as_two_stage
+        self.criterion = nn.ModuleList([c for c in (criterion or []) if isinstance(c, nn.Module)])
+        num_pred = transformer.decoder.num_layers + 1
+        # heads (deformable_detr.py:100-200): class_embed[i] / bbox_embed[i] are SHARED with transformer.decoder
+        self.class_embed = nn.ModuleList([VisionLanguageAlign(embed_dim, embed_dim_language) for _ in range(num_pred)])
+        self.bbox_embed = nn.ModuleList([MLP(embed_dim, embed_dim, 4, 3) for _ in range(num_pred)])
+        self.transformer.decoder.bbox_embed = self.bbox_embed
+        self.transformer.decoder.class_embed = self.class_embed
+        self.transformer.decoder.class_embed[-1] = nn.Linear(embed_dim, 1)   # class-agnostic encoder classifier (:178-179)
+        if self.transformer.proposal_ambiguous:
+            n = self.transformer.proposal_ambiguous
+            assert n == 1, "ape_amd implements proposal_ambiguous in {0 -> unsupported, 1}"
+            self.transformer.decoder.bbox_embed_ambiguous = nn.ModuleList([MLP(embed_dim, embed_dim, 4, 3) for _ in range(n)])
+            self.transformer.decoder.class_embed_ambiguous = nn.ModuleList([nn.Linear(embed_dim, 1) for _ in range(n)])
+        else:
+            raise NotImplementedError("ape_amd: proposal_ambiguous=0 (the eval scripts set it to 1)")
+        self.select_box_nums_for_evaluation = select_box_nums_for_evaluation
+        self.select_box_nums_for_evaluation_list = select_box_nums_for_evaluation_list
+        self.test_topk_per_image = select_box_nums_for_evaluation
+        self.test_nms_thresh, self.test_score_thresh = test_nms_thresh, test_score_thresh
+        self.input_format, self.vis_period, self.output_dir = input_format, vis_period, output_dir
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        self._mean, self._std = tuple(float(v) for v in pixel_mean), tuple(float(v) for v in pixel_std)
+        self.dataset_names, self.dataset_prompts = dataset_names, dataset_prompts
+        self.dataset_metas = [dataset_metas] if isinstance(dataset_metas, str) else list(dataset_metas)
+        self.dataset_name_to_idx = {k: i for i, k in enumerate(self.dataset_names)}
+        self.class_names = {}                       # dataset name -> list[str]; filled by set_class_names (MetadataCatalog stand-in)
+        self.eval_dataset_id, self.eval_dataset_entity = -1, ""
+        self.text_feature_bank, self.text_feature_bank_reset = text_feature_bank, text_feature_bank_reset
+        self.embed_dim_language = embed_dim_language
+        self.instance_on, self.semantic_on, self.panoptic_on = instance_on, semantic_on, panoptic_on
+        self.input_shapes, self.mask_in_features, self.mask_encode_level = input_shapes, mask_in_features, mask_encode_level
+        assert len(mask_in_features) == 1 and mask_encode_level == 0
+        hidden = self.transformer.embed_dim
+        cin = getattr(input_shapes[mask_in_features[0]], "channels", input_shapes[mask_in_features[0]])
+        self.lateral_conv = _ConvGN(cin, hidden, 1)
+        self.output_conv = _ConvGN(hidden, hidden, 3)
+        self.mask_conv = _ConvGN(hidden, hidden, 1, norm=False)
+        self.mask_embed = MLP(hidden, hidden, hidden, 3)
+        self.test_mask_on = test_mask_on
+        self.name_prompt_fusion_type = name_prompt_fusion_type
+        if name_prompt_fusion_type == "zero":
+            self.name_prompt_fusion_feature = nn.Parameter(torch.zeros(1, 1, embed_dim_language), requires_grad=False)
+        elif name_prompt_fusion_type == "learnable":
+            self.name_prompt_fusion_feature = nn.Parameter(torch.randn(1, 1, embed_dim_language))
+        else:
+            raise NotImplementedError("ape_amd: name_prompt_fusion_type must be 'zero' or 'learnable' (fusion needs a token)")
+        self.model_language = None
+        self.compute_dtype = torch.bfloat16
+        self._geo, self._text = {}, {}
+        self.preprocess_time = self.backbone_time = self.transformer_time = self.postprocess_time = 0.0
+        attach_cache(self)
+        def _drop_caches(m, incompatible):
+            m._geo.clear()
+            m._text.clear()
+
+        self.register_load_state_dict_post_hook(_drop_caches)
+
+    # ------------------------------------------------------------------ configuration helpers
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def set_compute_dtype(self, dt):
+        """torch.bfloat16 (production) or torch.float32 (exact-math validation mode)"""
+        self.compute_dtype = dt
+        for m in self.modules():
+            if hasattr(m, "compute_dtype") and m is not self and not isinstance(getattr(type(m), "compute_dtype", None), property):
+                m.compute_dtype = dt
+        return self
+
+    def set_model_language(self, model_language):
+        self.model_language = model_language
+
+    def set_eval_dataset(self, dataset_name):
+        for d in self.dataset_names:
+            if sum([dd in dataset_name for dd in d.split("+")]):
+                self.eval_dataset_id = self.dataset_name_to_idx[d]
+                break
+        else:
+            self.eval_dataset_id = -1
+
+    def set_class_names(self, dataset_id, names):
+        self.class_names[dataset_id] = list(names)
+
+    # ------------------------------------------------------------------ packing
+    def packed(self, dt):
+        def build(dt):
+            def conv(m):
+                w = m.weight.detach().float()
+                return pack_matrix(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), dt)
+            neck = [(pack_matrix(c.conv.weight.detach().reshape(c.conv.weight.shape[0], -1), dt), f32(c.conv.bias),
+                     f32(c.norm.weight), f32(c.norm.bias), c.norm.num_groups, c.norm.eps) for c in self.neck.convs]
+            gn = lambda m: (f32(m.norm.weight), f32(m.norm.bias), m.norm.num_groups, m.norm.eps)  # noqa: E731
+            return dict(neck=neck, lat=(conv(self.lateral_conv),) + gn(self.lateral_conv),
+                        outc=(conv(self.output_conv),) + gn(self.output_conv), maskc=conv(self.mask_conv))
+        return self._pack.get(self, dt, build)
+
+    def geometry(self, image_size, level_shapes):
+        key = (tuple(image_size), tuple(level_shapes), str(self.device))
+        if key not in self._geo:
+            pe = self.position_embedding
+            cfg = dict(num_pos_feats=pe.num_pos_feats, temperature=pe.temperature, normalize=pe.normalize, offset=pe.offset,
+                       eps=pe.eps, scale=pe.scale)
+            square = self.backbone.padding_constraints.get("square_size", 0)
+            self._geo[key] = G.build_geometry(square, image_size, level_shapes, self.device, cfg)
+        return self._geo[key]
+
+    # ------------------------------------------------------------------ text side
+    def text_features(self, batched_input):
+        """name-prompt text bank [K, D_l] fp32 on the device (deformable_detr_segm_vl.py:224-259)"""
+        if "text_features" in batched_input:                       # pre-computed CLIP features (the broadcast payload)
+            return batched_input["text_features"].to(self.device).float(), None
+        if self.eval_dataset_id >= 0:
+            prompt = self.dataset_prompts[self.eval_dataset_id]
+            names, cache = self.class_names[self.eval_dataset_id], True
+        else:
+            prompt = batched_input.get("prompt", "name")
+            if prompt == "text":
+                names = [x.strip() for x in batched_input["text_prompt"].split(",") if len(x.strip()) > 0]
+                prompt = "phrase" if any(x.count(" ") >= 1 for x in names) else "name"
+                cache = False
+            else:
+                names, cache = sum((self.class_names[i] for i in sorted(self.class_names)), [])[:1203], True
+        if prompt != "name":
+            raise NotImplementedError("ape_amd: phrase / expression prompts (dense multi-token fusion) are not implemented yet")
+        if self.model_language is None:
+            raise RuntimeError("no text tower attached (set_model_language) and no 'text_features' in the input")
+        out = self.model_language.forward_text(names, cache=cache)
+        return out["last_hidden_state_eot"].to(self.device).float(), names
+
+    def class_tokens(self, feats, lvl, dt):
+        """per-vocabulary constants of the last-level classifier, cached by tensor identity"""
+        key = (feats.data_ptr(), feats._version, tuple(feats.shape), lvl, dt)
+        if key not in self._text:
+            if len(self._text) > 16:
+                self._text.clear()
+            self._text[key] = self.class_embed[lvl].text_side(feats, dt)
+        return self._text[key]
+
+    # ------------------------------------------------------------------ the hot path, one image
+    def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True):
+        """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes)."""
+        dt = self.compute_dtype
+        P = self.packed(dt)
+        h, w = image.shape[-2:]
+        t0 = time.perf_counter()
+        maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std)
+        self.backbone_time = time.perf_counter() - t0
+        names = self.neck.in_features
+        level_shapes = [maps[f][1] for f in names]
+        geo = self.geometry((h, w), level_shapes)
+        t0 = time.perf_counter()
+        src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
+        for i, f in enumerate(names):
+            wn, bn, gw, gb, groups, eps = P["neck"][i]
+            t = ops.gemm(maps[f][0], wn, bn)
+            ops.groupnorm(t, gw, gb, groups, eps, out=src[geo.starts[i]:geo.starts[i] + t.shape[0]])
+        if stages is not None:
+            stages.update({k: v[0] for k, v in maps.items()})
+            stages["enc_input"] = src
+        l0 = self.name_prompt_fusion_feature.detach().float().reshape(1, -1)
+        tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages)
+        self.transformer_time = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        # last decoder level only feeds inference (:519-524); "name" mode classifies against the RAW text bank (:446)
+        lvl = self.transformer.decoder.num_layers - 1
+        x = tr["inter_states"][lvl]
+        ref_prev = tr["init_reference"] if lvl == 0 else tr["inter_references"][lvl - 1]
+        tok, cbias = self.class_tokens(text_feats, lvl, dt)
+        logits = self.class_embed[lvl].forward_tokens(x, tok, cbias)                                  # [Q,K] fp32
+        boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
+        out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
+        det = self.inference_single(logits, boxes, (h, w))
+        out.update(det)
+        if with_masks and self.test_mask_on:
+            # maskdino_mask_features (:728-750): lateral 1x1 + GN, + encoder memory of level 0, 3x3 + GN + ReLU, 1x1
+            H0, W0 = geo.shapes[0]
+            p2 = maps[self.mask_in_features[0]][0]
+            lat = ops.gemm(p2, P["lat"][0], None)
+            lat = ops.groupnorm(lat, P["lat"][1], P["lat"][2], P["lat"][3], P["lat"][4], add=tr["memory"][: H0 * W0])
+            y = ops.gemm(ops.im2col3x3(lat, None, H0, W0), P["outc"][0], None)
+            y = ops.groupnorm(y, P["outc"][1], P["outc"][2], P["outc"][3], P["outc"][4], act=ops.ACT_RELU)
+            mask_feat = ops.gemm(y, P["maskc"], None)                                                 # [H0*W0, 256]
+            membed = self.mask_embed.forward_tokens(x, dt, out_dtype=dt)                              # [Q,256]
+            # only the kept queries are decoded / upsampled: the einsum (:510) and F.interpolate (:569-572) act per query
+            kept = ops.gather_rows(membed, det["det_query"].to(torch.int32))
+            mlog = ops.gemm(kept, mask_feat, None, out_dtype=torch.float32)                           # [n, H0*W0]
+            S = self.backbone.padding_constraints.get("square_size", 0)
+            bits = ops.mask_upsample_bits(mlog, H0, W0, S)
+            out["det_masks128"] = ops.roi_align_bits(bits, det["det_boxes"].contiguous(), 128)
+            if stages is not None:
+                stages.update(mask_features=mask_feat, mask_embed=membed, det_mask_logits=mlog)
+        if stages is not None:
+            stages.update(pred_logits=logits, pred_boxes=boxes, inter_states=torch.stack(tr["inter_states"])[:, None],
+                          inter_references=torch.stack(tr["inter_references"])[:, None], **det)
+        self.postprocess_time = time.perf_counter() - t0
+        return out
+
+    def inference_single(self, logits, boxes, image_size):
+        """sigmoid scores, cxcywh -> xyxy * (w,h,w,h), clip, score threshold, class-wise NMS, top-k
+        (deformable_detr_segm_vl.py:759-810 + ape_deta/fast_rcnn.py:97-201).  Fixed-shape outputs:
+        det_boxes [k,4], det_scores [k] (-1 = empty slot), det_classes [k], det_query [k]."""
+        h, w = image_size
+        Q, K = logits.shape
+        scores = logits.sigmoid()
+        cx, cy, bw, bh = boxes.unbind(-1)
+        scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=boxes.device)
+        xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1) * scale
+        finite = torch.isfinite(xyxy).all(1) & torch.isfinite(scores).all(1)
+        xyxy = torch.stack([xyxy[:, 0].clamp(0, w), xyxy[:, 1].clamp(0, h), xyxy[:, 2].clamp(0, w), xyxy[:, 3].clamp(0, h)], -1)
+        xyxy = torch.where(finite[:, None], xyxy, torch.zeros_like(xyxy)).contiguous()
+        st = scores.t().contiguous()                                               # [K,Q]
+        sorted_scores, order = torch.sort(st, dim=1, descending=True, stable=True)
+        valid = (sorted_scores > self.test_score_thresh) & finite[order]
+        keep = ops.nms_classes(xyxy, order.to(torch.int32).contiguous(), self.test_nms_thresh, valid.to(torch.uint8).contiguous())
+        masked = torch.where(keep.bool(), sorted_scores, torch.full_like(sorted_scores, -1.0)).reshape(-1)
+        k = min(self.test_topk_per_image, masked.numel())
+        top_scores, flat = torch.sort(masked, descending=True, stable=True)
+        top_scores, flat = top_scores[:k], flat[:k]
+        cls = torch.div(flat, Q, rounding_mode="floor")
+        qidx = order.reshape(-1)[flat]
+        return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)
+
+    # ------------------------------------------------------------------ reference entry point
+    @torch.no_grad()
+    def forward(self, batched_inputs, do_postprocess=True):
+        if self.training:
+            raise NotImplementedError("ape_amd implements the inference forward only")
+        if self.semantic_on or self.panoptic_on:
+            raise NotImplementedError("ape_amd: semantic / panoptic tails are not implemented yet (instance branch only)")
+        results = []
+        for inp in batched_inputs:
+            t0 = time.perf_counter()
+            image = inp["image"].to(self.device, non_blocking=True).float()
+            feats, _ = self.text_features(inp)
+            self.preprocess_time = time.perf_counter() - t0
+            out = self.forward_single(image, feats)
+            h, w = image.shape[-2:]
+            results.append({"instances": self.postprocess_instance(out, (h, w), inp.get("height", h), inp.get("width", w))})
+        return results
+
+    def postprocess_instance(self, out, image_size, height, width):
+        """detector_postprocess (:857-872): rescale to (height, width), clip, drop empty boxes, paste masks; the
+        result is moved to the CPU like the reference (`r.to("cpu")`)."""
+        h, w = image_size
+        boxes = out["det_boxes"].clone()
+        sx, sy = width / w, height / h
+        boxes[:, 0::2] = (boxes[:, 0::2] * sx).clamp(0, width)
+        boxes[:, 1::2] = (boxes[:, 1::2] * sy).clamp(0, height)
+        keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+        res = SimpleNamespace(image_size=(height, width))
+        masks = None
+        if "det_masks128" in out:
+            masks = ops.paste_bits(out["det_masks128"], boxes.contiguous(), height, width)
+        keep_c = keep.cpu()                                   # the one host sync of the forward
+        res.pred_boxes = boxes.cpu()[keep_c]
+        res.scores = out["det_scores"].cpu()[keep_c]
+        res.pred_classes = out["det_classes"].cpu()[keep_c]
+        res.query_index = out["det_query"].cpu()[keep_c]
+        if masks is not None:
+            res.pred_masks = masks.cpu()[keep_c].bool()
+        return res

@@ -1,0 +1,273 @@
+"""DETA-style two-stage deformable transformer with vision-language fusion, on the HIP kernels.
+
+Mirror of ape/modeling/ape_deta/deformable_transformer_vl.py: DeformableDetrTransformerEncoderVL (:20-121),
+DeformableDetrTransformerDecoderVL (:124-255), DeformableDetrTransformerVL (:258-699) with the same constructor
+kwargs and (detrex-compatible) parameter names.  The token stream is a single [T, 256] token-major tensor (the
+reference's flatten(2).transpose(1,2) layout is our native one), per-image-size constants come from geometry.py,
+and all arithmetic goes through ape_amd.ops.  Batch = 1 per forward like the reference's evaluation
+(ape/data/build.py:79; fuse_helper.py:89-90 couples images inside a batch through a global max).
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...layers import MultiScaleDeformableAttention
+from ...packing import attach_cache, f32, pack_matrix, round_up
+from . import geometry as G
+from ._containers import FFN, SelfAttention, TransformerLayer
+
+
+def stable_topk(values, k):
+    """indices of the k largest values, ties by lowest index (the defined tie rule; torch.topk's is unspecified)"""
+    return torch.sort(values, descending=True, stable=True)[1][:k]
+
+
+class DeformableDetrTransformerEncoderVL(nn.Module):
+    def __init__(self, embed_dim=256, num_heads=8, feedforward_dim=1024, attn_dropout=0.1, ffn_dropout=0.1, num_layers=6,
+                 post_norm=False, num_feature_levels=4, vl_layer=None, use_act_checkpoint=False, pytorch_attn=False):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            TransformerLayer([MultiScaleDeformableAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=attn_dropout,
+                                                            batch_first=True, num_levels=num_feature_levels,
+                                                            pytorch_attn=pytorch_attn)],
+                             FFN(embed_dim=embed_dim, feedforward_dim=feedforward_dim, output_dim=embed_dim, num_fcs=2,
+                                 ffn_drop=ffn_dropout), 2, embed_dim) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.embed_dim = embed_dim
+        self.pre_norm = False
+        self.post_norm_layer = nn.LayerNorm(embed_dim) if post_norm else None
+        self.vl_layers = nn.ModuleList([copy.deepcopy(vl_layer) for _ in range(num_layers)])
+        self.use_checkpoint = use_act_checkpoint
+
+    def forward_tokens(self, x, geo, lvl_pos, l, dt, stages=None):
+        """x [T,256], l [1, l_dim] fp32 -> (memory [T,256], l) -- reference loop :84-115"""
+        for i, (vl, layer) in enumerate(zip(self.vl_layers, self.layers)):
+            v_new, qp, l = vl.b_attn.forward_tokens_single(x, lvl_pos, l, dt)
+            if stages is not None:
+                stages[f"enc{i}_fused_v"], stages[f"enc{i}_fused_l"] = v_new, l
+            # BaseTransformerLayer ("self_attn", "norm", "ffn", "norm"): value = fused tokens (no pos), identity = same
+            x1 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
+                                                    mask=geo.mask_u8)
+            x2 = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt)
+            x3 = layer.ffns[0].forward_tokens(x2, dt)
+            x = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
+            if stages is not None:
+                stages[f"enc{i}_out"] = x
+        if self.post_norm_layer is not None:
+            x = ops.layernorm(x, f32(self.post_norm_layer.weight), f32(self.post_norm_layer.bias), self.post_norm_layer.eps, out_dtype=dt)
+        return x, l
+
+
+class DeformableDetrTransformerDecoderVL(nn.Module):
+    def __init__(self, embed_dim=256, num_heads=8, feedforward_dim=1024, attn_dropout=0.1, ffn_dropout=0.1, num_layers=6,
+                 return_intermediate=True, num_feature_levels=4, use_act_checkpoint=False, look_forward_twice=False,
+                 pytorch_attn=False):
+        super().__init__()
+        self.layers = nn.ModuleList([
+            TransformerLayer([SelfAttention(embed_dim=embed_dim, num_heads=num_heads, attn_drop=attn_dropout, batch_first=True),
+                              MultiScaleDeformableAttention(embed_dim=embed_dim, num_heads=num_heads, dropout=attn_dropout,
+                                                            batch_first=True, num_levels=num_feature_levels,
+                                                            pytorch_attn=pytorch_attn)],
+                             FFN(embed_dim=embed_dim, feedforward_dim=feedforward_dim, output_dim=embed_dim, ffn_drop=ffn_dropout),
+                             3, embed_dim) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.embed_dim = embed_dim
+        self.return_intermediate = return_intermediate
+        self.bbox_embed = None
+        self.class_embed = None
+        self.use_checkpoint = use_act_checkpoint
+        self.look_forward_twice = look_forward_twice
+        attach_cache(self)
+
+    def packed(self, dt):
+        def build(dt):
+            ws = [l.attentions[1].value_proj.weight for l in self.layers]
+            bs = [l.attentions[1].value_proj.bias.detach().float() for l in self.layers]
+            return dict(wval=pack_matrix(torch.cat(ws, 0), dt), bval=torch.cat(bs).contiguous())
+        return self._pack.get(self, dt, build)
+
+    def forward_tokens(self, query, query_pos, memory, geo, reference, dt):
+        """query/query_pos [Q,256], memory [T,256], reference [Q,4] fp32 (sigmoid space) -> (inter [list of Q,256],
+        inter_ref [list of Q,4]) -- reference loop :195-250"""
+        P = self.packed(dt)
+        E = self.embed_dim
+        # value_proj of all layers in ONE pass over the encoder memory (the reference re-reads it per layer)
+        value_all = ops.gemm(memory, P["wval"], P["bval"], rowmask=geo.mask_u8, mask_mode=ops.MASK_ZERO_OUTPUT)
+        Q = query.shape[0]
+        vt_buf = torch.zeros((E, round_up(Q, 64)), dtype=dt, device=query.device)
+        vr4 = torch.cat([geo.valid_ratios, geo.valid_ratios], -1)      # [L, 4]
+        out = query
+        outp = (query.float() + query_pos.float()).to(dt)
+        inter, inter_ref = [], []
+        for i, layer in enumerate(self.layers):
+            ref_in = (reference[:, None, :] * vr4[None]).contiguous()
+            x1 = layer.attentions[0].forward_tokens(out, outp, dt, vt_buf)
+            x2, x2p = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt, add=query_pos)
+            x3 = layer.attentions[1].forward_tokens(x2p, x2, ref_in, geo.shapes, geo.starts, dt,
+                                                    value=value_all[:, i * E:(i + 1) * E])
+            x4 = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
+            x5 = layer.ffns[0].forward_tokens(x4, dt)
+            out, outp = ops.layernorm(x5, *layer.norm_params(2), out_dtype=dt, add=query_pos)
+            if self.bbox_embed is not None:
+                tmp = self.bbox_embed[i].forward_tokens(out, dt, out_dtype=torch.float32)
+                reference = (tmp + G.inverse_sigmoid(reference)).sigmoid()
+            inter.append(out)
+            inter_ref.append(reference)
+        return inter, inter_ref
+
+
+class DeformableDetrTransformerVL(nn.Module):
+    def __init__(self, encoder=None, decoder=None, num_feature_levels=4, as_two_stage=False, two_stage_num_proposals=300,
+                 assign_first_stage=False, pre_nms_topk=1000, nms_thresh_enc=0.9, proposal_ambiguous=0):
+        super().__init__()
+        assert as_two_stage and assign_first_stage, "ape_amd implements the two-stage DETA selection used by every APE config"
+        self.encoder, self.decoder = encoder, decoder
+        self.num_feature_levels = num_feature_levels
+        self.as_two_stage = as_two_stage
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.assign_first_stage = assign_first_stage
+        self.pre_nms_topk, self.nms_thresh_enc = pre_nms_topk, nms_thresh_enc
+        self.proposal_ambiguous = proposal_ambiguous
+        self.embed_dim = self.encoder.embed_dim
+        self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dim))
+        self.enc_output = nn.Linear(self.embed_dim, self.embed_dim)
+        self.enc_output_norm = nn.LayerNorm(self.embed_dim)
+        self.pos_trans = nn.Linear(self.embed_dim * 2, self.embed_dim * 2)
+        self.pos_trans_norm = nn.LayerNorm(self.embed_dim * 2)
+        self.pix_trans = nn.Linear(self.embed_dim, self.embed_dim)
+        self.pix_trans_norm = nn.LayerNorm(self.embed_dim)
+        nn.init.normal_(self.level_embeds)
+        attach_cache(self)
+
+    # ------------------------------------------------------------------ packing
+    def packed(self, dt):
+        def build(dt):
+            dec = self.decoder
+            nd = dec.num_layers
+            be, bea = dec.bbox_embed[nd], dec.bbox_embed_ambiguous[0]
+            ce, cea = dec.class_embed[nd], dec.class_embed_ambiguous[0]
+            return dict(
+                wenc=pack_matrix(self.enc_output.weight, dt), benc=f32(self.enc_output.bias),
+                nenc=(f32(self.enc_output_norm.weight), f32(self.enc_output_norm.bias), self.enc_output_norm.eps),
+                wpos=pack_matrix(self.pos_trans.weight, dt), bpos=f32(self.pos_trans.bias),
+                npos=(f32(self.pos_trans_norm.weight), f32(self.pos_trans_norm.bias), self.pos_trans_norm.eps),
+                wpix=pack_matrix(self.pix_trans.weight, dt), bpix=f32(self.pix_trans.bias),
+                npix=(f32(self.pix_trans_norm.weight), f32(self.pix_trans_norm.bias), self.pix_trans_norm.eps),
+                # two-stage heads: main + ambiguous copies share their input, so their first layers are one GEMM
+                w1=pack_matrix(torch.cat([be.layers[0].weight, bea.layers[0].weight], 0), dt),
+                b1=torch.cat([be.layers[0].bias, bea.layers[0].bias]).detach().float().contiguous(),
+                w2=(pack_matrix(be.layers[1].weight, dt), pack_matrix(bea.layers[1].weight, dt)),
+                b2=(f32(be.layers[1].bias), f32(bea.layers[1].bias)),
+                w3=(pack_matrix(be.layers[2].weight, dt), pack_matrix(bea.layers[2].weight, dt)),
+                b3=(f32(be.layers[2].bias), f32(bea.layers[2].bias)),
+                wcls=pack_matrix(torch.cat([ce.weight, cea.weight], 0), dt),
+                bcls=torch.cat([ce.bias, cea.bias]).detach().float().contiguous(),
+                level_embeds=f32(self.level_embeds))
+        return self._pack.get(self, dt, build)
+
+    def lvl_pos(self, geo, dt):
+        key = (dt, self.level_embeds.data_ptr(), self.level_embeds._version)
+        if key not in geo._lvl_pos:
+            geo._lvl_pos.clear()
+            geo._lvl_pos[key] = (geo.pos + self.level_embeds.detach().float()[geo.level_ids]).to(dt).contiguous()
+        return geo._lvl_pos[key]
+
+    # ------------------------------------------------------------------ two-stage selection (:565-627)
+    def select_proposals(self, logit, boxes, geo):
+        """logit [T] fp32, boxes [T,4] xyxy in [0,1] -> topk_proposals [num_queries] int64.
+        Sync-free (fixed shapes); torch glue around the HIP NMS (ape_amd.ops.nms_segments)."""
+        dev = logit.device
+        T, L = logit.numel(), len(geo.shapes)
+        k = min(self.pre_nms_topk, T)
+        nq = self.two_stage_num_proposals
+        prob = logit.sigmoid()
+        cands = []
+        for lvl, ((H, W), start) in enumerate(zip(geo.shapes, geo.starts)):
+            n_l = H * W
+            # torch.topk(sigmoid * level_mask, k) with ties by lowest index: the level's tokens by descending score,
+            # then (levels shorter than k) the lowest-index tokens of OTHER levels, whose masked score is exactly 0
+            inl = start + stable_topk(prob[start:start + n_l], min(k, n_l))
+            if n_l < k:
+                extra = torch.arange(k - n_l, device=dev)
+                extra = torch.where(extra >= start, extra + n_l, extra)
+                inl = torch.cat([inl, extra])
+            cands.append(inl)
+        cand = torch.cat(cands)
+        n = cand.numel()
+        sc, lv, bx = logit[cand], geo.level_ids[cand], boxes[cand]
+        o1 = torch.sort(sc, descending=True, stable=True)[1]          # global descending-score order (batched_nms output order)
+        o2 = torch.sort(lv[o1], stable=True)[1]                       # level-major, score order kept inside a level
+        order = o1[o2]
+        ar = torch.arange(L, device=dev)
+        counts = (lv[None, :] == ar[:, None]).sum(1)
+        seg = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+        keep_s = ops.nms_segments(bx[order].float().contiguous(), lv[order].to(torch.int32).contiguous(), seg, n, self.nms_thresh_enc)
+        keep1 = torch.zeros(n, dtype=torch.bool, device=dev)
+        keep1[o2] = keep_s.bool()                                     # flags in o1 (score) order
+        cand1, lv1 = cand[o1], lv[o1]
+        # "nms proposals < num_queries -> naive top-k" fallback (:600-606), selected on the device
+        alt = stable_topk(logit, min(nq, T))
+        pad = n - alt.numel()
+        cand_alt = torch.cat([alt, alt.new_zeros(pad)]) if pad > 0 else alt[:n]
+        valid_alt = torch.arange(n, device=dev) < alt.numel()
+        use_alt = keep1.sum() < nq
+        candx = torch.where(use_alt, cand_alt, cand1)
+        valid = torch.where(use_alt, valid_alt, keep1)
+        lvx = torch.where(use_alt, geo.level_ids[cand_alt], lv1)
+        is_lvl = (lvx[None, :] == ar[:, None]) & valid[None, :]
+        sel = (is_lvl & (is_lvl.cumsum(1) <= nq // L)).any(0)
+        need = nq - sel.sum()
+        notsel = valid & ~sel
+        sel = sel | (notsel & (notsel.cumsum(0) <= need))
+        slot = torch.where(sel, sel.cumsum(0) - 1, torch.full_like(candx, nq))
+        out = torch.zeros(nq + 1, dtype=torch.long, device=dev)
+        out.scatter_(0, slot, candx)
+        return out[:nq]
+
+    # ------------------------------------------------------------------ forward (:422-699), batch 1
+    def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None):
+        """src [T,256] neck output (token-major, levels concatenated), l [1, l_dim] fp32 fusion token(s)."""
+        P = self.packed(dt)
+        lvl_pos = self.lvl_pos(geo, dt)
+        memory, l_out = self.encoder.forward_tokens(src, geo, lvl_pos, l, dt, stages)
+        # gen_encoder_output_proposals (:321-369): rows of padded / out-of-range anchors enter enc_output as zeros
+        om = ops.gemm(memory, P["wenc"], P["benc"], rowmask=geo.invalid_u8, mask_mode=ops.MASK_ZERO_INPUT)
+        om = ops.layernorm(om, *P["nenc"], out_dtype=dt)
+        E = self.embed_dim
+        T = om.shape[0]
+        h1 = ops.gemm(om, P["w1"], P["b1"], act=ops.ACT_RELU)                                    # [T, 2E]
+        h2 = torch.empty((T, 2 * E), dtype=dt, device=om.device)
+        ops.gemm(h1[:, :E], P["w2"][0], P["b2"][0], act=ops.ACT_RELU, out=h2[:, :E])
+        ops.gemm(h1[:, E:], P["w2"][1], P["b2"][1], act=ops.ACT_RELU, out=h2[:, E:])
+        d = torch.empty((T, 8), dtype=torch.float32, device=om.device)
+        ops.gemm(h2[:, :E], P["w3"][0], P["b3"][0], out=d[:, :4])
+        ops.gemm(h2[:, E:], P["w3"][1], P["b3"][1], out=d[:, 4:])
+        cls2 = ops.gemm(om, P["wcls"], P["bcls"], out_dtype=torch.float32)                       # [T, 2]
+        # ambiguous heads (:508-533): per token keep the (logit, box) pair with the larger logit (first on ties)
+        pick = cls2[:, 1] > cls2[:, 0]
+        enc_class = torch.where(pick, cls2[:, 1], cls2[:, 0])
+        enc_coord = torch.where(pick[:, None], d[:, 4:], d[:, :4]) + geo.proposals
+        if stages is not None:
+            stages.update(memory=memory, query_l=l_out, output_memory=om, enc_class=enc_class, enc_coord_unact=enc_coord)
+        if forced_topk is not None:
+            topk = forced_topk.to(om.device).long()
+        else:
+            cs = enc_coord.sigmoid()
+            xyxy = torch.stack([cs[:, 0] - 0.5 * cs[:, 2], cs[:, 1] - 0.5 * cs[:, 3], cs[:, 0] + 0.5 * cs[:, 2],
+                                cs[:, 1] + 0.5 * cs[:, 3]], -1).clamp(0, 1)
+            topk = self.select_proposals(enc_class, xyxy, geo)
+        coords = enc_coord[topk]                                          # [Q,4] unactivated
+        reference = coords.sigmoid()
+        pe = G.proposal_pos_embed(coords).to(dt).contiguous()
+        pt = ops.layernorm(ops.gemm(pe, P["wpos"], P["bpos"], out_dtype=torch.float32), *P["npos"], out_dtype=torch.float32)
+        query_pos = pt[:, :E].to(dt).contiguous()
+        feats = ops.gather_rows(om, topk.to(torch.int32))
+        pix = ops.layernorm(ops.gemm(feats, P["wpix"], P["bpix"], out_dtype=torch.float32), *P["npix"], out_dtype=torch.float32)
+        query = (pt[:, E:] + pix).to(dt).contiguous()
+        if stages is not None:
+            stages.update(topk_proposals=topk, query_init=query, query_pos=query_pos, init_reference=reference)
+        inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt)
+        return dict(inter_states=inter, init_reference=reference, inter_references=inter_ref, enc_class=enc_class,
+                    enc_coord_unact=enc_coord, memory=memory, query_l=l_out, topk_proposals=topk)

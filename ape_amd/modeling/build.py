@@ -1,0 +1,112 @@
+"""Build the APE-L_D model graph from our classes with the constructor arguments of the reference's LazyConfig
+(configs/common/backbone/vitl_eva02_clip.py:9-48, configs/COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py:24-137,
+configs/LVISCOCOCOCOSTUFF_O365_OID_VGR_SA1B_REFCOCO_GQA_PhraseCut_Flickr30k/ape_deta/
+ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py:36-108,171-177) -- what detectron2.config.instantiate(cfg.model)
+does in a full environment.  Scaled-down sizes exist for CPU-side tests.
+"""
+import math
+from functools import partial
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from ..layers import VisionLanguageFusion
+from .ape_deta import (DeformableDETRSegmVL, DeformableDetrTransformerDecoderVL, DeformableDetrTransformerEncoderVL,
+                       DeformableDetrTransformerVL, SomeThing)
+from .ape_deta._containers import ChannelMapper, PositionEmbeddingSine
+from .backbone.vit_eva_clip import LastLevelMaxPool, SimpleFeaturePyramid, ViT
+
+SIZES = {
+    "tiny": dict(img_size=256, embed_dim=128, depth=3, num_heads=2, window_size=8, pretrain_img_size=112, enc_layers=2,
+                 dec_layers=2, num_queries=300, topk_eval=50),
+    "small": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=3,
+                  dec_layers=3, num_queries=900, topk_eval=100),
+    "L_D": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336, enc_layers=6,
+                dec_layers=6, num_queries=900, topk_eval=100),
+    "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
+                     enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
+}
+
+
+def build_ape(size="L_D", model_language=None, **overrides):
+    c = SimpleNamespace(**{**SIZES[size], **overrides}) if isinstance(size, str) else SimpleNamespace(**{**size, **overrides})
+    feats = ["p2", "p3", "p4", "p5", "p6"]
+    net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
+              drop_path_rate=0.4, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
+              norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=[i for i in range(c.depth) if i % 3 != 2],
+              residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=True, xattn=True,
+              rope=True, pt_hw_seq_len=16, intp_freq=True, naiveswiglu=True, subln=True,
+              pretrain_img_size=c.pretrain_img_size, pretrain_use_cls_token=True)
+    backbone = SimpleFeaturePyramid(net=net, in_feature="last_feat", out_channels=256, scale_factors=(4.0, 2.0, 1.0, 0.5),
+                                    top_block=LastLevelMaxPool(), norm="LN", square_pad=c.img_size)
+    shapes = {f: SimpleNamespace(channels=256) for f in feats}
+    neck = ChannelMapper(input_shapes=shapes, in_features=feats, out_channels=256, num_outs=5, kernel_size=1,
+                         norm_layer=nn.GroupNorm(num_groups=32, num_channels=256))
+    vl = VisionLanguageFusion(v_dim=256, l_dim=1024, embed_dim=2048, num_heads=8, dropout=0.1, drop_path=0.0,
+                              init_values=1.0 / 6, stable_softmax_2d=True, clamp_min_for_underflow=True,
+                              clamp_max_for_overflow=True, use_checkpoint=True)
+    encoder = DeformableDetrTransformerEncoderVL(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0,
+                                                 ffn_dropout=0.0, num_layers=c.enc_layers, post_norm=False,
+                                                 num_feature_levels=5, vl_layer=vl, use_act_checkpoint=True)
+    decoder = DeformableDetrTransformerDecoderVL(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0,
+                                                 ffn_dropout=0.0, num_layers=c.dec_layers, return_intermediate=True,
+                                                 num_feature_levels=5)
+    transformer = DeformableDetrTransformerVL(encoder=encoder, decoder=decoder, as_two_stage=True, num_feature_levels=5,
+                                              two_stage_num_proposals=c.num_queries, assign_first_stage=True,
+                                              proposal_ambiguous=1)
+    mv = DeformableDETRSegmVL(
+        backbone=backbone, position_embedding=PositionEmbeddingSine(num_pos_feats=128, temperature=10000, normalize=True, offset=-0.5),
+        neck=neck, transformer=transformer, embed_dim=256, num_classes=1256, num_queries=c.num_queries, criterion=[],
+        pixel_mean=[123.675, 116.280, 103.530], pixel_std=[58.395, 57.120, 57.375], aux_loss=True, with_box_refine=True,
+        as_two_stage=True, select_box_nums_for_evaluation=c.topk_eval, input_format="RGB", mask_encode_level=0,
+        mask_in_features=["p2"], input_shapes=shapes, embed_dim_language=1024, instance_on=True, semantic_on=False,
+        panoptic_on=False, text_feature_bank=True, text_feature_reduce_before_fusion=True, text_feature_batch_repeat=True,
+        name_prompt_fusion_type="zero", dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"],
+        text_feature_bank_reset=True)
+    model = SomeThing(model_vision=mv, model_language=model_language)
+    model.eval()
+    return model
+
+
+@torch.no_grad()
+def init_synthetic(model, seed=0):
+    """Seeded NON-degenerate weights for benchmarking / smoke runs when no checkpoint is available: unit-variance
+    preserving linears, non-zero deformable offsets and attention logits (the reference zero-initialises those,
+    multi_scale_deform_attn.py:194-209, which would collapse every sample onto the reference point)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    seen = set()
+    for name, p in list(model.named_parameters()) + list(model.named_buffers()):
+        if id(p) in seen or name.endswith(("freqs_cos", "freqs_sin", "pixel_mean", "pixel_std")):
+            continue
+        seen.add(id(p))
+        leaf = name.rsplit(".", 1)[-1]
+        r = torch.randn(p.shape, generator=g)
+        if name.endswith("name_prompt_fusion_feature"):
+            t = torch.zeros(p.shape)
+        elif leaf in ("gamma_v", "gamma_l"):
+            t = 1.0 / 6 + 0.02 * r
+        elif leaf == "log_scale":
+            t = torch.zeros(p.shape)
+        elif leaf == "bias0" or (leaf == "bias" and p.numel() == 1):
+            t = -math.log(99.0) + 0.1 * r
+        elif leaf == "level_embeds":
+            t = r
+        elif leaf == "pos_embed":
+            t = 0.02 * r
+        elif name.endswith("sampling_offsets.bias"):
+            L = p.numel() // 64
+            th = torch.arange(8, dtype=torch.float32) * (2.0 * math.pi / 8)
+            grid = torch.stack([th.cos(), th.sin()], -1)
+            grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(8, 1, 1, 2).repeat(1, L, 4, 1)
+            for i in range(4):
+                grid[:, :, i, :] *= i + 1
+            t = grid.reshape(-1) + 0.1 * r
+        elif p.dim() >= 2:
+            t = r * ((0.5 if "sampling_offsets" in name else 1.0) / math.sqrt(p[0].numel()))
+        elif leaf == "weight":
+            t = 1.0 + 0.1 * r
+        else:
+            t = 0.02 * r
+        p.copy_(t.to(p.dtype))
+    return model

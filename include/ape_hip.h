@@ -45,7 +45,7 @@ int ape_hip_abi_version(void);
  *   ape/layers/fuse_helper.py:70-73 (VL projections), ape/layers/vision_language_align.py:36-49.
  * epilogue order: x = alpha*acc ; rowmask(ZERO_INPUT) ; + bias[n] ; RoPE (pairs) ; act ;
  *                 clamp(+-clamp) ; + residual[m,n] ; rowmask(ZERO_OUTPUT) ; store (out_dt).
- * bf16 inputs: K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W.  trans_out writes C^T[N][M]
+ * bf16 inputs: K % 8 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W.  trans_out writes C^T[N][M]
  * (ldc = leading dimension of C^T) and supports bias + activation only.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ApeGemmArgs {

@@ -1,0 +1,83 @@
+"""Host-side composition of the model (ape_amd.modeling / ape_amd.layers) checked on CPU: the HIP ops are swapped
+for their torch definitions (fixture `fake_ops`, tests/ref_ops.py) and the result is compared with the oracle and
+with the reference-generated golden fixtures.  This pins everything EXCEPT the kernels themselves, which the
+-m gpu tests pin against the same torch definitions."""
+import pytest
+import torch
+
+import model_util as M
+import oracle_util as U
+
+
+def test_state_dict_contract_full_size():
+    """our module tree exposes exactly the reference model's state-dict names/shapes (APE-L_D)"""
+    from ape_amd.modeling.build import build_ape
+
+    with torch.device("meta"):
+        model = build_ape("L_D")
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    spec = dict(U.load_spec("L_D"))
+    assert set(own) == set(spec), (sorted(set(spec) - set(own))[:5], sorted(set(own) - set(spec))[:5])
+    bad = [k for k in spec if own[k] != spec[k]]
+    assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square"])
+def test_fp32_host_pipeline_matches_oracle(fake_ops, case):
+    model, orc, image, text, gold = M.build_pair(case)
+    mv = model.model_vision
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    O = orc.stages
+    for k in ("p2", "p3", "p4", "p5", "p6", "enc0_fused_v", "enc0_fused_l", "enc1_out", "memory", "query_l", "output_memory",
+              "enc_class", "enc_coord_unact"):
+        b = M.token_major(k, O[k])
+        assert U.relerr(stages[k].reshape(b.shape), b) < 2e-4, k
+    # reference-generated fingerprints of the same stages (token-major <-> NCHW handled by comparing the oracle, which
+    # test_oracle.py pins to the fixtures); here only the proposal set is compared with the reference run directly
+    assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+    orc.forward(image, text, forced_topk=ref_topk[None])
+    assert (out["det_masks128"].bool() != orc.stages["det_masks128"]).float().mean().item() < 1e-3
+
+
+def test_forward_api_matches_oracle_instances(fake_ops):
+    """the reference entry point: model([{"image", "height", "width", ...}]) -> [{"instances": ...}]"""
+    model, orc, image, text, gold = M.build_pair("tiny_padded")
+    h, w = image.shape[-2:]
+    res = model([{"image": image, "height": 2 * h, "width": 2 * w, "text_features": text}])[0]["instances"]
+    oi = orc.forward(image, text, height=2 * h, width=2 * w)["instances"]
+    frac = U.match_detections(res.pred_boxes, res.scores, res.pred_classes, oi["pred_boxes"], oi["scores"], oi["pred_classes"])
+    assert frac >= 0.95
+    assert res.pred_masks.shape[1:] == (2 * h, 2 * w) and res.pred_masks.dtype == torch.bool
+
+
+def test_bf16_host_pipeline_reported(fake_ops):
+    """T3: bf16 storage at the kernels' rounding points vs the fp32 oracle -- reported, loose bound"""
+    model, orc, image, text, gold = M.build_pair("tiny_padded", dtype=torch.bfloat16)
+    mv = model.model_vision
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    O = orc.stages
+    errs = {k: U.relerr(stages[k].float().reshape(M.token_major(k, O[k]).shape), M.token_major(k, O[k]))
+            for k in ("p2", "p6", "memory", "enc_class")}
+    print("bf16 vs fp32 oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert errs["p2"] < 0.1 and errs["memory"] < 0.15
+    assert M.set_overlap(stages["topk_proposals"], O["topk_proposals"][0]) > 0.7
+
+
+def test_product_path_has_no_cpu_fallback():
+    """without the fake_ops fixture a CPU tensor must be refused loudly"""
+    import ape_amd.ops as ops
+
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))

@@ -41,7 +41,7 @@ TOL = {torch.bfloat16: 6e-3, torch.float32: 2e-5}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (4096, 1024, 1024), (900, 2048, 256), (1000, 130, 64), (333, 8, 256), (87296, 480, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (4096, 1024, 1024), (900, 2048, 256), (1000, 130, 64), (333, 8, 256), (87296, 480, 256), (700, 200, 2736), (130, 70, 40)])
 def test_gemm_plain(ops, dtype, M, N, K):
     if dtype == torch.float32 and M * N * K > 2e9:
         pytest.skip("f32 validation kernel: keep the case small")
