@@ -31,20 +31,20 @@ class VisionLanguageAlign(nn.Module):
         e = torch.nn.functional.normalize(embedding.float(), p=2, dim=-1)
         tok = ops.gemm((e / 2.0).contiguous(), P["w"], P["b"], out_dtype=torch.float32)
         bias = (torch.matmul(e, self.bias_lang.detach().float()) + self.bias0.detach().float()).contiguous()
-        return tok.to(dt).contiguous(), bias
+        inv_scale = 1.0 / float(self.log_scale.detach().exp())   # host scalar: read once per vocabulary, not per image
+        return tok.to(dt).contiguous(), bias, inv_scale
 
-    def forward_tokens(self, x, tok, bias):
+    def forward_tokens(self, x, tok, bias, inv_scale):
         """x [Q,256] compute dtype -> logits [Q,K] fp32 (:44-51)"""
-        scale = 1.0 / float(self.log_scale.detach().exp())
-        return ops.gemm(x, tok, bias, alpha=scale, clamp=50000.0 if self.clamp_dot_product else 0.0, out_dtype=torch.float32)
+        return ops.gemm(x, tok, bias, alpha=inv_scale, clamp=50000.0 if self.clamp_dot_product else 0.0, out_dtype=torch.float32)
 
     def forward(self, x, embedding):
         """reference signature: x [bs,Q,256], embedding [bs,K,D_l] -> [bs,Q,K]"""
         dt = self.compute_dtype
         outs = []
         for b in range(x.shape[0]):
-            tok, bias = self.text_side(embedding[b], dt)
-            outs.append(self.forward_tokens(x[b].to(dt).contiguous(), tok, bias).to(x.dtype))
+            tok, bias, inv_scale = self.text_side(embedding[b], dt)
+            outs.append(self.forward_tokens(x[b].to(dt).contiguous(), tok, bias, inv_scale).to(x.dtype))
         return torch.stack(outs)
 
 

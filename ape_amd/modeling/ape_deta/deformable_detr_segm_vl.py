@@ -228,11 +228,11 @@ class DeformableDETRSegmVL(nn.Module):
         lvl = self.transformer.decoder.num_layers - 1
         x = tr["inter_states"][lvl]
         ref_prev = tr["init_reference"] if lvl == 0 else tr["inter_references"][lvl - 1]
-        tok, cbias = self.class_tokens(text_feats, lvl, dt)
-        logits = self.class_embed[lvl].forward_tokens(x, tok, cbias)                                  # [Q,K] fp32
+        tok, cbias, inv_scale = self.class_tokens(text_feats, lvl, dt)
+        logits = self.class_embed[lvl].forward_tokens(x, tok, cbias, inv_scale)                       # [Q,K] fp32
         boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
         out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
-        det = self.inference_single(logits, boxes, (h, w))
+        det = self.inference_single(logits, boxes, (h, w), geo.box_scale)
         out.update(det)
         if with_masks and self.test_mask_on:
             # maskdino_mask_features (:728-750): lateral 1x1 + GN, + encoder memory of level 0, 3x3 + GN + ReLU, 1x1
@@ -258,7 +258,7 @@ class DeformableDETRSegmVL(nn.Module):
         self.postprocess_time = time.perf_counter() - t0
         return out
 
-    def inference_single(self, logits, boxes, image_size):
+    def inference_single(self, logits, boxes, image_size, scale=None):
         """sigmoid scores, cxcywh -> xyxy * (w,h,w,h), clip, score threshold, class-wise NMS, top-k
         (deformable_detr_segm_vl.py:759-810 + ape_deta/fast_rcnn.py:97-201).  Fixed-shape outputs:
         det_boxes [k,4], det_scores [k] (-1 = empty slot), det_classes [k], det_query [k]."""
@@ -266,7 +266,8 @@ class DeformableDETRSegmVL(nn.Module):
         Q, K = logits.shape
         scores = logits.sigmoid()
         cx, cy, bw, bh = boxes.unbind(-1)
-        scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=boxes.device)
+        if scale is None:
+            scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=boxes.device)
         xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1) * scale
         finite = torch.isfinite(xyxy).all(1) & torch.isfinite(scores).all(1)
         xyxy = torch.stack([xyxy[:, 0].clamp(0, w), xyxy[:, 1].clamp(0, h), xyxy[:, 2].clamp(0, w), xyxy[:, 3].clamp(0, h)], -1)

@@ -97,7 +97,7 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         value_all = ops.gemm(memory, P["wval"], P["bval"], rowmask=geo.mask_u8, mask_mode=ops.MASK_ZERO_OUTPUT)
         Q = query.shape[0]
         vt_buf = torch.zeros((E, round_up(Q, 64)), dtype=dt, device=query.device)
-        vr4 = torch.cat([geo.valid_ratios, geo.valid_ratios], -1)      # [L, 4]
+        vr4 = geo.vr4                                                   # [L, 4] = cat(valid_ratios, valid_ratios)
         out = query
         outp = (query.float() + query_pos.float()).to(dt)
         inter, inter_ref = [], []

@@ -15,10 +15,23 @@ import torch
 
 class LevelGeometry:
     __slots__ = ("shapes", "starts", "T", "mask", "mask_u8", "pos", "valid_ratios", "enc_ref", "proposals", "invalid_u8",
-                 "level_ids", "image_size", "_lvl_pos")
+                 "level_ids", "image_size", "_lvl_pos", "box_scale", "vr4", "arange_T")
 
     def __init__(self):
         self._lvl_pos = {}
+
+
+_DIM_T = {}
+
+
+def dim_t_table(num_pos_feats, temperature, device):
+    """temperature ** (2*(i//2)/n), computed on the HOST once per device: pow() may differ by an ulp between host and
+    device libms, and the sine embedding of fully padded rows/columns (argument ~ -3e6) is a chaotic function of it"""
+    key = (num_pos_feats, float(temperature), str(device))
+    if key not in _DIM_T:
+        d = torch.arange(num_pos_feats, dtype=torch.float32)
+        _DIM_T[key] = (temperature ** (2 * torch.div(d, 2, rounding_mode="floor") / num_pos_feats)).to(device)
+    return _DIM_T[key]
 
 
 def _sine_pos(mask, num_pos_feats, temperature, normalize, offset, eps, scale):
@@ -29,8 +42,7 @@ def _sine_pos(mask, num_pos_feats, temperature, normalize, offset, eps, scale):
     if normalize:
         y_embed = (y_embed + offset) / (y_embed[-1:, :] + eps) * scale
         x_embed = (x_embed + offset) / (x_embed[:, -1:] + eps) * scale
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=mask.device)
-    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    dim_t = dim_t_table(num_pos_feats, temperature, mask.device)
     pos_x = x_embed[:, :, None] / dim_t
     pos_y = y_embed[:, :, None] / dim_t
     H, W = mask.shape
@@ -95,14 +107,16 @@ def build_geometry(square, image_size, level_shapes, device, pos_cfg):
     prop = prop.masked_fill(g.mask.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
     g.proposals = prop.contiguous()                                  # logit-space anchors, inf where unusable
     g.invalid_u8 = (g.mask | ~valid[:, 0]).to(torch.uint8).contiguous()
+    g.box_scale = torch.tensor([w, h, w, h], dtype=torch.float32).to(device)
+    g.vr4 = torch.cat([g.valid_ratios, g.valid_ratios], -1).contiguous()
+    g.arange_T = torch.arange(g.T, device=device)
     return g
 
 
 def proposal_pos_embed(coords_unact, num_pos_feats=128, temperature=10000):
     """deformable_transformer_vl.py:412-420 for [Q,4] unactivated coords -> [Q, 512] fp32"""
     scale = 2 * math.pi
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32, device=coords_unact.device)
-    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / num_pos_feats)
+    dim_t = dim_t_table(num_pos_feats, temperature, coords_unact.device)
     p = coords_unact.sigmoid() * scale
     pos = p[:, :, None] / dim_t
     return torch.stack((pos[:, :, 0::2].sin(), pos[:, :, 1::2].cos()), dim=3).flatten(1)

@@ -1,0 +1,207 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the APE-L_D inference forward at 1024^2 (bf16, 80 COCO classes) on N x MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+`python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+A "step" = one image through the whole hot path on every rank: normalise + pad + patchify -> EVA-02 ViT-L ->
+SimpleFPN -> neck -> 6x (VL fusion + deformable encoder layer) -> two-stage proposal selection -> 6x decoder ->
+heads -> class-wise NMS -> masks of the kept detections (upsample, ROIAlign 128, paste) -> detections on the host.
+Inputs (images, text-embedding bank) are resident in HBM before the timed region.  Weights are seeded synthetic
+(no checkpoint can be downloaded here); data = synthetic COCO-shaped images.
+
+Multi-GPU: images are independent units -> rank r takes images r, r+N, ... (InferenceSampler striding,
+ape/data/build.py:127); the text bank is broadcast once from rank 0 (RCCL) and each step's fixed-size detection
+records are all-gathered (RCCL over xGMI).  scaling = weak (one image per rank per step).
+
+Extra objects on the JSON line: `roofline` for the dominant kernel (the bf16 MFMA GEMM, measured with HIP events on
+the launch stream in an instrumented pass right after the timed region) and `cpu_baseline` (the oracle -- a CPU port
+of the reference algorithm -- timed on the host cores of the same box, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", default="L_D")
+    ap.add_argument("--classes", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--stream-images", type=int, default=8, help="distinct synthetic images cycled per rank")
+    return ap.parse_args()
+
+
+def make_images(n, S, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randint(0, 256, (3, S, S), generator=g).float().to(device) for _ in range(n)]
+
+
+class GemmMeter:
+    """wraps ape_amd.ops.gemm with HIP event pairs (torch.cuda.Event on the launch stream = torch's current stream)"""
+
+    def __init__(self, ops):
+        self.ops, self.orig, self.records = ops, ops.gemm, []
+
+    def __enter__(self):
+        def wrapped(a, w, *args, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = self.orig(a, w, *args, **kw)
+            e.record()
+            if a.dtype == torch.bfloat16 and not kw.get("trans_out", False):
+                self.records.append((s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0]))
+            return out
+        self.ops.gemm = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
+        fl = sum(f for _, _, f in self.records)
+        return len(self.records), t, fl
+
+
+def cpu_baseline(model, size, image, text, max_threads=32):
+    """The oracle (CPU port of the reference algorithm, oracle/ape_oracle.py) on the host cores, on a BOUNDED sample of
+    the same workload: the full-resolution image runs through a depth-reduced copy of the model (3 of the ViT blocks
+    = 2 windowed + 1 global, 1 of the encoder layers, 1 of the decoder layers, everything else in full) and the
+    per-layer times are scaled back to the real depth.  A full 24+6+6-layer CPU forward takes minutes."""
+    from oracle import ape_oracle
+    from oracle.configs import CONFIGS
+
+    cfg = dict(CONFIGS[size])
+    depth, enc, dec = cfg["depth"], cfg["enc_layers"], cfg["dec_layers"]
+    cfg.update(depth=3, enc_layers=1, dec_layers=1)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    # the reduced oracle reads decoder level 0 heads and the encoder-side heads stored at index `dec`
+    for k in list(sd):
+        for sub in ("class_embed.", "bbox_embed."):
+            if f"{sub}{dec}." in k:
+                sd[k.replace(f"{sub}{dec}.", f"{sub}1.")] = sd[k]
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    orc = ape_oracle.ApeOracle(cfg, sd)
+    t0 = time.perf_counter()
+    orc.forward(image.cpu(), text.cpu())
+    total = time.perf_counter() - t0
+    T = orc.timers
+    n_win = len([i for i in range(depth) if i % 3 != 2])
+    layered = T["vit_win_block"] + T["vit_glb_block"] + T["enc_layer"] + T["dec_layer"]
+    est = (total - layered) + T["vit_win_block"] / 2 * n_win + T["vit_glb_block"] * (depth - n_win) + T["enc_layer"] * enc + T["dec_layer"] * dec
+    return {"value": 1.0 / est, "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": (f"1 image {tuple(image.shape)}, oracle fp32 with 3/{depth} ViT blocks, 1/{enc} encoder and 1/{dec} decoder "
+                       f"layers measured ({total:.1f} s) and scaled per layer to full depth -> {est:.1f} s/image; torch "
+                       f"{torch.__version__} CPU, {cores} threads")}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import ape_amd.ops as ops
+    from ape_amd.modeling.build import build_ape, init_synthetic
+    from ape_amd.runtime import GraphedForward
+
+    model = init_synthetic(build_ape(args.size), seed=0).to(dev)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.bfloat16)
+    S = mv.backbone.padding_constraints["square_size"]
+    # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast
+    text = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)).to(dev) if rank == 0 else \
+        torch.empty(args.classes, 1024, device=dev)
+    if dist is not None:
+        dist.broadcast(text, src=0)
+    # rank r owns images r, r+N, ... of the synthetic stream
+    images = make_images(args.stream_images, S, seed=100 + rank, device=dev)
+    runner = GraphedForward(mv, use_graph=not args.no_graph)
+    k = mv.test_topk_per_image
+    gathered = [torch.empty(k, 6, device=dev) for _ in range(world)] if dist is not None else None
+
+    def step(i):
+        inst, rec = runner(images[i % len(images)], text)
+        if dist is not None:
+            dist.all_gather(gathered, rec)      # fixed-size detection records [k, (x1,y1,x2,y2,score,class)]
+        return inst
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        # instrumented pass (eager, NOT part of the timed region): HIP events around every bf16 GEMM launch
+        with GemmMeter(ops) as meter:
+            for i in range(3):
+                out = mv.forward_single(images[i % len(images)], text)
+                mv.postprocess_instance(out, (S, S), S, S)
+            n_launch, t_gemm, flops = meter.summary()
+        achieved = flops / t_gemm / 1e12
+        result = {
+            "metric": "images/sec @1024^2 APE-L_D fwd", "value": world * args.steps / elapsed, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"APE-{args.size} forward, 1x{S}x{S} image per rank per step, {args.classes} classes "
+                                   "(name prompt), masks on, top-100 detections; seeded synthetic weights",
+                       "parallelism": f"dp{world}", "graph": not args.no_graph},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<false>", "achieved": achieved,
+                         "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": None, "launches_per_image": n_launch // 3,
+                         "avg_launch_us": 1e6 * t_gemm / max(n_launch, 1), "gemm_ms_per_image": 1e3 * t_gemm / 3,
+                         "flops_per_image": flops / 3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(model, args.size, images[0], text)
+            except Exception as exc:  # the baseline must never take the GPU number down with it
+                result["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                                          "sample": f"failed: {type(exc).__name__}: {exc}"}
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == "__main__":
+    main()

@@ -103,6 +103,11 @@ class ApeOracle:
         self.rope_win = rope_tables(self.ws)
         self.rope_glb = rope_tables(hw)
         self.stages = {}
+        self.timers = {}
+
+    def _tick(self, key, t0):
+        import time
+        self.timers[key] = self.timers.get(key, 0.0) + (time.perf_counter() - t0)
 
     def p(self, name):
         return self.sd[self.prefix + name]
@@ -186,8 +191,11 @@ class ApeOracle:
         x = x.permute(0, 2, 3, 1)
         x = x + self.abs_pos((x.shape[1], x.shape[2]))
         self.stages["vit_embed"] = x
+        import time
         for i in range(self.depth):
+            t0 = time.perf_counter()
             x = self.vit_block(x, i)
+            self._tick("vit_win_block" if i in self.win_blocks else "vit_glb_block", t0)
             self.stages[f"vit_block{i}"] = x
         return x.permute(0, 3, 1, 2)
 
@@ -387,8 +395,10 @@ class ApeOracle:
         S["enc_input"], S["lvl_pos"], S["valid_ratios"] = feat, lvl_pos, valid_ratios
 
         # encoder (:84-115): VL fusion, then BaseTransformerLayer("self_attn","norm","ffn","norm")
+        import time
         x, l = feat, query_l
         for i in range(self.enc_layers):
+            t0 = time.perf_counter()
             x, l = self.vl_fusion(x, l, i)
             S[f"enc{i}_fused_v"], S[f"enc{i}_fused_l"] = x, l
             pre = f"transformer.encoder.layers.{i}."
@@ -396,6 +406,7 @@ class ApeOracle:
             x = self.ln(x, pre + "norms.0")
             x = self.ffn(x, pre + "ffns.0.")
             x = self.ln(x, pre + "norms.1")
+            self._tick("enc_layer", t0)
             S[f"enc{i}_out"] = x
         memory = x
         S["memory"], S["query_l"] = memory, l
@@ -437,6 +448,7 @@ class ApeOracle:
         inter, inter_ref = [], []
         out = query
         for i in range(self.dec_layers):
+            t0 = time.perf_counter()
             ref_in = reference[:, :, None] * torch.cat([valid_ratios, valid_ratios], -1)[:, None]
             pre = f"transformer.decoder.layers.{i}."
             # self attention: nn.MultiheadAttention(256, 8), q = k = x + pos, v = x (detrex MultiheadAttention)
@@ -463,6 +475,7 @@ class ApeOracle:
             reference = (tmp + tp.inverse_sigmoid(reference)).sigmoid()
             inter.append(out)
             inter_ref.append(reference)
+            self._tick("dec_layer", t0)
         return (torch.stack(inter), init_reference, torch.stack(inter_ref), enc_class, enc_coord, props.sigmoid(), memory, l,
                 spatial_shapes)
 
