@@ -10,6 +10,8 @@
 //   (conflict-free ds_read_b128 fragments), XCD-aware tile order.  The MFMA operands are swapped
 //   (D = W.A^T) so each lane owns 4 consecutive output columns -> 8/16-byte epilogue stores.
 // f32 path: plain LDS-tiled FMA kernel with the same epilogue (exact-math validation mode).
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -31,9 +33,9 @@ __device__ __forceinline__ void store_n(T* dst, const float* v, int cnt, bool ve
   }
 }
 
-// 4 consecutive output columns n0..n0+3 (n0 % 4 == 0) of row m.
-__device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float v[4]) {
-  if (m >= p.M || n0 >= p.N) return;
+// Epilogue arithmetic for 4 consecutive output columns n0..n0+3 (n0 % 4 == 0) of row m (m < M, n0 < N).
+// On return v[0..cnt) are the final values for output columns ocol..ocol+cnt (SwiGLU halves the column index).
+__device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0, float v[4], int& ocol, int& cnt) {
   const bool masked = p.rowmask != nullptr && p.rowmask[m] != 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -57,25 +59,15 @@ __device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float
   }
   if (p.act == APE_ACT_SWIGLU) {
     // interleaved (gate, up) pairs -> N/2 output columns
-    float o[2];
-    o[0] = (v[0] / (1.f + __expf(-v[0]))) * v[1];
-    o[1] = (v[2] / (1.f + __expf(-v[2]))) * v[3];
-    const int c0 = n0 >> 1;
-    const int nout = p.N >> 1;
-    const int cnt = (c0 + 1 < nout) ? 2 : 1;
-    const size_t off = (size_t)m * p.ldc + c0;
-    if (p.out_dt == APE_DT_F32) {
-      float* dst = reinterpret_cast<float*>(p.C) + off;
-      for (int r = 0; r < cnt; ++r) dst[r] = o[r];
-    } else {
-      bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + off;
-      if (cnt == 2 && p.vec_ok) *reinterpret_cast<uint32_t*>(dst) = pack2bf(o[0], o[1]);
-      else for (int r = 0; r < cnt; ++r) dst[r] = f2bf(o[r]);
-    }
+    const float o0 = (v[0] / (1.f + __expf(-v[0]))) * v[1];
+    const float o1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
+    v[0] = o0; v[1] = o1;
+    ocol = n0 >> 1;
+    cnt = (ocol + 1 < (p.N >> 1)) ? 2 : 1;
     return;
   }
-  const int cnt = (p.N - n0) < 4 ? (p.N - n0) : 4;
-  const bool vec = p.vec_ok != 0;
+  ocol = n0;
+  cnt = (p.N - n0) < 4 ? (p.N - n0) : 4;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float x = act_fn(v[r], p.act);
@@ -84,6 +76,7 @@ __device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float
   }
   if (p.residual != nullptr) {
     const size_t roff = (size_t)m * p.ldr + n0;
+    const bool vec = p.vec_ok != 0;
     float rv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.res_dt == APE_DT_F32) {
       const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
@@ -99,17 +92,30 @@ __device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = 0.f;
   }
-  const size_t off = (size_t)m * p.ldc + n0;
+}
+
+// direct (register -> global) epilogue: 4 consecutive output columns of row m
+__device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float v[4]) {
+  if (m >= p.M || n0 >= p.N) return;
+  int ocol, cnt;
+  epi_n4_values(p, m, n0, v, ocol, cnt);
+  const bool vec = p.vec_ok != 0 && cnt == 4;
+  const size_t off = (size_t)m * p.ldc + ocol;
   if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, vec);
+  else if (cnt == 2 && p.vec_ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = pack2bf(v[0], v[1]);
   else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, vec);
+}
+
+__device__ __forceinline__ void epi_m4_values(const GemmParams& p, int n, float v[4]) {
+  const float b = p.bias != nullptr ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r] * p.alpha + b, p.act);
 }
 
 // transposed output C^T[n][m0..m0+3]  (bias by n, activation, no residual/rope/mask)
 __device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float v[4]) {
   if (n >= p.N || m0 >= p.M) return;
-  const float b = p.bias != nullptr ? p.bias[n] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r] * p.alpha + b, p.act);
+  epi_m4_values(p, n, v);
   const int cnt = (p.M - m0) < 4 ? (p.M - m0) : 4;
   const size_t off = (size_t)n * p.ldc + m0;
   if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, p.vec_ok != 0);
@@ -243,6 +249,197 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel v2.  Same 128x128x64 tiling / swizzled LDS image as above, but
+//  * GLDS: the operand tiles go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write
+//    pass: the ds_write path, ~80 B/clk/CU, was the LDS bottleneck of the register-staged loop).  The XOR
+//    swizzle is applied to the per-lane SOURCE address; the LDS destination stays lane-linear.
+//  * the epilogue goes through LDS so that every global store is a 16-byte chunk of a full output row
+//    (the MFMA accumulator layout only yields 8-byte pieces 32 B apart, which made the K=256 GEMMs of the
+//    deformable encoder store-bound).
+// ------------------------------------------------------------------------------------------
+#define GEMM_V2_LDS (GB_M * (GB_N * 4 + 16))  /* 67584 B: fp32 epilogue tile; >= the 64 KiB operand buffers */
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+template <bool TRANS, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // GEMM_V2_LDS bytes
+  bf16_t (*smem)[2][GB_M * GB_K] = reinterpret_cast<bf16_t (*)[2][GB_M * GB_K]>(smem_raw);  // [buf][A|W] 64 KiB
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + GB_N - 1) / GB_N;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * GB_M, n0 = tn * GB_N;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+
+  // ---- staging addresses
+  // GLDS: wave w fills row groups rg = 4w..4w+3 (8 rows x 128 B = 1 KiB per instruction); lane -> (row rg*8 + lane/8,
+  //       LDS chunk lane%8) and fetches global chunk (lane%8) ^ f(row) so that reads use the usual swz128().
+  // !GLDS: register staging exactly as in v1 (supports a K tail).
+  const bf16_t* ga[4];
+  const bf16_t* gw[4];
+  int soff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int row, c;
+    if (GLDS) {
+      row = (wave * 4 + i) * 8 + (lane >> 3);
+      c = (lane & 7) ^ ((row >> 1) & 7);
+      soff[i] = (wave * 4 + i) * 512;  // wave-uniform LDS base (elements) of this row group
+    } else {
+      const int cid = tid + 256 * i;
+      row = cid >> 3; c = cid & 7;
+      soff[i] = swz128(row, c);
+    }
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    ga[i] = A + (size_t)gm * p.lda + c * 8;
+    gw[i] = W + (size_t)gn * p.ldw + c * 8;
+  }
+  uint4 ra[4], rw[4];
+  const int kchunk = (tid & 7) * 8;
+  auto stage_issue = [&](int kt, int buf) {
+    if (GLDS) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga[i] + kt * GB_K), (lds_void_t*)(&smem[buf][0][soff[i]]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw[i] + kt * GB_K), (lds_void_t*)(&smem[buf][1][soff[i]]), 16, 0, 0);
+      }
+    } else {
+      const bool kin = kt * GB_K + kchunk < p.K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ra[i] = kin ? *reinterpret_cast<const uint4*>(ga[i] + kt * GB_K) : make_uint4(0u, 0u, 0u, 0u);
+        rw[i] = kin ? *reinterpret_cast<const uint4*>(gw[i] + kt * GB_K) : make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  };
+  auto stage_commit = [&](int buf) {
+    if (GLDS) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<uint4*>(&smem[buf][0][soff[i]]) = ra[i];
+        *reinterpret_cast<uint4*>(&smem[buf][1][soff[i]]) = rw[i];
+      }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&smem[buf][0][swz128(row, ks * 4 + fq)]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + frow;
+        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&smem[buf][1][swz128(row, ks * 4 + fq)]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  const int nk = (p.K + GB_K - 1) / GB_K;
+  stage_issue(0, 0);
+  stage_commit(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage_issue(kt + 1, buf ^ 1);
+    compute(buf);
+    if (kt + 1 < nk) stage_commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue through LDS (reusing the operand buffers + the dynamic tail): tile [128 rows][tcols], pitch + 16 B
+  const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+  const bool swiglu = p.act == APE_ACT_SWIGLU;
+  const int tcols = swiglu ? GB_N / 2 : GB_N;                 // output columns held by the tile
+  const int pitch = tcols * esz + 16;                         // bytes
+  unsigned char* tile = reinterpret_cast<unsigned char*>(smem_raw);
+  const int out_rows = TRANS ? p.N : p.M, out_cols = TRANS ? p.M : (swiglu ? (p.N >> 1) : p.N);
+  const int orow0 = TRANS ? n0 : m0;
+  const int ocol0 = TRANS ? m0 : (swiglu ? (n0 >> 1) : n0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      int lrow, lcol, cnt;
+      if (TRANS) {
+        const int n = n0 + wn * 64 + j * 16 + frow, mm = m0 + wm * 64 + i * 16 + fq * 4;
+        if (n >= p.N || mm >= p.M) continue;
+        epi_m4_values(p, n, v);
+        lrow = wn * 64 + j * 16 + frow; lcol = wm * 64 + i * 16 + fq * 4; cnt = 4;
+      } else {
+        const int m = m0 + wm * 64 + i * 16 + frow, nn = n0 + wn * 64 + j * 16 + fq * 4;
+        if (m >= p.M || nn >= p.N) continue;
+        int ocol;
+        epi_n4_values(p, m, nn, v, ocol, cnt);
+        lrow = wm * 64 + i * 16 + frow; lcol = ocol - ocol0; cnt = swiglu ? 2 : 4;
+      }
+      unsigned char* dst = tile + lrow * pitch + lcol * esz;
+      if (esz == 4) {
+        if (cnt == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+      } else {
+        if (cnt == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+      }
+    }
+  __syncthreads();
+  // coalesced copy-out: 128 rows x (tcols*esz/16) 16-byte chunks; consecutive lanes -> consecutive chunks of a row
+  const int cpr = tcols * esz / 16;
+  const int per = 16 / esz;  // elements per chunk
+  for (int cid = tid; cid < GB_M * cpr; cid += 256) {
+    const int lrow = cid / cpr, cc = cid % cpr;
+    const int grow = orow0 + lrow;
+    const int gcol = ocol0 + cc * per;
+    if (grow >= out_rows || gcol >= out_cols) continue;
+    const unsigned char* src = tile + lrow * pitch + cc * 16;
+    unsigned char* gdst = reinterpret_cast<unsigned char*>(p.C) + ((size_t)grow * p.ldc + gcol) * esz;
+    if (gcol + per <= out_cols) {
+      *reinterpret_cast<uint4*>(gdst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      const int rem = out_cols - gcol;
+      if (esz == 4) for (int e = 0; e < rem; ++e) reinterpret_cast<float*>(gdst)[e] = reinterpret_cast<const float*>(src)[e];
+      else for (int e = 0; e < rem; ++e) reinterpret_cast<bf16_t*>(gdst)[e] = reinterpret_cast<const bf16_t*>(src)[e];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // f32 kernel (validation mode): 64x64x16 tile, 256 threads, 4x4 outputs / thread
 // ------------------------------------------------------------------------------------------
@@ -343,7 +540,30 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
     APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
     APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
     const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);
-    if (p.trans_out) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
+    static const int force_v1 = getenv("APE_GEMM_V1") ? atoi(getenv("APE_GEMM_V1")) : 0;
+    static const int no_glds = getenv("APE_GEMM_NOGLDS") ? atoi(getenv("APE_GEMM_NOGLDS")) : 0;
+    const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+    // v2's LDS-staged epilogue writes 16-byte chunks of output rows
+    const bool v2_ok = !force_v1 && ((size_t)p.ldc * esz) % 16 == 0 && ((uintptr_t)p.C) % 16 == 0 &&
+                       (p.act != APE_ACT_SWIGLU || p.N % 4 == 0);
+    const bool glds = v2_ok && !no_glds && p.K % GB_K == 0;
+    if (v2_ok) {
+      static bool attr_done = false;
+      if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        attr_done = true;
+      }
+      if (p.trans_out) {
+        if (glds) hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, false>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+      } else {
+        if (glds) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+      }
+    } else if (p.trans_out) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(nblk), dim3(256), 0, s, p);
   } else {
     const int nblk = ceil_div(p.M, 64) * ceil_div(p.N, 64);

@@ -99,8 +99,8 @@ class Block(nn.Module):
                 bqk=torch.cat([a.q_bias.detach().float(), torch.zeros_like(a.q_bias, dtype=torch.float32)]).contiguous(),
                 wv=pack_matrix(a.v_proj.weight, dt), bv=f32(a.v_bias),
                 wproj=pack_matrix(a.proj.weight, dt), bproj=f32(a.proj.bias),
-                w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=round_up(max(hid, n12 // 2), 8),
-                w3=pack_matrix(m.w3.weight, dt), b3=f32(m.w3.bias),
+                w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=round_up(max(hid, n12 // 2), 64),
+                w3=pack_matrix(m.w3.weight, dt, kpad=64), b3=f32(m.w3.bias),
                 n1=(f32(self.norm1.weight), f32(self.norm1.bias), self.norm1.eps),
                 n2=(f32(self.norm2.weight), f32(self.norm2.bias), self.norm2.eps),
                 nin=(f32(a.inner_attn_ln.weight), f32(a.inner_attn_ln.bias), a.inner_attn_ln.eps),
