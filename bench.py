@@ -134,21 +134,18 @@ def main():
     mv = model.model_vision
     mv.set_compute_dtype(torch.bfloat16)
     S = mv.backbone.padding_constraints["square_size"]
-    # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast
-    text = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)).to(dev) if rank == 0 else \
-        torch.empty(args.classes, 1024, device=dev)
-    if dist is not None:
-        dist.broadcast(text, src=0)
+    from ape_amd.dp import DataParallelRunner
+
+    graphed = GraphedForward(mv, use_graph=not args.no_graph)
+    dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev)
+    # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
+    bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
+    text = dp.broadcast_text_bank(bank, args.classes, 1024)
     # rank r owns images r, r+N, ... of the synthetic stream
     images = make_images(args.stream_images, S, seed=100 + rank, device=dev)
-    runner = GraphedForward(mv, use_graph=not args.no_graph)
-    k = mv.test_topk_per_image
-    gathered = [torch.empty(k, 6, device=dev) for _ in range(world)] if dist is not None else None
 
     def step(i):
-        inst, rec = runner(images[i % len(images)], text)
-        if dist is not None:
-            dist.all_gather(gathered, rec)      # fixed-size detection records [k, (x1,y1,x2,y2,score,class)]
+        inst, _ = dp.step(images[i % len(images)], text)   # all-gathers the fixed-size detection records [k, 6]
         return inst
 
     for i in range(args.warmup):

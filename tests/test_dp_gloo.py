@@ -1,0 +1,74 @@
+"""world_size-2 gloo test (CPU) of the data-parallel runner: strided image shards, text-bank broadcast from rank 0,
+all-gather of fixed-size detection records.  The model runs on the torch definitions of the ops (fake backend)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    import ape_amd.ops as ops
+    import ref_ops
+    for n in dir(ref_ops):
+        if not n.startswith("_") and callable(getattr(ref_ops, n)) and hasattr(ops, n):
+            setattr(ops, n, getattr(ref_ops, n))
+    from ape_amd.dp import DataParallelRunner, shard_indices
+    from ape_amd.modeling.build import build_ape, init_synthetic
+
+    model = init_synthetic(build_ape("tiny"), seed=0)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.float32)
+
+    def fwd(image, text):
+        out = mv.forward_single(image, text, with_masks=False)
+        rec = torch.cat([out["det_boxes"], out["det_scores"][:, None], out["det_classes"][:, None].float()], 1)
+        return None, rec
+
+    runner = DataParallelRunner(fwd, mv.test_topk_per_image, torch.device("cpu"))
+    bank = torch.randn(6, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
+    text = runner.broadcast_text_bank(bank, 6, 1024)
+    images = [torch.randint(0, 256, (3, 256, 256), generator=torch.Generator().manual_seed(10 + i)).float() for i in range(4)]
+    mine = shard_indices(len(images), rank, world)
+    gathered = []
+    for i in mine:
+        _, allrec = runner.step(images[i], text)
+        gathered.append(allrec)
+    if rank == 0:
+        # single-process ground truth for every image
+        want = [fwd(img, text)[1] for img in images]
+        ok = True
+        for step, allrec in enumerate(gathered):
+            for r in range(world):
+                ok &= torch.allclose(allrec[r], want[step * world + r], atol=1e-5)
+        ret["ok"] = bool(ok)
+        ret["text_sum"] = float(text.sum())
+    else:
+        ret[f"text_sum_{rank}"] = float(text.sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_two_ranks_gloo():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret["ok"]
+    assert abs(ret["text_sum"] - ret["text_sum_1"]) < 1e-6   # the broadcast reached rank 1
+
+
+def test_shard_indices():
+    from ape_amd.dp import shard_indices
+    assert shard_indices(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((shard_indices(1000, r, 8) for r in range(8)), [])) == list(range(1000))
