@@ -10,3 +10,14 @@ void ape_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" int ape_hip_abi_version(void) { return 1; }
+
+// layout self-check for FFI bindings: sizeof the argument structs (0 = ApeGemmArgs, 1 = ApeLayerNormArgs, 2 = ApeGroupNormArgs)
+#include "../../include/ape_hip.h"
+extern "C" int ape_hip_sizeof_args(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(ApeGemmArgs);
+    case 1: return (int)sizeof(ApeLayerNormArgs);
+    case 2: return (int)sizeof(ApeGroupNormArgs);
+    default: return -1;
+  }
+}

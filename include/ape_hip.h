@@ -35,6 +35,7 @@ extern "C" {
 
 const char* ape_hip_last_error(void);
 int ape_hip_abi_version(void);
+int ape_hip_sizeof_args(int which); /* sizeof(ApeGemmArgs / ApeLayerNormArgs / ApeGroupNormArgs) for which = 0 / 1 / 2 */
 
 /* ---------------------------------------------------------------------------------------------
  * GEMM:  C[M,N] = epi(alpha * A[M,K] . W[N,K]^T)     (nn.Linear weight layout, K contiguous)
