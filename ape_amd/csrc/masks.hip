@@ -9,29 +9,50 @@
 #include "common.h"
 #include "../../include/ape_hip.h"
 
+// one thread = 16 consecutive output pixels of one row (one 16-byte store)
 template <typename T>
 __global__ __launch_bounds__(256) void mask_upsample_bits_kernel(const T* __restrict__ logits, int ldl, int h0, int w0, int S,
                                                                  int n, uint8_t* __restrict__ out) {
+  const int xg = (S + 15) / 16;
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)n * S * S) return;
-  const int x = (int)(gid % S), y = (int)((gid / S) % S), q = (int)(gid / ((size_t)S * S));
+  if (gid >= (size_t)n * S * xg) return;
+  const int xb = (int)(gid % xg) * 16, y = (int)((gid / xg) % S), q = (int)(gid / ((size_t)xg * S));
   const float sy = (float)h0 / (float)S, sx = (float)w0 / (float)S;
   float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
-  float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-  const int y0 = (int)fy, x0 = (int)fx;
-  const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0), x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
-  const float ly = fy - (float)y0, lx = fx - (float)x0;
-  const T* p = logits + (size_t)q * ldl;
-  const float v00 = ldf<T>(p + y0 * w0 + x0), v01 = ldf<T>(p + y0 * w0 + x1);
-  const float v10 = ldf<T>(p + y1 * w0 + x0), v11 = ldf<T>(p + y1 * w0 + x1);
-  const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
-  out[gid] = v > 0.f ? 1 : 0;
+  const int y0 = (int)fy;
+  const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0);
+  const float ly = fy - (float)y0;
+  const T* p0 = logits + (size_t)q * ldl + (size_t)y0 * w0;
+  const T* p1 = logits + (size_t)q * ldl + (size_t)y1 * w0;
+  uint8_t b[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int x = xb + i;
+    float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+    int x0 = (int)fx; x0 = x0 < w0 - 1 ? x0 : w0 - 1;
+    const int x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+    const float lx = fx - (float)x0;
+    const float v = (1.f - ly) * ((1.f - lx) * ldf<T>(p0 + x0) + lx * ldf<T>(p0 + x1)) +
+                    ly * ((1.f - lx) * ldf<T>(p1 + x0) + lx * ldf<T>(p1 + x1));
+    b[i] = v > 0.f ? 1 : 0;
+  }
+  uint8_t* dst = out + ((size_t)q * S + y) * S + xb;
+  if (xb + 16 <= S && (S % 16) == 0) {
+    uint4 pk;
+    pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+    pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+    pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+    pk.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
+    *reinterpret_cast<uint4*>(dst) = pk;
+  } else {
+    for (int i = 0; i < 16 && xb + i < S; ++i) dst[i] = b[i];
+  }
 }
 
 extern "C" int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, int h0, int w0, int S, int n, uint8_t* out,
                                           void* stream) {
   APE_CHECK_ARG(logits && out && h0 > 0 && w0 > 0 && S > 0 && n > 0, "ape_hip_mask_upsample_bits: bad args");
-  const size_t total = (size_t)n * S * S;
+  const size_t total = (size_t)n * S * ((S + 15) / 16);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   if (dt == APE_DT_BF16) hipLaunchKernelGGL(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
   else hipLaunchKernelGGL(mask_upsample_bits_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, ldl, h0, w0, S, n, out);
@@ -81,29 +102,51 @@ extern "C" int ape_hip_roi_align_bits(const uint8_t* bits, int H, int W, const f
   return 0;
 }
 
+// one thread = 16 consecutive output pixels of one row
 __global__ __launch_bounds__(256) void paste_bits_kernel(const uint8_t* __restrict__ m, int P, const float* __restrict__ boxes, int n,
                                                          int Ho, int Wo, uint8_t* __restrict__ out) {
+  const int xg = (Wo + 15) / 16;
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (size_t)n * Ho * Wo) return;
-  const int x = (int)(gid % Wo), y = (int)((gid / Wo) % Ho), q = (int)(gid / ((size_t)Wo * Ho));
+  if (gid >= (size_t)n * Ho * xg) return;
+  const int xb = (int)(gid % xg) * 16, y = (int)((gid / xg) % Ho), q = (int)(gid / ((size_t)xg * Ho));
   const float x0 = boxes[q * 4 + 0], y0 = boxes[q * 4 + 1], x1 = boxes[q * 4 + 2], y1 = boxes[q * 4 + 3];
   const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
-  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
   // grid_sample, align_corners=False: ix = ((g + 1) * size - 1) / 2 ; zeros padding
-  const float fx = ((gx + 1.f) * (float)P - 1.f) * 0.5f, fy = ((gy + 1.f) * (float)P - 1.f) * 0.5f;
-  const float flx = floorf(fx), fly = floorf(fy);
-  const int ix0 = (int)flx, iy0 = (int)fly, ix1 = ix0 + 1, iy1 = iy0 + 1;
-  const float lx = fx - flx, ly = fy - fly;
+  const float fy = ((gy + 1.f) * (float)P - 1.f) * 0.5f;
+  const float fly = floorf(fy);
+  const int iy0 = (int)fly, iy1 = iy0 + 1;
+  const float ly = fy - fly;
   const uint8_t* img = m + (size_t)q * P * P;
   auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < P && xx >= 0 && xx < P) ? (float)img[yy * P + xx] : 0.f; };
-  const float v = at(iy0, ix0) * (1.f - lx) * (1.f - ly) + at(iy0, ix1) * lx * (1.f - ly) + at(iy1, ix0) * (1.f - lx) * ly +
-                  at(iy1, ix1) * lx * ly;
-  out[gid] = v >= 0.5f ? 1 : 0;
+  uint8_t* dst = out + ((size_t)q * Ho + y) * Wo + xb;
+  uint8_t b[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int x = xb + i;
+    const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+    const float fx = ((gx + 1.f) * (float)P - 1.f) * 0.5f;
+    const float flx = floorf(fx);
+    const int ix0 = (int)flx, ix1 = ix0 + 1;
+    const float lx = fx - flx;
+    const float v = at(iy0, ix0) * (1.f - lx) * (1.f - ly) + at(iy0, ix1) * lx * (1.f - ly) + at(iy1, ix0) * (1.f - lx) * ly +
+                    at(iy1, ix1) * lx * ly;
+    b[i] = v >= 0.5f ? 1 : 0;
+  }
+  if (xb + 16 <= Wo && (Wo % 16) == 0) {
+    uint4 pk;
+    pk.x = b[0] | (b[1] << 8) | (b[2] << 16) | ((uint32_t)b[3] << 24);
+    pk.y = b[4] | (b[5] << 8) | (b[6] << 16) | ((uint32_t)b[7] << 24);
+    pk.z = b[8] | (b[9] << 8) | (b[10] << 16) | ((uint32_t)b[11] << 24);
+    pk.w = b[12] | (b[13] << 8) | (b[14] << 16) | ((uint32_t)b[15] << 24);
+    *reinterpret_cast<uint4*>(dst) = pk;
+  } else {
+    for (int i = 0; i < 16 && xb + i < Wo; ++i) dst[i] = b[i];
+  }
 }
 
 extern "C" int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxes, int n, int Ho, int Wo, uint8_t* out, void* stream) {
   APE_CHECK_ARG(masks && boxes && out && n > 0 && P > 0 && Ho > 0 && Wo > 0, "ape_hip_paste_bits: bad args");
-  const size_t total = (size_t)n * Ho * Wo;
+  const size_t total = (size_t)n * Ho * ((Wo + 15) / 16);
   hipLaunchKernelGGL(paste_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks, P, boxes, n, Ho, Wo, out);
   APE_CHECK_LAUNCH("ape_hip_paste_bits");
   return 0;

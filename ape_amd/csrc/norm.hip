@@ -16,7 +16,8 @@ __device__ __forceinline__ float ln_act(float x, int act) {
   return x;
 }
 
-// One wave per row.  NV4 > 0: row cached in registers (C <= NV4*256, C % 4 == 0); NV4 == 0: generic 3-pass.
+// One wave per row, the row cached in registers: lane owns float4 groups (i*64 + lane), i < NV4 (C <= NV4*256).
+// Any C is accepted (ragged last group handled element-wise); rows must be 16-byte aligned (ld % 4 == 0).
 template <typename TX, typename TY, typename TA, int NV4>
 __global__ __launch_bounds__(256) void layernorm_kernel(const ApeLayerNormArgs p) {
   const int lane = threadIdx.x & 63;
@@ -28,62 +29,78 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const ApeLayerNormArgs p
   TY* y2 = p.y2 ? reinterpret_cast<TY*>(p.y2) + (size_t)row * p.ldy2 : nullptr;
   const int C = p.C;
   const float invC = 1.f / (float)C;
-
-  if (NV4 > 0) {
-    float v[NV4 > 0 ? NV4 : 1][4];
-    float s = 0.f;
+  float v[NV4][4];
+  float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < C) {
-        ld4<TX>(x + c, v[i]);
-        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c + 3 < C) {
+      ld4<TX>(x + c, v[i]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[i][r] = (c + r < C) ? ldf<TX>(x + c + r) : 0.f;
+    }
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * invC;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = (c + r < C) ? v[i][r] - mean : 0.f;
+      q = fmaf(d, d, q);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= p.Cpad) continue;
+    float o[4], o2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (c + r < C) {
+        o[r] = ln_act((v[i][r] - mean) * rstd * p.w[c + r] + p.b[c + r], p.act);
+        o2[r] = (y2 != nullptr) ? o[r] + ldf<TA>(add + c + r) : 0.f;
       } else {
-        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        o[r] = 0.f; o2[r] = 0.f;   // K padding columns C..Cpad-1
       }
     }
-    const float mean = wave_sum(s) * invC;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < C) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q = fmaf(d, d, q); }
-      }
+    if (c + 3 < p.Cpad) {
+      st4<TY>(y + c, o);
+      if (y2 != nullptr) st4<TY>(y2 + c, o2);
+    } else {
+      for (int r = 0; r < 4 && c + r < p.Cpad; ++r) { stf<TY>(y + c + r, o[r]); if (y2 != nullptr) stf<TY>(y2 + c + r, o2[r]); }
     }
-    const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
-#pragma unroll
-    for (int i = 0; i < NV4; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      if (c < C) {
-        float w4[4], b4[4], o[4];
-        ld4<float>(p.w + c, w4);
-        ld4<float>(p.b + c, b4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = ln_act((v[i][r] - mean) * rstd * w4[r] + b4[r], p.act);
-        st4<TY>(y + c, o);
-        if (y2 != nullptr) {
-          float a4[4];
-          ld4<TA>(add + c, a4);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) a4[r] += o[r];
-          st4<TY>(y2 + c, a4);
-        }
-      }
-    }
-  } else {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += ldf<TX>(x + c);
-    const float mean = wave_sum(s) * invC;
-    float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = ldf<TX>(x + c) - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
-    for (int c = lane; c < C; c += 64) {
-      const float o = ln_act((ldf<TX>(x + c) - mean) * rstd * p.w[c] + p.b[c], p.act);
-      stf<TY>(y + c, o);
-      if (y2 != nullptr) stf<TY>(y2 + c, o + ldf<TA>(add + c));
-    }
+  }
+  // Cpad beyond the register window (never the case for NV4*256 >= Cpad)
+  for (int c = NV4 * 256 + lane; c < p.Cpad; c += 64) { stf<TY>(y + c, 0.f); if (y2 != nullptr) stf<TY>(y2 + c, 0.f); }
+}
+
+// generic fallback: three passes over the row (unaligned rows or C > 3072)
+template <typename TX, typename TY, typename TA>
+__global__ __launch_bounds__(256) void layernorm_generic_kernel(const ApeLayerNormArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const TX* x = reinterpret_cast<const TX*>(p.x) + (size_t)row * p.ldx;
+  TY* y = reinterpret_cast<TY*>(p.y) + (size_t)row * p.ldy;
+  const TA* add = p.add ? reinterpret_cast<const TA*>(p.add) + (size_t)row * p.ldadd : nullptr;
+  TY* y2 = p.y2 ? reinterpret_cast<TY*>(p.y2) + (size_t)row * p.ldy2 : nullptr;
+  const int C = p.C;
+  const float invC = 1.f / (float)C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += ldf<TX>(x + c);
+  const float mean = wave_sum(s) * invC;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = ldf<TX>(x + c) - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+  for (int c = lane; c < C; c += 64) {
+    const float o = ln_act((ldf<TX>(x + c) - mean) * rstd * p.w[c] + p.b[c], p.act);
+    stf<TY>(y + c, o);
+    if (y2 != nullptr) stf<TY>(y2 + c, o + ldf<TA>(add + c));
   }
   for (int c = C + lane; c < p.Cpad; c += 64) {
     stf<TY>(y + c, 0.f);
@@ -94,14 +111,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const ApeLayerNormArgs p
 template <typename TX, typename TY, typename TA>
 static int launch_ln(const ApeLayerNormArgs& p, hipStream_t s) {
   const dim3 grid(ceil_div(p.M, 4)), block(256);
-  const bool vec = (p.C % 4 == 0) && (p.ldx % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) &&
-                   (((uintptr_t)p.y) % 16 == 0) && (((uintptr_t)p.w) % 16 == 0) && (((uintptr_t)p.b) % 16 == 0) &&
+  const bool vec = (p.ldx % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.y) % 16 == 0) &&
                    (!p.y2 || ((p.ldadd % 4 == 0) && (p.ldy2 % 4 == 0) && (((uintptr_t)p.add) % 16 == 0) &&
                               (((uintptr_t)p.y2) % 16 == 0)));
-  if (vec && p.C <= 256) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 1>), grid, block, 0, s, p);
-  else if (vec && p.C <= 512) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 2>), grid, block, 0, s, p);
-  else if (vec && p.C <= 1024) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 4>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 0>), grid, block, 0, s, p);
+  const int need = p.Cpad > p.C ? p.Cpad : p.C;
+  if (vec && need <= 256) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 1>), grid, block, 0, s, p);
+  else if (vec && need <= 512) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 2>), grid, block, 0, s, p);
+  else if (vec && need <= 1024) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 4>), grid, block, 0, s, p);
+  else if (vec && need <= 2048) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 8>), grid, block, 0, s, p);
+  else if (vec && need <= 3072) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 12>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((layernorm_generic_kernel<TX, TY, TA>), grid, block, 0, s, p);
   return 0;
 }
 

@@ -46,7 +46,37 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
 }
 
 #define NMS_PF 16
-// segments: wave g scans candidates [seg[g], seg[g+1]) in order; valid[i]==0 candidates are skipped entirely
+// segments: wave g scans candidates [seg[g], seg[g+1]) in order; valid[i]==0 candidates are skipped entirely.
+// The bit-matrix rows of chunk c+1 are fetched while chunk c is being decided (software pipelined).
+struct NmsRows { unsigned long long r0[NMS_PF], r1[NMS_PF]; };
+
+__device__ __forceinline__ void nms_load_rows(NmsRows& R, const unsigned long long* __restrict__ mask, int nw, int base, int s1,
+                                              int w0, int nws, int lane) {
+#pragma unroll
+  for (int u = 0; u < NMS_PF; ++u) {
+    const int i = base + u;
+    R.r0[u] = (i < s1 && lane < nws) ? mask[(size_t)i * nw + w0 + lane] : 0ull;
+    R.r1[u] = (i < s1 && lane + 64 < nws) ? mask[(size_t)i * nw + w0 + lane + 64] : 0ull;
+  }
+}
+
+__device__ __forceinline__ void nms_decide_rows(const NmsRows& R, int base, int s1, int w0, int lane, const uint8_t* __restrict__ valid,
+                                                uint8_t* __restrict__ keep, unsigned long long& rem0, unsigned long long& rem1) {
+#pragma unroll
+  for (int u = 0; u < NMS_PF; ++u) {
+    const int i = base + u;
+    if (i < s1) {  // wave-uniform
+      const int word = (i >> 6) - w0, bit = i & 63;
+      const unsigned long long rv = (word >= 64) ? rem1 : rem0;
+      const unsigned long long r = __shfl(rv, word & 63, 64);
+      const bool ok = (valid == nullptr) || (valid[i] != 0);
+      const bool kept = ok && !((r >> bit) & 1ull);
+      if (kept) { rem0 |= R.r0[u]; rem1 |= R.r1[u]; }
+      if (lane == 0) keep[i] = kept ? 1 : 0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void nms_scan_segments_kernel(const unsigned long long* __restrict__ mask, int nw,
                                                                const int* __restrict__ seg, const uint8_t* __restrict__ valid,
                                                                uint8_t* __restrict__ keep) {
@@ -56,60 +86,45 @@ __global__ __launch_bounds__(64) void nms_scan_segments_kernel(const unsigned lo
   const int w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
   const int nws = w1 - w0 + 1;  // <= 128 (checked by the launcher through max segment length)
   unsigned long long rem0 = 0ull, rem1 = 0ull;
-  for (int base = s0; base < s1; base += NMS_PF) {
-    unsigned long long r0[NMS_PF], r1[NMS_PF];
-#pragma unroll
-    for (int u = 0; u < NMS_PF; ++u) {
-      const int i = base + u;
-      r0[u] = (i < s1 && lane < nws) ? mask[(size_t)i * nw + w0 + lane] : 0ull;
-      r1[u] = (i < s1 && lane + 64 < nws) ? mask[(size_t)i * nw + w0 + lane + 64] : 0ull;
-    }
-#pragma unroll
-    for (int u = 0; u < NMS_PF; ++u) {
-      const int i = base + u;
-      if (i < s1) {  // wave-uniform
-        const int word = (i >> 6) - w0, bit = i & 63;
-        const unsigned long long rv = (word >= 64) ? rem1 : rem0;
-        const unsigned long long r = __shfl(rv, word & 63, 64);
-        const bool ok = (valid == nullptr) || (valid[i] != 0);
-        const bool kept = ok && !((r >> bit) & 1ull);
-        if (kept) { rem0 |= r0[u]; rem1 |= r1[u]; }
-        if (lane == 0) keep[i] = kept ? 1 : 0;
-      }
-    }
+  NmsRows A, B;
+  nms_load_rows(A, mask, nw, s0, s1, w0, nws, lane);
+  for (int base = s0; base < s1; base += 2 * NMS_PF) {
+    nms_load_rows(B, mask, nw, base + NMS_PF, s1, w0, nws, lane);
+    nms_decide_rows(A, base, s1, w0, lane, valid, keep, rem0, rem1);
+    nms_load_rows(A, mask, nw, base + 2 * NMS_PF, s1, w0, nws, lane);
+    nms_decide_rows(B, base + NMS_PF, s1, w0, lane, valid, keep, rem0, rem1);
   }
 }
 
-// class-wise scan over shared boxes: wave c visits queries order[c][0..n) (descending score of class c);
-// valid[c][pos] (optional) marks candidates passing the score threshold.
-__global__ __launch_bounds__(64) void nms_scan_classes_kernel(const unsigned long long* __restrict__ mask, int nw, int n,
-                                                              const int* __restrict__ order, const uint8_t* __restrict__ valid,
-                                                              uint8_t* __restrict__ keep) {
-  const int lane = threadIdx.x;
-  const int c = blockIdx.x;
+// class-wise scan over shared boxes: the whole n x nw bit matrix is staged in LDS once per workgroup (900 boxes:
+// 108 KB) and each of the 4 waves scans one class; per step only LDS + cross-lane traffic.
+__global__ __launch_bounds__(256) void nms_scan_classes_kernel(const unsigned long long* __restrict__ mask, int nw, int n,
+                                                               const int* __restrict__ order, const uint8_t* __restrict__ valid,
+                                                               uint8_t* __restrict__ keep, int num_classes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long smask[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < n * nw; i += 256) smask[i] = mask[i];
+  __syncthreads();
+  const int c = blockIdx.x * 4 + wave;
+  if (c >= num_classes) return;
   const int* ord = order + (size_t)c * n;
-  unsigned long long rem = 0ull;  // lane w owns word w (n <= 4096)
-  for (int base = 0; base < n; base += NMS_PF) {
-    unsigned long long r0[NMS_PF];
-    int q[NMS_PF];
-#pragma unroll
-    for (int u = 0; u < NMS_PF; ++u) {
-      const int p = base + u;
-      q[u] = p < n ? ord[p] : 0;
-      r0[u] = (p < n && lane < nw) ? mask[(size_t)q[u] * nw + lane] : 0ull;
+  unsigned long long rem = 0ull;  // lane w owns word w (n <= 4096 -> nw <= 64)
+  for (int base = 0; base < n; base += 64) {
+    const int p = base + lane;
+    const int qv = p < n ? ord[p] : 0;
+    const int okv = (p < n) && (valid == nullptr || valid[(size_t)c * n + p] != 0);
+    int keptv = 0;
+    const int cnt = min(64, n - base);
+    for (int u = 0; u < cnt; ++u) {
+      const int qi = __shfl(qv, u, 64);
+      const int ok = __shfl(okv, u, 64);
+      const unsigned long long row = lane < nw ? smask[(size_t)qi * nw + lane] : 0ull;
+      const unsigned long long r = __shfl(rem, qi >> 6, 64);
+      const bool kept = ok && !((r >> (qi & 63)) & 1ull);
+      if (kept) rem |= row;
+      if (lane == u) keptv = kept ? 1 : 0;
     }
-#pragma unroll
-    for (int u = 0; u < NMS_PF; ++u) {
-      const int p = base + u;
-      if (p < n) {
-        const int qi = q[u];
-        const unsigned long long r = __shfl(rem, qi >> 6, 64);
-        const bool ok = (valid == nullptr) || (valid[(size_t)c * n + p] != 0);
-        const bool kept = ok && !((r >> (qi & 63)) & 1ull);
-        if (kept) rem |= r0[u];
-        if (lane == 0) keep[(size_t)c * n + p] = kept ? 1 : 0;
-      }
-    }
+    if (p < n) keep[(size_t)c * n + p] = (uint8_t)keptv;
   }
 }
 
@@ -136,9 +151,17 @@ extern "C" int ape_hip_nms_scan_segments(const uint64_t* mask, int n, const int*
 
 extern "C" int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int* order, int num_classes, const uint8_t* valid,
                                         uint8_t* keep, void* stream) {
-  APE_CHECK_ARG(mask && order && keep && n > 0 && n <= 4096 && num_classes > 0, "ape_hip_nms_scan_classes: bad args (n <= 4096)");
-  hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(num_classes), dim3(64), 0, (hipStream_t)stream,
-                     (const unsigned long long*)mask, ceil_div(n, 64), n, order, valid, keep);
+  const int nw = ceil_div(n, 64);
+  const size_t lds = (size_t)n * nw * 8;
+  APE_CHECK_ARG(mask && order && keep && n > 0 && num_classes > 0 && lds <= 160 * 1024,
+                "ape_hip_nms_scan_classes: bad args (the n x n/64 bit matrix must fit the 160 KiB LDS: n <= 1280)");
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)nms_scan_classes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(ceil_div(num_classes, 4)), dim3(256), lds, (hipStream_t)stream,
+                     (const unsigned long long*)mask, nw, n, order, valid, keep, num_classes);
   APE_CHECK_LAUNCH("ape_hip_nms_scan_classes");
   return 0;
 }

@@ -11,7 +11,7 @@
 #include "common.h"
 #include "../../include/ape_hip.h"
 
-#define VL_CHUNK 512
+#define VL_CHUNK 128
 #define VL_H 8
 
 __global__ __launch_bounds__(256) void vl_smax_partial_kernel(const float* __restrict__ S, int lds, int T, float* __restrict__ pmax) {
@@ -40,10 +40,17 @@ __global__ __launch_bounds__(256) void vl_pool_partial_kernel(const float* __res
   __shared__ float gmax_s;
   __shared__ float P[VL_CHUNK][VL_H];
   const int t = threadIdx.x;
-  if (t < VL_H) {
+  {
+    // per-head maxima over all chunks: 32 threads per head, LDS tree
     float a = -INFINITY;
-    for (int k = 0; k < nchunk; ++k) a = fmaxf(a, pmax[k * VL_H + t]);
-    hmax[t] = a;
+    for (int k = t >> 3; k < nchunk; k += 32) a = fmaxf(a, pmax[k * VL_H + (t & 7)]);
+    P[t >> 3][t & 7] = a;
+    __syncthreads();
+    if (t < VL_H) {
+      float m = -INFINITY;
+      for (int j = 0; j < 32; ++j) m = fmaxf(m, P[j][t]);
+      hmax[t] = m;
+    }
   }
   __syncthreads();
   if (t == 0) {
@@ -89,15 +96,27 @@ __global__ __launch_bounds__(256) void vl_pool_partial_kernel(const float* __res
   }
 }
 
+// grid (8 heads, C/32): 8 k-groups x 32 columns per block, LDS tree over the k-groups
 __global__ __launch_bounds__(256) void vl_pool_final_kernel(const float* __restrict__ pacc, const float* __restrict__ psum, int nchunk,
                                                             int C, float* __restrict__ out) {
-  const int h = blockIdx.x;
+  __shared__ float sa[8][32];
+  __shared__ float sl[256];
+  const int h = blockIdx.x, t = threadIdx.x;
+  const int kg = t >> 5, cl = t & 31;
+  const int c = blockIdx.y * 32 + cl;
   float l = 0.f;
-  for (int k = 0; k < nchunk; ++k) l += psum[k * VL_H + h];
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float a = 0.f;
-    for (int k = 0; k < nchunk; ++k) a += pacc[((size_t)k * VL_H + h) * C + c];
-    out[h * C + c] = a / l;
+  for (int k = t; k < nchunk; k += 256) l += psum[k * VL_H + h];
+  sl[t] = l;
+  float a = 0.f;
+  if (c < C) for (int k = kg; k < nchunk; k += 8) a += pacc[((size_t)k * VL_H + h) * C + c];
+  sa[kg][cl] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) sl[t] += sl[t + o]; __syncthreads(); }
+  if (t < 32 && c < C) {
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc += sa[g][t];
+    out[h * C + c] = acc / sl[0];
   }
 }
 
@@ -120,7 +139,7 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
     hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
   else
     hipLaunchKernelGGL(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
-  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H), dim3(256), 0, s, pacc, psum, nchunk, C, out);
+  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, out);
   APE_CHECK_LAUNCH("ape_hip_vl_pool");
   return 0;
 }

@@ -46,7 +46,13 @@ def test_fp32_host_pipeline_matches_oracle(fake_ops, case):
                               gold["full"]["det_scores"], gold["full"]["det_classes"])
     assert frac >= 0.97
     orc.forward(image, text, forced_topk=ref_topk[None])
-    assert (out["det_masks128"].bool() != orc.stages["det_masks128"]).float().mean().item() < 1e-3
+    ours = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(out["det_query"], out["det_classes"]))}
+    pairs = [(ours[(int(q), int(c))], j) for j, (q, c) in enumerate(zip(orc.stages["det_query"], orc.stages["det_classes"]))
+             if (int(q), int(c)) in ours]
+    assert len(pairs) >= 0.97 * len(orc.stages["det_query"])
+    a = out["det_masks128"].bool()[[i for i, _ in pairs]]
+    b = orc.stages["det_masks128"][[j for _, j in pairs]]
+    assert (a != b).float().mean().item() < 1e-3
 
 
 def test_forward_api_matches_oracle_instances(fake_ops):

@@ -119,7 +119,7 @@ def test_gemv(ops):
         assert e < 2e-5
 
 
-@pytest.mark.parametrize("C,cpad", [(256, 256), (512, 512), (1024, 1024), (2730, 2752), (100, 104)])
+@pytest.mark.parametrize("C,cpad", [(256, 256), (512, 512), (1024, 1024), (2730, 2752), (100, 104), (1536, 1536), (341, 384), (3500, 3504)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
 def test_layernorm(ops, C, cpad, xdt, ydt):
     M = 1037
