@@ -25,16 +25,41 @@ __global__ __launch_bounds__(256) void mask_upsample_bits_kernel(const T* __rest
   const T* p0 = logits + (size_t)q * ldl + (size_t)y0 * w0;
   const T* p1 = logits + (size_t)q * ldl + (size_t)y1 * w0;
   uint8_t b[16];
+  if (S == 4 * w0 && xb + 16 <= S) {
+    // x4 upsampling (the mask features live at stride 4): 16 outputs need source columns kb-1 .. kb+4; load the two
+    // source rows once and blend in registers.  src = 0.25*(x+0.5)-0.5 -> (x0, lx) = (k-1, .625), (k-1, .875), (k, .125), (k, .375)
+    const int kb = xb >> 2;
+    float r0[6], r1[6];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int x = xb + i;
-    float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
-    int x0 = (int)fx; x0 = x0 < w0 - 1 ? x0 : w0 - 1;
-    const int x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
-    const float lx = fx - (float)x0;
-    const float v = (1.f - ly) * ((1.f - lx) * ldf<T>(p0 + x0) + lx * ldf<T>(p0 + x1)) +
-                    ly * ((1.f - lx) * ldf<T>(p1 + x0) + lx * ldf<T>(p1 + x1));
-    b[i] = v > 0.f ? 1 : 0;
+    for (int j = 0; j < 6; ++j) {
+      int xs = kb - 1 + j; xs = xs < 0 ? 0 : (xs > w0 - 1 ? w0 - 1 : xs);
+      r0[j] = ldf<T>(p0 + xs);
+      r1[j] = ldf<T>(p1 + xs);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int x = xb + i;
+      float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+      const float lx = fx - (float)(int)fx;
+      // source column of the left tap relative to kb-1 is a compile-time function of i; the clamped preloads make the
+      // image borders come out right (left border: lx == 0; right border: both taps read column w0-1)
+      const int j0 = (i >> 2) + ((i & 3) >= 2 ? 1 : 0);
+      const float v00 = r0[j0], v01 = r0[j0 + 1], v10 = r1[j0], v11 = r1[j0 + 1];
+      const float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+      b[i] = v > 0.f ? 1 : 0;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int x = xb + i;
+      float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+      int x0 = (int)fx; x0 = x0 < w0 - 1 ? x0 : w0 - 1;
+      const int x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+      const float lx = fx - (float)x0;
+      const float v = (1.f - ly) * ((1.f - lx) * ldf<T>(p0 + x0) + lx * ldf<T>(p0 + x1)) +
+                      ly * ((1.f - lx) * ldf<T>(p1 + x0) + lx * ldf<T>(p1 + x1));
+      b[i] = v > 0.f ? 1 : 0;
+    }
   }
   uint8_t* dst = out + ((size_t)q * S + y) * S + xb;
   if (xb + 16 <= S && (S % 16) == 0) {

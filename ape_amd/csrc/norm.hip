@@ -59,6 +59,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const ApeLayerNormArgs p
     const int c = (i * 64 + lane) * 4;
     if (c >= p.Cpad) continue;
     float o[4], o2[4];
+    if (c + 3 < C) {   // fast path: whole float4 group inside the row
+      float w4[4], b4[4];
+      ld4<float>(p.w + c, w4);
+      ld4<float>(p.b + c, b4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = ln_act((v[i][r] - mean) * rstd * w4[r] + b4[r], p.act);
+      st4<TY>(y + c, o);
+      if (y2 != nullptr) {
+        ld4<TA>(add + c, o2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o2[r] += o[r];
+        st4<TY>(y2 + c, o2);
+      }
+      continue;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (c + r < C) {
@@ -112,6 +127,7 @@ template <typename TX, typename TY, typename TA>
 static int launch_ln(const ApeLayerNormArgs& p, hipStream_t s) {
   const dim3 grid(ceil_div(p.M, 4)), block(256);
   const bool vec = (p.ldx % 4 == 0) && (p.ldy % 4 == 0) && (((uintptr_t)p.x) % 16 == 0) && (((uintptr_t)p.y) % 16 == 0) &&
+                   (((uintptr_t)p.w) % 16 == 0) && (((uintptr_t)p.b) % 16 == 0) &&
                    (!p.y2 || ((p.ldadd % 4 == 0) && (p.ldy2 % 4 == 0) && (((uintptr_t)p.add) % 16 == 0) &&
                               (((uintptr_t)p.y2) % 16 == 0)));
   const int need = p.Cpad > p.C ? p.Cpad : p.C;

@@ -45,6 +45,12 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__
   mask[(size_t)i * nw + cbk] = bits;
 }
 
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int lane_uniform) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xffffffffull), lane_uniform);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane_uniform);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 #define NMS_PF 16
 // segments: wave g scans candidates [seg[g], seg[g+1]) in order; valid[i]==0 candidates are skipped entirely.
 // The bit-matrix rows of chunk c+1 are fetched while chunk c is being decided (software pipelined).
@@ -68,7 +74,7 @@ __device__ __forceinline__ void nms_decide_rows(const NmsRows& R, int base, int 
     if (i < s1) {  // wave-uniform
       const int word = (i >> 6) - w0, bit = i & 63;
       const unsigned long long rv = (word >= 64) ? rem1 : rem0;
-      const unsigned long long r = __shfl(rv, word & 63, 64);
+      const unsigned long long r = readlane64(rv, word & 63);   // `word` is wave-uniform: v_readlane, not a bpermute
       const bool ok = (valid == nullptr) || (valid[i] != 0);
       const bool kept = ok && !((r >> bit) & 1ull);
       if (kept) { rem0 |= R.r0[u]; rem1 |= R.r1[u]; }
@@ -116,10 +122,10 @@ __global__ __launch_bounds__(256) void nms_scan_classes_kernel(const unsigned lo
     int keptv = 0;
     const int cnt = min(64, n - base);
     for (int u = 0; u < cnt; ++u) {
-      const int qi = __shfl(qv, u, 64);
-      const int ok = __shfl(okv, u, 64);
+      const int qi = __builtin_amdgcn_readlane(qv, u);     // u is wave-uniform
+      const int ok = __builtin_amdgcn_readlane(okv, u);
       const unsigned long long row = lane < nw ? smask[(size_t)qi * nw + lane] : 0ull;
-      const unsigned long long r = __shfl(rem, qi >> 6, 64);
+      const unsigned long long r = readlane64(rem, qi >> 6);
       const bool kept = ok && !((r >> (qi & 63)) & 1ull);
       if (kept) rem |= row;
       if (lane == u) keptv = kept ? 1 : 0;
