@@ -27,6 +27,7 @@ class GemmArgs(Structure):
         ("act", c_int32), ("mask_mode", c_int32), ("trans_out", c_int32),
         ("rope_rows", c_int32), ("rope_hd", c_int32), ("rope_cols", c_int32), ("vec_ok", c_int32),
         ("alpha", c_float), ("clamp", c_float),
+        ("splitk", c_int32), ("tile64", c_int32), ("workspace", c_void_p),
     ]
 
 

@@ -259,9 +259,261 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 //    (the MFMA accumulator layout only yields 8-byte pieces 32 B apart, which made the K=256 GEMMs of the
 //    deformable encoder store-bound).
 // ------------------------------------------------------------------------------------------
+#define GEMM_T64_LDS (4 * 128 * 32 * 2)  /* 64x64 ring: 4 stages x (64+64) rows x 64 B = 32 KiB >= the 64 x (64*4+16) B fp32 epilogue tile */
 #define GEMM_V2_LDS (GB_M * (GB_N * 4 + 16))  /* 67584 B: fp32 epilogue tile; >= the 64 KiB operand buffers */
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// LDS-staged epilogue shared by the MFMA kernels: tile [128 rows][tcols], pitch + 16 B, then 16-byte row chunks
+template <bool TRANS, int TM = 4, int TN = 4>
+__device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&acc)[TM][TN], unsigned char* smem_raw, int m0, int n0,
+                                                 int tid, int wm, int wn, int frow, int fq) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;   // block tile; each of the 2x2 waves owns (16*TM) x (16*TN)
+  const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+  const bool swiglu = p.act == APE_ACT_SWIGLU;
+  const int tcols = TRANS ? BM : (swiglu ? BN / 2 : BN);                 // output columns held by the tile
+  const int pitch = tcols * esz + 16;                         // bytes
+  unsigned char* tile = reinterpret_cast<unsigned char*>(smem_raw);
+  const int out_rows = TRANS ? p.N : p.M, out_cols = TRANS ? p.M : (swiglu ? (p.N >> 1) : p.N);
+  const int orow0 = TRANS ? n0 : m0;
+  const int ocol0 = TRANS ? m0 : (swiglu ? (n0 >> 1) : n0);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      int lrow, lcol, cnt;
+      if (TRANS) {
+        const int n = n0 + wn * (16 * TN) + j * 16 + frow, mm = m0 + wm * (16 * TM) + i * 16 + fq * 4;
+        if (n >= p.N || mm >= p.M) continue;
+        epi_m4_values(p, n, v);
+        lrow = wn * (16 * TN) + j * 16 + frow; lcol = wm * (16 * TM) + i * 16 + fq * 4; cnt = 4;
+      } else {
+        const int m = m0 + wm * (16 * TM) + i * 16 + frow, nn = n0 + wn * (16 * TN) + j * 16 + fq * 4;
+        if (m >= p.M || nn >= p.N) continue;
+        int ocol;
+        epi_n4_values(p, m, nn, v, ocol, cnt);
+        lrow = wm * (16 * TM) + i * 16 + frow; lcol = ocol - ocol0; cnt = swiglu ? 2 : 4;
+      }
+      unsigned char* dst = tile + lrow * pitch + lcol * esz;
+      if (esz == 4) {
+        if (cnt == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+      } else {
+        if (cnt == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+        else *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+      }
+    }
+  __syncthreads();
+  // coalesced copy-out: 128 rows x (tcols*esz/16) 16-byte chunks; consecutive lanes -> consecutive chunks of a row
+  const int cpr = tcols * esz / 16;
+  const int per = 16 / esz;  // elements per chunk
+  const int trows = TRANS ? BN : BM;
+  for (int cid = tid; cid < trows * cpr; cid += 256) {
+    const int lrow = cid / cpr, cc = cid % cpr;
+    const int grow = orow0 + lrow;
+    const int gcol = ocol0 + cc * per;
+    if (grow >= out_rows || gcol >= out_cols) continue;
+    const unsigned char* src = tile + lrow * pitch + cc * 16;
+    unsigned char* gdst = reinterpret_cast<unsigned char*>(p.C) + ((size_t)grow * p.ldc + gcol) * esz;
+    if (gcol + per <= out_cols) {
+      *reinterpret_cast<uint4*>(gdst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+      const int rem = out_cols - gcol;
+      if (esz == 4) for (int e = 0; e < rem; ++e) reinterpret_cast<float*>(gdst)[e] = reinterpret_cast<const float*>(src)[e];
+      else for (int e = 0; e < rem; ++e) reinterpret_cast<bf16_t*>(gdst)[e] = reinterpret_cast<const bf16_t*>(src)[e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel v3 ("ring"): 128x128 tile, BK = 32, FOUR LDS stages filled by global_load_lds and consumed
+// behind counted `s_waitcnt vmcnt(N)` + raw `s_barrier`, so three K-tiles stay in flight across every barrier
+// (the v2 loop drained its single prefetched tile with vmcnt(0) each iteration and sat on HBM/L2 latency).
+// LDS image per stage: A [128][32] | W [128][32] bf16 (64-byte rows, chunk ^= ((row>>3)&1)<<1 keeps the 16-row
+// ds_read_b128 fragments conflict-free).  Needs K % 32 == 0.
+// ------------------------------------------------------------------------------------------
+#define GR_K 32
+#define GR_STAGES 4
+__device__ __forceinline__ int swz64(int row, int c) { return row * 32 + ((c ^ (((row >> 3) & 1) << 1)) << 3); }
+
+template <bool TRANS, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams p) {
+  constexpr int BM = 32 * TM, BN = 32 * TN;           // 128x128 (TM=TN=4) or 64x64 (TM=TN=2) block tile
+  constexpr int STAGE = (BM + BN) * GR_K;              // elements per LDS stage: A [BM][32] | W [BN][32]
+  constexpr int GA = TM / 2, GW = TN / 2;              // 16-row glds groups per wave for A and for W
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // GEMM_V2_LDS bytes; stages use the first 64 KiB
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);                        // stage s: A at s*STAGE, W at s*STAGE + BM*32 (elements)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nblk = gridDim.x;
+  int id;
+  {
+    const int b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tm = id / tiles_n, tn = id % tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+
+  // wave w fills row groups 2w, 2w+1 (16 rows x 64 B = 1 KiB per instruction) of A and of W
+  const bf16_t* ga[GA];
+  const bf16_t* gw[GW];
+  int soa[GA], sow[GW];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    const int rg = wave * GA + i;
+    const int row = rg * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
+    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+    ga[i] = A + (size_t)gm * p.lda + c * 8;
+    soa[i] = rg * 512;
+  }
+#pragma unroll
+  for (int i = 0; i < GW; ++i) {
+    const int rg = wave * GW + i;
+    const int row = rg * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ (((row >> 3) & 1) << 1);
+    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+    gw[i] = W + (size_t)gn * p.ldw + c * 8;
+    sow[i] = rg * 512;
+  }
+  constexpr int LPT = GA + GW;   // glds instructions per wave per K-tile
+  auto issue = [&](int kt) {
+    bf16_t* st = smem + (kt & (GR_STAGES - 1)) * STAGE;
+#pragma unroll
+    for (int i = 0; i < GA; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ga[i] + kt * GR_K), (lds_void_t*)(st + soa[i]), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < GW; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gw[i] + kt * GR_K), (lds_void_t*)(st + BM * GR_K + sow[i]), 16, 0, 0);
+  };
+
+  f32x4_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+
+  // split-K: blockIdx.y owns k-tiles [kbeg, kbeg + nk)
+  const int nk_total = p.K / GR_K;
+  const int splits = gridDim.y;
+  const int per_split = (nk_total + splits - 1) / splits;
+  const int kbeg = blockIdx.y * per_split;
+  const int nk = (nk_total - kbeg) < per_split ? (nk_total - kbeg) : per_split;
+#pragma unroll
+  for (int i = 0; i < GA; ++i) ga[i] += (size_t)kbeg * GR_K;
+#pragma unroll
+  for (int i = 0; i < GW; ++i) gw[i] += (size_t)kbeg * GR_K;
+  auto load_frags = [&](int kt, bf16x8_t (&af)[TM], bf16x8_t (&wf)[TN]) {
+    const bf16_t* sa = smem + (kt & (GR_STAGES - 1)) * STAGE;
+    const bf16_t* sw = sa + BM * GR_K;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(sa + swz64(wm * (16 * TM) + i * 16 + frow, fq)));
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(sw + swz64(wn * (16 * TN) + j * 16 + frow, fq)));
+  };
+  auto mma = [&](bf16x8_t (&af)[TM], bf16x8_t (&wf)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+  };
+  // Opaque "use" of a fragment set: hipcc places the lgkmcnt wait for these registers HERE (before the barrier and
+  // before the next set's ds_reads are issued) instead of in front of the first MFMA, where it would also wait for the
+  // freshly issued prefetch reads and serialise LDS latency with the matrix pipe.
+  auto touch = [&](bf16x8_t (&af)[TM], bf16x8_t (&wf)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(wf[j]));
+  };
+  // wait until this wave's loads of tile `t` have landed, given that tiles up to min(t+2, nk-1) were issued after it
+  auto wait_n_tiles_in_flight = [&](int tiles) {   // allow `tiles` younger K-tiles (LPT loads each) to stay outstanding
+    if (tiles >= 2) { if (LPT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else if (tiles == 1) { if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  auto wait_tile = [&](int t) { wait_n_tiles_in_flight(t + 2 < nk ? 2 : (t + 1 < nk ? 1 : 0)); };
+  // Software pipeline: fragments of tile t+1 are read from LDS while the 16 MFMAs of tile t run from registers.
+  //   iteration t: [tile t+1 landed] -> barrier -> issue tile t+4 into the stage tile t just vacated ->
+  //                ds_read fragments(t+1) || mfma(fragments(t))
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
+  if (nk > 2) issue(2);
+  wait_tile(0);
+  __builtin_amdgcn_s_barrier();
+  if (nk > 3) issue(3);
+  bf16x8_t fa0[TM], fw0[TN], fa1[TM], fw1[TN];
+  if (nk > 0) load_frags(0, fa0, fw0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    // ---- even tile kt from (fa0, fw0); prefetch kt+1 into (fa1, fw1)
+    if (kt + 1 < nk) wait_tile(kt + 1);   // tiles issued so far: up to min(kt+3, nk-1)
+    touch(fa0, fw0);   // our own fragment reads of tile kt are complete (see touch())
+    __builtin_amdgcn_s_barrier();
+    if (kt + 4 < nk) issue(kt + 4);
+    if (kt + 1 < nk) load_frags(kt + 1, fa1, fw1);
+    mma(fa0, fw0);
+    if (kt + 1 >= nk) break;
+    // ---- odd tile kt+1 from (fa1, fw1); prefetch kt+2 into (fa0, fw0)
+    if (kt + 2 < nk) wait_tile(kt + 2);
+    touch(fa1, fw1);
+    __builtin_amdgcn_s_barrier();
+    if (kt + 5 < nk) issue(kt + 5);
+    if (kt + 2 < nk) load_frags(kt + 2, fa0, fw0);
+    mma(fa1, fw1);
+  }
+  __syncthreads();   // all operand reads done before the epilogue reuses the LDS
+  if (splits > 1) {
+    // raw fp32 partial tile -> workspace plane of this split; gemm_splitk_reduce_kernel finishes the job
+    GemmParams q = p;
+    q.C = p.workspace + (size_t)blockIdx.y * p.M * p.N;
+    q.ldc = p.N; q.out_dt = APE_DT_F32; q.bias = nullptr; q.residual = nullptr; q.rowmask = nullptr; q.rope_cos = nullptr;
+    q.act = APE_ACT_NONE; q.alpha = 1.f; q.clamp = 0.f;
+    if (nk <= 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    epilogue_via_lds<TRANS, TM, TN>(q, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
+    return;
+  }
+  epilogue_via_lds<TRANS, TM, TN>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
+}
+
+// sum the split-K partial planes and apply the full epilogue; one thread per 4 consecutive columns
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
+  const int ngrp = (p.N + 3) / 4;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)p.M * ngrp) return;
+  const int m = (int)(gid / ngrp), n0 = (int)(gid % ngrp) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const size_t plane = (size_t)p.M * p.N;
+  const float* src = p.workspace + (size_t)m * p.N + n0;
+  const bool full = (n0 + 3 < p.N) && (p.N % 4 == 0);
+  for (int s = 0; s < p.splitk; ++s) {
+    if (full) {
+      const float4 t = *reinterpret_cast<const float4*>(src + s * plane);
+      v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    } else {
+      for (int r = 0; r < 4 && n0 + r < p.N; ++r) v[r] += src[s * plane + r];
+    }
+  }
+  epi_n4(p, m, n0, v);
+}
 
 template <bool TRANS, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p) {
@@ -383,61 +635,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p
     __syncthreads();
   }
 
-  // ---- epilogue through LDS (reusing the operand buffers + the dynamic tail): tile [128 rows][tcols], pitch + 16 B
-  const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
-  const bool swiglu = p.act == APE_ACT_SWIGLU;
-  const int tcols = swiglu ? GB_N / 2 : GB_N;                 // output columns held by the tile
-  const int pitch = tcols * esz + 16;                         // bytes
-  unsigned char* tile = reinterpret_cast<unsigned char*>(smem_raw);
-  const int out_rows = TRANS ? p.N : p.M, out_cols = TRANS ? p.M : (swiglu ? (p.N >> 1) : p.N);
-  const int orow0 = TRANS ? n0 : m0;
-  const int ocol0 = TRANS ? m0 : (swiglu ? (n0 >> 1) : n0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      int lrow, lcol, cnt;
-      if (TRANS) {
-        const int n = n0 + wn * 64 + j * 16 + frow, mm = m0 + wm * 64 + i * 16 + fq * 4;
-        if (n >= p.N || mm >= p.M) continue;
-        epi_m4_values(p, n, v);
-        lrow = wn * 64 + j * 16 + frow; lcol = wm * 64 + i * 16 + fq * 4; cnt = 4;
-      } else {
-        const int m = m0 + wm * 64 + i * 16 + frow, nn = n0 + wn * 64 + j * 16 + fq * 4;
-        if (m >= p.M || nn >= p.N) continue;
-        int ocol;
-        epi_n4_values(p, m, nn, v, ocol, cnt);
-        lrow = wm * 64 + i * 16 + frow; lcol = ocol - ocol0; cnt = swiglu ? 2 : 4;
-      }
-      unsigned char* dst = tile + lrow * pitch + lcol * esz;
-      if (esz == 4) {
-        if (cnt == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-      } else {
-        if (cnt == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        else *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
-      }
-    }
-  __syncthreads();
-  // coalesced copy-out: 128 rows x (tcols*esz/16) 16-byte chunks; consecutive lanes -> consecutive chunks of a row
-  const int cpr = tcols * esz / 16;
-  const int per = 16 / esz;  // elements per chunk
-  for (int cid = tid; cid < GB_M * cpr; cid += 256) {
-    const int lrow = cid / cpr, cc = cid % cpr;
-    const int grow = orow0 + lrow;
-    const int gcol = ocol0 + cc * per;
-    if (grow >= out_rows || gcol >= out_cols) continue;
-    const unsigned char* src = tile + lrow * pitch + cc * 16;
-    unsigned char* gdst = reinterpret_cast<unsigned char*>(p.C) + ((size_t)grow * p.ldc + gcol) * esz;
-    if (gcol + per <= out_cols) {
-      *reinterpret_cast<uint4*>(gdst) = *reinterpret_cast<const uint4*>(src);
-    } else {
-      const int rem = out_cols - gcol;
-      if (esz == 4) for (int e = 0; e < rem; ++e) reinterpret_cast<float*>(gdst)[e] = reinterpret_cast<const float*>(src)[e];
-      else for (int e = 0; e < rem; ++e) reinterpret_cast<bf16_t*>(gdst)[e] = reinterpret_cast<const bf16_t*>(src)[e];
-    }
-  }
+  epilogue_via_lds<TRANS>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -526,6 +724,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(p.act != APE_ACT_SWIGLU || (p.N % 4 == 0 && !p.trans_out), "ape_hip_gemm: swiglu needs N%%4==0, no transpose");
   APE_CHECK_ARG(!p.trans_out || (p.residual == nullptr && p.rope_cos == nullptr && p.rowmask == nullptr),
                 "ape_hip_gemm: transposed output supports bias/act only");
+  APE_CHECK_ARG(p.splitk <= 1 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: split-K is implemented for the bf16 kernel only");
   APE_CHECK_ARG(p.rope_cos == nullptr || (p.rope_sin != nullptr && p.rope_rows > 0 && p.rope_hd > 0 && p.rope_hd % 4 == 0),
                 "ape_hip_gemm: bad rope args");
   const int esz_out = p.out_dt == APE_DT_F32 ? 4 : 2;
@@ -540,6 +739,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
     APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
     APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
     const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);
+    const int nblk64 = ceil_div(p.M, 64) * ceil_div(p.N, 64);
     static const int force_v1 = getenv("APE_GEMM_V1") ? atoi(getenv("APE_GEMM_V1")) : 0;
     static const int no_glds = getenv("APE_GEMM_NOGLDS") ? atoi(getenv("APE_GEMM_NOGLDS")) : 0;
     const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
@@ -547,6 +747,9 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
     const bool v2_ok = !force_v1 && ((size_t)p.ldc * esz) % 16 == 0 && ((uintptr_t)p.C) % 16 == 0 &&
                        (p.act != APE_ACT_SWIGLU || p.N % 4 == 0);
     const bool glds = v2_ok && !no_glds && p.K % GB_K == 0;
+    static const int no_ring = getenv("APE_GEMM_NORING") ? atoi(getenv("APE_GEMM_NORING")) : 0;
+    static const int use_ring_always = getenv("APE_GEMM_RING") ? atoi(getenv("APE_GEMM_RING")) : 0;
+    const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
     if (v2_ok) {
       static bool attr_done = false;
       if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
@@ -554,9 +757,25 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<true, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
         attr_done = true;
       }
-      if (p.trans_out) {
+      if (p.splitk > 1) {
+        APE_CHECK_ARG(ring && !p.trans_out && p.workspace != nullptr && p.act != APE_ACT_SWIGLU,
+                      "ape_hip_gemm: split-K needs bf16, K %% 32 == 0, no trans_out / SwiGLU, and a workspace");
+        APE_CHECK_ARG(p.N % 4 == 0 && ((uintptr_t)p.workspace) % 16 == 0, "ape_hip_gemm: split-K needs N %% 4 == 0 and an aligned workspace");
+        if (p.tile64) hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64, p.splitk), dim3(256), GEMM_T64_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk, p.splitk), dim3(256), GEMM_V2_LDS, s, p);
+        const size_t groups = (size_t)p.M * ((p.N + 3) / 4);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
+      } else if (ring && p.tile64) {
+        if (p.trans_out) hipLaunchKernelGGL((gemm_bf16_ring_kernel<true, 2, 2>), dim3(nblk64), dim3(256), GEMM_T64_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64), dim3(256), GEMM_T64_LDS, s, p);
+      } else if (ring && (use_ring_always || nblk < 64)) {
+        if (p.trans_out) hipLaunchKernelGGL((gemm_bf16_ring_kernel<true, 4, 4>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+      } else if (p.trans_out) {
         if (glds) hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
         else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, false>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
       } else {

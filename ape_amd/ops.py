@@ -55,8 +55,31 @@ def _ld(t):
     return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
 
 
+def _auto_tiling(M, N, K, dtype, trans_out, act):
+    """(tile64, splitk) chosen from graph-replayed measurements on MI355X (tools/gpu_probe_small.py):
+    * K <= 512: 64x64 tiles always -- 32 KiB of LDS per workgroup lets 4-5 workgroups overlap on a CU, which is what
+      a 4..16-iteration K loop needs (87296x2048x256: 369 vs 480 us; 900x256x256: 7 vs 20 us);
+    * few output tiles: 64x64 tiles plus split-K up to ~256 workgroups (900x256x2048: 11 vs 38 us);
+    * one 128x128 tile per CU: 64x64 tiles for K <= 1024 (4096x1024x1024: 24 vs 29 us), split-K 2 for long K."""
+    if dtype != torch.bfloat16 or K % 32 != 0:
+        return 0, 1
+    t128 = ((M + 127) // 128) * ((N + 127) // 128)
+    t64 = ((M + 63) // 64) * ((N + 63) // 64)
+    splittable = not trans_out and act != ACT_SWIGLU and N % 4 == 0
+    if K <= 512:
+        return 1, 1
+    if t128 < 96:
+        return 1, (max(1, min(K // 512, 256 // t64)) if splittable else 1)
+    if t128 <= 256:
+        if K <= 1024:
+            return 1, 1
+        if splittable and K >= 2048:
+            return 0, 2
+    return 0, 1
+
+
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None):
     """C = epi(alpha * a @ w.T); see ApeGemmArgs in include/ape_hip.h for the epilogue order.
 
     a [M,K], w [N,K] (same dtype).  rope = (cos, sin, rows, head_dim, cols).  trans_out returns C^T as
@@ -100,6 +123,15 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         args.rope_cos, args.rope_sin = _f32vec(cos, "rope cos").data_ptr(), _f32vec(sin, "rope sin").data_ptr()
         args.rope_rows, args.rope_hd, args.rope_cols = rows, hd, cols
     args.alpha, args.clamp = float(alpha), float(clamp)
+    t64, sk = _auto_tiling(M, N, K, a.dtype, trans_out, act)
+    if splitk is not None:
+        sk = int(splitk)
+    if tile64 is not None:
+        t64 = int(tile64)
+    args.tile64 = t64
+    if sk > 1:
+        ws = torch.empty((sk * M * N,), dtype=torch.float32, device=a.device)
+        args.splitk, args.workspace = sk, ws.data_ptr()
     _lib.check(_lib.load().ape_hip_gemm(ctypes.byref(args), _stream()), "ape_hip_gemm")
     return out
 

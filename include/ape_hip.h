@@ -68,6 +68,12 @@ typedef struct ApeGemmArgs {
   int32_t vec_ok;                        /* filled by the launcher */
   float alpha;
   float clamp; /* <= 0: no clamp */
+  /* split-K (bf16, K % 32 == 0, no trans_out): `splitk` > 1 slices K over blockIdx.y; fp32 partial tiles go to
+   * `workspace` ([splitk, M, N] floats, caller-owned) and a second kernel reduces them and applies the epilogue.
+   * For launches with too few 128x128 tiles to keep the memory system busy (M = 900 decoder GEMMs, K = T). */
+  int32_t splitk;
+  int32_t tile64; /* 1: 64x64 block tiles (4x more blocks; for launches with few output tiles), needs K % 32 == 0 */
+  float* workspace;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 

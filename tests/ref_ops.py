@@ -33,7 +33,7 @@ def _rotate_half(x):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None):
     M, K = a.shape
     N = w.shape[0]
     x = (a.float() @ w.float().t()) * alpha

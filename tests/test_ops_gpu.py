@@ -109,6 +109,43 @@ def test_gemm_into_view(ops):
     assert out[:, :256].abs().max().item() == 0 and out[:, 512:].abs().max().item() == 0
 
 
+def test_gemm_splitk(ops):
+    """split-K ring kernel + reduce/epilogue kernel (tiny-grid GEMMs of the decoder, K = tokens reductions)"""
+    for (M, N, K, sk) in [(900, 256, 2048, 8), (900, 256, 2048, None), (256, 256, 87296, 32), (100, 512, 1024, 3), (77, 8, 256, 2)]:
+        a, w = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=2)
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        for kw in (dict(out_dtype=torch.float32), dict(act=ref_ops.ACT_RELU, residual=res, out_dtype=torch.bfloat16)):
+            got = ops.gemm(a, w, bias, splitk=sk, **kw)
+            ref = ref_ops.gemm(a, w, bias, **kw)
+            e = relerr(got, ref)
+            print(f"gemm splitk M{M} N{N} K{K} sk={sk} {list(kw)}: {e:.3e}")
+            assert e < (TOL[torch.bfloat16] if kw["out_dtype"] == torch.bfloat16 else 3e-4)
+
+
+@pytest.mark.parametrize("trans", [False, True])
+def test_gemm_tile64(ops, trans):
+    """64x64-tile ring kernel (small launches), with and without split-K, all epilogues that matter for the decoder"""
+    M, N, K = 900, 256, 256
+    a, w = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
+    if trans:
+        cases = [dict(trans_out=True, m_pad=960), dict(trans_out=True, out_dtype=torch.float32, act=ref_ops.ACT_RELU)]
+    else:
+        cases = [dict(), dict(out_dtype=torch.float32), dict(residual=res, act=ref_ops.ACT_RELU), dict(splitk=4, residual=res),
+                 dict(act=ref_ops.ACT_SWIGLU, out_dtype=torch.float32)]
+    for kw in cases:
+        got = ops.gemm(a, w, bias, tile64=1, **kw)
+        ref = ref_ops.gemm(a, w, bias, **kw)
+        e = relerr(got, ref)
+        print(f"gemm tile64 trans={trans} {list(kw)}: {e:.3e}")
+        assert got.shape == ref.shape and e < 6e-3
+    # ragged shapes
+    for (M2, N2, K2) in [(77, 40, 96), (130, 200, 64), (64, 64, 32)]:
+        a2, w2 = rnd(M2, K2, dtype=torch.bfloat16, seed=5), rnd(N2, K2, dtype=torch.bfloat16, seed=6)
+        e = relerr(ops.gemm(a2, w2, None, tile64=1, out_dtype=torch.float32), ref_ops.gemm(a2, w2, None, out_dtype=torch.float32))
+        assert e < 3e-4, (M2, N2, K2, e)
+
+
 def test_gemv(ops):
     x = rnd(3, 1024, seed=1)
     for dt in (torch.float32, torch.bfloat16):
