@@ -77,6 +77,11 @@ SIGNATURES = {
     "ape_hip_nms_scan_classes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ape_hip_vl_pool_workspace_floats": (c_int, [c_int, c_int]),
     "ape_hip_vl_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_segment_softmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_colstats_workspace_floats": (c_int, [c_int, c_int]),
+    "ape_hip_colstats": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_transpose": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                  c_void_p]),
     "ape_hip_mask_upsample_bits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ape_hip_roi_align_bits": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ape_hip_paste_bits": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

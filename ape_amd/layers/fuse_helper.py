@@ -1,8 +1,16 @@
 """Bi-directional vision<->language attention block -- mirror of ape/layers/fuse_helper.py
 (BiMultiHeadAttention :8-166, BiAttentionBlock :178-232): same constructor kwargs and parameter names.
 
-Implemented path: ONE language token (name-prompt mode: deformable_detr_segm_vl.py:349-352 passes a single zero
-token).  With L = 1 the softmax over the language axis is identically 1, so
+Two device paths share the parameters:
+
+* dense (`forward_tokens_dense`, L > 1: phrase / expression prompts fuse the whole text bank, :356-358) -- the score
+  tensor is ONE [T, 8L] matrix S = LN_v(v) U^T with U[(h,l)] = scale * W_v,h^T k_h[l] (the 256->2048 query projection
+  over T tokens is folded into the L text tokens), both softmaxes run on S (csrc/softmax.hip), and the two value
+  paths are single GEMMs with the per-head output projections folded into their small operand:
+      v' = LN_v(v) + softmax_l(S) Z,           Z[(h,l)] = gamma_v * W_ov,h vl_h[l]              (K = 8L)
+      l' = LN_l(l) + gamma_l out_l( concat_h( (softmax_t(S)^T LN_v(v))_h W_vv,h^T + b_vv,h ) )   (K = T, split-K)
+* single token (`forward_tokens_single`, L = 1: name-prompt mode, deformable_detr_segm_vl.py:349-352 passes one zero
+  token).  With L = 1 the softmax over the language axis is identically 1, so
     delta_v = out_v_proj(values_l_proj(LN_l(l)))                              (a per-layer vector)
 and the language update is an attention pool over all vision tokens,
     S[t,h]  = scale * (LN_v(v)[t] . (W_v,h^T k_h) + b_v,h . k_h)             ([T,8], one skinny GEMM)
@@ -71,6 +79,63 @@ class BiAttentionBlock(nn.Module):
                 gv=f32(self.gamma_v), gl=f32(self.gamma_l))
         return self._pack.get(self, dt, build)
 
+    def packed_dense(self, dt):
+        def build(_key):
+            a = self.attn
+            nh, hd, vd = a.num_heads, a.head_dim, a.v_dim
+            gv = f32(self.gamma_v)
+            wov = f32(a.out_v_proj.weight) * gv[:, None]                         # gamma_v folded into out_v_proj
+            return dict(
+                wl=pack_matrix(a.l_proj.weight, dt), bl=f32(a.l_proj.bias),
+                wvl=pack_matrix(a.values_l_proj.weight, dt), bvl=f32(a.values_l_proj.bias),
+                # per head: W_v,h^T  [v_dim, hd]  (W operand of  U_h = k_h W_v,h)
+                wvT=(f32(a.v_proj.weight).view(nh, hd, vd).transpose(1, 2) * a.scale).contiguous().to(dt),
+                bv=f32(a.v_proj.bias).view(nh, hd),
+                # per head: gamma_v * W_ov[:, h]  [v_dim, hd]  (W operand of  Z_h = vl_h W_ov,h^T)
+                wov=wov.view(vd, nh, hd).permute(1, 0, 2).contiguous().to(dt), bov=(gv * f32(a.out_v_proj.bias)).contiguous(),
+                wvv=f32(a.values_v_proj.weight).view(nh, hd, vd).contiguous().to(dt), bvv=f32(a.values_v_proj.bias).view(nh, hd).contiguous(),
+                wol=pack_matrix(a.out_l_proj.weight, dt), bol=f32(a.out_l_proj.bias))
+        return self._pack.get(self, ("dense", dt), build)
+
+    def forward_tokens_dense(self, x, lvl_pos, l, dt):
+        """x [T,256] vision tokens, l [L, l_dim] fp32 text tokens (L > 1) -> (v_new, v_new + lvl_pos, l_new [L, l_dim]).
+        fuse_helper.py:67-166 + 224-231; no language mask (the banks are reduced to one token per phrase, :303)."""
+        P, Pd = self.packed(dt), self.packed_dense(dt)
+        a = self.attn
+        nh, hd, L, T = a.num_heads, a.head_dim, l.shape[0], x.shape[0]
+        dev = x.device
+        l_n = ops.layernorm(l, P["lnl"][0], P["lnl"][1], P["lnl"][2], out_dtype=torch.float32)
+        l_c = l_n.to(dt)
+        k = ops.gemm(l_c, Pd["wl"], Pd["bl"], out_dtype=dt)                      # l_proj          [L, E]
+        vl = ops.gemm(l_c, Pd["wvl"], Pd["bvl"], out_dtype=dt)                   # values_l_proj   [L, E]
+        v_n = ops.layernorm(x, P["lnv"][0], P["lnv"][1], P["lnv"][2], out_dtype=dt)
+        U = torch.empty((nh * L, a.v_dim), dtype=dt, device=dev)                 # rows (h, l)
+        Zt = torch.empty((a.v_dim, nh * L), dtype=dt, device=dev)                # Z^T: columns (h, l)
+        for h in range(nh):
+            seg = slice(h * hd, (h + 1) * hd)
+            ops.gemm(k[:, seg], Pd["wvT"][h], None, out=U[h * L:(h + 1) * L])
+            ops.gemm(vl[:, seg], Pd["wov"][h], None, trans_out=True, out=Zt[:, h * L:(h + 1) * L])
+        c = (a.scale * (k.float().view(L, nh, hd) * Pd["bv"][None]).sum(-1)).t().reshape(-1).contiguous()   # b_v,h . k_h[l]
+        S = ops.gemm(v_n, U, c, out_dtype=torch.float32)                         # [T, 8L] scores (scale folded into U)
+        gmax = S.max().reshape(1)                                                # stable_softmax_2d: one global max (:89-90)
+        pv = ops.segment_softmax(S, nh, gmax, dt)                                # softmax over l per head       (:131)
+        v_new = ops.gemm(pv, Zt, Pd["bov"], residual=v_n, out_dtype=dt)          # LN_v(v) + gamma_v out_v(...)  (:225-229)
+        qp = v_new + lvl_pos
+        plT = ops.col_softmax_t(S, gmax, dt, pad=8)                              # softmax over t, [8L, Tp]      (:101-116)
+        vT = ops.transpose(v_n, pad=8)                                           # [256, Tp]
+        G = ops.gemm(plT, vT, None, out_dtype=dt)                                # sum_t p[(h,l),t] LN_v(v)[t]   [8L, 256]
+        ol = torch.empty((L, nh * hd), dtype=dt, device=dev)
+        for h in range(nh):
+            ops.gemm(G[h * L:(h + 1) * L], Pd["wvv"][h], Pd["bvv"][h], out=ol[:, h * hd:(h + 1) * hd])   # values_v_proj
+        dl = ops.gemm(ol, Pd["wol"], Pd["bol"], out_dtype=torch.float32)
+        l_new = l_n + P["gl"] * dl
+        return v_new, qp, l_new
+
+    def forward_tokens(self, x, lvl_pos, l, dt):
+        if l.shape[0] == 1:
+            return self.forward_tokens_single(x, lvl_pos, l, dt)
+        return self.forward_tokens_dense(x, lvl_pos, l, dt)
+
     def forward_tokens_single(self, x, lvl_pos, l, dt):
         """x [T,256] vision tokens, lvl_pos [T,256], l [1, l_dim] fp32 ->
         (v_new [T,256], v_new + lvl_pos [T,256], l_new [1, l_dim])"""
@@ -94,14 +159,15 @@ class BiAttentionBlock(nn.Module):
         return v_new, qp, l_new
 
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
-        """reference signature (fuse_helper.py:221-232) for a single language token"""
-        if l.shape[1] != 1 or attention_mask_l is not None:
-            raise NotImplementedError("ape_amd BiAttentionBlock: only the single-text-token (name prompt) path is implemented")
+        """reference signature (fuse_helper.py:221-232); the text bank carries no mask (reduced tokens, :266/:303)"""
+        if attention_mask_l is not None:
+            raise NotImplementedError("ape_amd BiAttentionBlock: per-token language masks (un-reduced expression tokens, "
+                                      "text_feature_reduce_before_fusion=False) are not implemented")
         dt = getattr(self, "compute_dtype", torch.bfloat16)
         vs, ls = [], []
         for b in range(v.shape[0]):
             zeros = torch.zeros_like(v[b], dtype=dt)
-            vn, _, ln = self.forward_tokens_single(v[b].to(dt).contiguous(), zeros, l[b].float().contiguous(), dt)
+            vn, _, ln = self.forward_tokens(v[b].to(dt).contiguous(), zeros, l[b].float().contiguous(), dt)
             vs.append(vn.to(v.dtype))
             ls.append(ln.to(l.dtype))
         return torch.stack(vs), torch.stack(ls)

@@ -31,7 +31,8 @@ class VisionLanguageAlign(nn.Module):
         e = torch.nn.functional.normalize(embedding.float(), p=2, dim=-1)
         tok = ops.gemm((e / 2.0).contiguous(), P["w"], P["b"], out_dtype=torch.float32)
         bias = (torch.matmul(e, self.bias_lang.detach().float()) + self.bias0.detach().float()).contiguous()
-        inv_scale = 1.0 / float(self.log_scale.detach().exp())   # host scalar: read once per vocabulary, not per image
+        # host scalar, read once per module (not per image / per vocabulary: phrase mode rebuilds the vocabulary per image)
+        inv_scale = self._pack.get(self, "inv_scale", lambda _k: 1.0 / float(self.log_scale.detach().exp()))
         return tok.to(dt).contiguous(), bias, inv_scale
 
     def forward_tokens(self, x, tok, bias, inv_scale):

@@ -88,6 +88,9 @@ class DeformableDETRSegmVL(nn.Module):
         self.class_names = {}                       # dataset name -> list[str]; filled by set_class_names (MetadataCatalog stand-in)
         self.eval_dataset_id, self.eval_dataset_entity = -1, ""
         self.text_feature_bank, self.text_feature_bank_reset = text_feature_bank, text_feature_bank_reset
+        self.text_feature_reduce_before_fusion = text_feature_reduce_before_fusion
+        # rows of features_phrase_bank (ape_deta/deformable_detr.py:281-291): max criterion.num_classes
+        self.phrase_bank_size = max([int(getattr(c, "num_classes", 0)) for c in self.criterion] + [0]) or 256
         self.embed_dim_language = embed_dim_language
         self.instance_on, self.semantic_on, self.panoptic_on = instance_on, semantic_on, panoptic_on
         self.input_shapes, self.mask_in_features, self.mask_encode_level = input_shapes, mask_in_features, mask_encode_level
@@ -169,9 +172,13 @@ class DeformableDETRSegmVL(nn.Module):
 
     # ------------------------------------------------------------------ text side
     def text_features(self, batched_input):
-        """name-prompt text bank [K, D_l] fp32 on the device (deformable_detr_segm_vl.py:224-259)"""
+        """(text bank [K, D_l] fp32 on the device, names, prompt mode) -- deformable_detr_segm_vl.py:204-259, 283-303.
+        prompt "name": the bank only feeds the classifier; "phrase" / "expression": it is fused in the encoder."""
         if "text_features" in batched_input:                       # pre-computed CLIP features (the broadcast payload)
-            return batched_input["text_features"].to(self.device).float(), None
+            prompt = batched_input.get("prompt", "name")
+            if prompt not in ("name", "phrase", "expression"):
+                raise ValueError(f"ape_amd: with pre-computed text_features the prompt must be name/phrase/expression, got {prompt!r}")
+            return batched_input["text_features"].to(self.device).float(), None, prompt
         if self.eval_dataset_id >= 0:
             prompt = self.dataset_prompts[self.eval_dataset_id]
             names, cache = self.class_names[self.eval_dataset_id], True
@@ -183,12 +190,32 @@ class DeformableDETRSegmVL(nn.Module):
                 cache = False
             else:
                 names, cache = sum((self.class_names[i] for i in sorted(self.class_names)), [])[:1203], True
-        if prompt != "name":
-            raise NotImplementedError("ape_amd: phrase / expression prompts (dense multi-token fusion) are not implemented yet")
+                if prompt in ("phrase", "expression"):       # (:283-290) phrases / expressions carried by the input
+                    names = list(batched_input["expressions"]) if prompt == "expression" else list(batched_input["phrases"])
+        if prompt not in ("name", "phrase", "expression"):
+            raise ValueError(f"ape_amd: unknown prompt mode {prompt!r}")
         if self.model_language is None:
             raise RuntimeError("no text tower attached (set_model_language) and no 'text_features' in the input")
-        out = self.model_language.forward_text(names, cache=cache)
-        return out["last_hidden_state_eot"].to(self.device).float(), names
+        if prompt == "name":
+            out = self.model_language.forward_text(names, cache=cache)
+        else:
+            out = self.model_language.forward_text(names)
+            if not self.text_feature_reduce_before_fusion or "last_hidden_state_eot" not in out:
+                raise NotImplementedError("ape_amd: un-reduced text tokens (text_feature_reduce_before_fusion=False) are not implemented")
+        return out["last_hidden_state_eot"].to(self.device).float(), names, prompt
+
+    def fusion_tokens(self, text_feats, prompt):
+        """the language tokens the encoder fuses with: the zero / learnable token in name mode (:349-352); in phrase /
+        expression mode the text bank zero-padded to the phrase-bank size (:304-327, text_feature_bank with reset)"""
+        if prompt == "name":
+            return self.name_prompt_fusion_feature.detach().float().reshape(1, -1)
+        K, D = text_feats.shape
+        if self.text_feature_bank:
+            if not self.text_feature_bank_reset:
+                raise NotImplementedError("ape_amd: a persistent phrase bank (text_feature_bank_reset=False) is not implemented")
+            bank = max(K, self.phrase_bank_size)
+            text_feats = torch.cat([text_feats.float(), text_feats.new_zeros((bank - K, D), dtype=torch.float32)], 0)
+        return text_feats.float().contiguous()
 
     def class_tokens(self, feats, lvl, dt):
         """per-vocabulary constants of the last-level classifier, cached by tensor identity"""
@@ -200,7 +227,7 @@ class DeformableDETRSegmVL(nn.Module):
         return self._text[key]
 
     # ------------------------------------------------------------------ the hot path, one image
-    def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True):
+    def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name"):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes)."""
         dt = self.compute_dtype
         P = self.packed(dt)
@@ -220,7 +247,7 @@ class DeformableDETRSegmVL(nn.Module):
         if stages is not None:
             stages.update({k: v[0] for k, v in maps.items()})
             stages["enc_input"] = src
-        l0 = self.name_prompt_fusion_feature.detach().float().reshape(1, -1)
+        l0 = self.fusion_tokens(text_feats, prompt)
         tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages)
         self.transformer_time = time.perf_counter() - t0
         t0 = time.perf_counter()
@@ -228,7 +255,10 @@ class DeformableDETRSegmVL(nn.Module):
         lvl = self.transformer.decoder.num_layers - 1
         x = tr["inter_states"][lvl]
         ref_prev = tr["init_reference"] if lvl == 0 else tr["inter_references"][lvl - 1]
-        tok, cbias, inv_scale = self.class_tokens(text_feats, lvl, dt)
+        if prompt == "name":
+            tok, cbias, inv_scale = self.class_tokens(text_feats, lvl, dt)
+        else:                                    # the FUSED tokens are the vocabulary (:448); they change per image
+            tok, cbias, inv_scale = self.class_embed[lvl].text_side(tr["query_l"], dt)
         logits = self.class_embed[lvl].forward_tokens(x, tok, cbias, inv_scale)                       # [Q,K] fp32
         boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
         out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
@@ -295,9 +325,9 @@ class DeformableDETRSegmVL(nn.Module):
         for inp in batched_inputs:
             t0 = time.perf_counter()
             image = inp["image"].to(self.device, non_blocking=True).float()
-            feats, _ = self.text_features(inp)
+            feats, _, prompt = self.text_features(inp)
             self.preprocess_time = time.perf_counter() - t0
-            out = self.forward_single(image, feats)
+            out = self.forward_single(image, feats, prompt=prompt)
             h, w = image.shape[-2:]
             results.append({"instances": self.postprocess_instance(out, (h, w), inp.get("height", h), inp.get("width", w))})
         return results

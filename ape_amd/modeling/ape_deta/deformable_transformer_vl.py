@@ -44,7 +44,7 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
     def forward_tokens(self, x, geo, lvl_pos, l, dt, stages=None):
         """x [T,256], l [1, l_dim] fp32 -> (memory [T,256], l) -- reference loop :84-115"""
         for i, (vl, layer) in enumerate(zip(self.vl_layers, self.layers)):
-            v_new, qp, l = vl.b_attn.forward_tokens_single(x, lvl_pos, l, dt)
+            v_new, qp, l = vl.b_attn.forward_tokens(x, lvl_pos, l, dt)
             if stages is not None:
                 stages[f"enc{i}_fused_v"], stages[f"enc{i}_fused_l"] = v_new, l
             # BaseTransformerLayer ("self_attn", "norm", "ffn", "norm"): value = fused tokens (no pos), identity = same

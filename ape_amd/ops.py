@@ -384,6 +384,60 @@ def vl_pool(scores, x):
     return out
 
 
+def segment_softmax(scores, nseg, gmax, out_dtype):
+    """Vision side of the dense bi-attention: softmax over each of the nseg column segments of every row of
+    clamp(scores - gmax) (fuse_helper.py:89-99,131).  scores fp32 [T, nseg*L], gmax fp32 device scalar."""
+    _dev(scores, gmax)
+    _rowmajor(scores, "scores")
+    if scores.dtype != torch.float32 or gmax.dtype != torch.float32 or scores.shape[1] % nseg:
+        raise ValueError("ape_amd.ops.segment_softmax: scores must be float32 [T, nseg*L], gmax a float32 scalar")
+    T, C = scores.shape
+    out = torch.empty((T, C), dtype=out_dtype, device=scores.device)
+    rc = _lib.load().ape_hip_segment_softmax(_p(scores), _ld(scores), T, nseg, C // nseg, _p(gmax), _p(out), _ld(out), _dt(out),
+                                             _stream())
+    _lib.check(rc, "ape_hip_segment_softmax")
+    return out
+
+
+def _padded(rows, cols, pad, dtype, device):
+    cp = (cols + pad - 1) // pad * pad
+    out = torch.empty((rows, cp), dtype=dtype, device=device)
+    if cp != cols:
+        out[:, cols:].zero_()
+    return out
+
+
+def col_softmax_t(scores, gmax, out_dtype, pad=1):
+    """Language side of the dense bi-attention: softmax over the T rows of clamp(scores - gmax), returned TRANSPOSED
+    [C, Tp] (fuse_helper.py:101-116) -- the A operand of the token reduction; Tp = T rounded up to `pad`, zero filled."""
+    _dev(scores, gmax)
+    _rowmajor(scores, "scores")
+    if scores.dtype != torch.float32 or gmax.dtype != torch.float32:
+        raise ValueError("ape_amd.ops.col_softmax_t: scores must be float32, gmax a float32 scalar")
+    T, C = scores.shape
+    lib = _lib.load()
+    ws = torch.empty((lib.ape_hip_colstats_workspace_floats(T, C),), dtype=torch.float32, device=scores.device)
+    stats = torch.empty((2, C), dtype=torch.float32, device=scores.device)
+    rc = lib.ape_hip_colstats(_p(scores), _ld(scores), T, C, _p(gmax), _p(ws), _p(stats[0]), _p(stats[1]), _stream())
+    _lib.check(rc, "ape_hip_colstats")
+    out = _padded(C, T, pad, out_dtype, scores.device)
+    rc = lib.ape_hip_transpose(_p(scores), _ld(scores), _dt(scores), T, C, _p(gmax), _p(stats[0]), _p(stats[1]), _p(out), _ld(out),
+                               _dt(out), _stream())
+    _lib.check(rc, "ape_hip_transpose")
+    return out
+
+
+def transpose(x, out_dtype=None, pad=1):
+    """out[c, t] = x[t, c] (materialised; feeds GEMM operands that must be K-contiguous); columns zero-padded to `pad`."""
+    _dev(x)
+    _rowmajor(x, "x")
+    T, C = x.shape
+    out = _padded(C, T, pad, out_dtype or x.dtype, x.device)
+    rc = _lib.load().ape_hip_transpose(_p(x), _ld(x), _dt(x), T, C, None, None, None, _p(out), _ld(out), _dt(out), _stream())
+    _lib.check(rc, "ape_hip_transpose")
+    return out
+
+
 def mask_upsample_bits(logits, h0, w0, size):
     """bilinear (align_corners=False) upsample of n mask-logit rows [n, h0*w0] to size x size, thresholded at 0."""
     _dev(logits)

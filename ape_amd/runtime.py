@@ -19,10 +19,10 @@ class GraphedForward:
         self.with_masks = with_masks
         self._graphs = {}
 
-    def _device_part(self, image, text, height, width):
+    def _device_part(self, image, text, height, width, prompt="name"):
         mv = self.mv
         h, w = image.shape[-2:]
-        out = mv.forward_single(image, text, with_masks=self.with_masks)
+        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt)
         boxes = out["det_boxes"].clone()
         boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
         boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
@@ -35,19 +35,19 @@ class GraphedForward:
             masks = ops.paste_bits(out["det_masks128"], boxes.contiguous(), height, width)
         return rec, masks, rec[:, :6].contiguous()
 
-    def _build(self, image, text, height, width):
+    def _build(self, image, text, height, width, prompt):
         mv = self.mv
         dev = image.device
         entry = SimpleNamespace()
         entry.image = image.clone()
         entry.text = text
         for _ in range(2):            # warm every cache (weight packing, geometry, text side) outside the capture
-            self._device_part(entry.image, text, height, width)
+            self._device_part(entry.image, text, height, width, prompt)
         torch.cuda.synchronize()
         if self.use_graph:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph):
-                entry.rec, entry.masks, entry.rec6 = self._device_part(entry.image, text, height, width)
+                entry.rec, entry.masks, entry.rec6 = self._device_part(entry.image, text, height, width, prompt)
         else:
             entry.graph = None
         k = mv.test_topk_per_image
@@ -56,22 +56,23 @@ class GraphedForward:
         return entry
 
     @torch.no_grad()
-    def __call__(self, image, text, height=None, width=None):
-        """image [3,h,w] fp32 on the device, text [K, D] on the device -> (instances on the host, device record [k,6])"""
+    def __call__(self, image, text, height=None, width=None, prompt="name"):
+        """image [3,h,w] fp32 on the device, text [K, D] on the device -> (instances on the host, device record [k,6]).
+        prompt: "name" (bank feeds the classifier only) or "phrase" / "expression" (bank fused in the encoder)."""
         h, w = image.shape[-2:]
         height, width = height or h, width or w
-        key = (h, w, height, width, text.data_ptr(), tuple(text.shape))
+        key = (h, w, height, width, text.data_ptr(), tuple(text.shape), prompt)
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            e = self._graphs[key] = self._build(image, text, height, width)
+            e = self._graphs[key] = self._build(image, text, height, width, prompt)
         if e.graph is not None:
             e.image.copy_(image, non_blocking=True)
             e.graph.replay()
             rec, masks, rec6 = e.rec, e.masks, e.rec6
         else:
-            rec, masks, rec6 = self._device_part(image, text, height, width)
+            rec, masks, rec6 = self._device_part(image, text, height, width, prompt)
         e.h_rec.copy_(rec, non_blocking=True)
         if masks is not None and e.h_masks is not None:
             e.h_masks.copy_(masks, non_blocking=True)

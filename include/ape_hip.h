@@ -210,6 +210,22 @@ int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, i
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Softmaxes of the DENSE bi-directional attention (L > 1 text tokens: phrase / expression prompts;
+ * ape/layers/fuse_helper.py:84-131).  S [T, nseg*L] fp32 is the score matrix (column (head, l)); gmax points at
+ * the device scalar max(S) (fuse_helper.py:89-90).  -- csrc/softmax.hip
+ *   segment_softmax : out[t, (h,l)] = softmax_l( clamp(S - gmax) )                     (vision side, :131)
+ *   colstats        : colmax[c], colsum[c] of clamp(S[:,c] - gmax) over the T rows         (language side, :101-116)
+ *   transpose       : out[c, t] = S[t, c], or with colmax/colsum the language-side softmax over t, transposed
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_segment_softmax(const float* S, int lds, int T, int nseg, int L, const float* gmax, void* out, int ldo, int out_dt,
+                            void* stream);
+int ape_hip_colstats_workspace_floats(int T, int C);
+int ape_hip_colstats(const float* S, int lds, int T, int C, const float* gmax, float* workspace, float* colmax, float* colsum,
+                     void* stream);
+int ape_hip_transpose(const void* S, int lds, int in_dt, int T, int C, const float* gmax, const float* colmax,
+                      const float* colsum, void* out, int ldo, int out_dt, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instance-mask post-processing of the kept detections -- csrc/masks.hip
  *   mask_upsample_bits: bilinear (align_corners=False) h0 x w0 -> S x S of n mask-logit rows, then > 0
  *                       (F.interpolate + sigmoid > 0.5, deformable_detr_segm_vl.py:569-572,605)

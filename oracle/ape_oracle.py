@@ -513,13 +513,23 @@ class ApeOracle:
     # whole forward, "name" prompt mode (deformable_detr_segm_vl.py:166-726)
     # --------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True):
+    def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True, prompt="name",
+                phrase_bank=256):
+        """prompt="phrase" (also "expression" with text_feature_reduce_before_fusion): the text bank, zero-padded to
+        the phrase-bank size (:304-327 with text_feature_bank + text_feature_bank_reset), is FUSED with the vision
+        tokens in the encoder and the fused tokens are the classifier's vocabulary (:356-358, 448)."""
         S = self.stages = {}
         images, img_mask, (h, w) = self.preprocess(image)
         height = height or h
         width = width or w
         features_l = text_feats.float()[None]                       # [1,K,1024]  (:279-280)
-        fusion = self.p("name_prompt_fusion_feature").repeat(1, 1, 1)  # zeros [1,1,1024] (:349-352)
+        if prompt == "name":
+            fusion = self.p("name_prompt_fusion_feature").repeat(1, 1, 1)  # zeros [1,1,1024] (:349-352)
+        else:
+            K = text_feats.shape[0]
+            bank = torch.cat([text_feats.float(), torch.zeros(phrase_bank, text_feats.shape[1])], 0)[: max(K, phrase_bank)]
+            features_l = bank[None]                                  # (:321-335)
+            fusion = features_l + 0.0 * self.p("name_prompt_fusion_feature")   # (:357-360)
         feat = self.vit(images)
         S["last_feat"] = feat
         fpn = self.fpn(feat)
@@ -535,7 +545,10 @@ class ApeOracle:
         S["inter_states"], S["inter_references"], S["init_reference"] = inter, inter_ref, init_ref
         mask_feat = self.mask_features(memory, fpn["p2"], spatial_shapes)
         S["mask_features"] = mask_feat
-        features_l = 1.0 * features_l + 0.0 * l_out                  # (:446)
+        if prompt == "name":
+            features_l = 1.0 * features_l + 0.0 * l_out              # (:446)
+        else:
+            features_l = 0.0 * features_l + 1.0 * l_out              # (:448)
         lvl = self.dec_layers - 1                                   # only the last level is consumed (:519-524)
         reference = tp.inverse_sigmoid(init_ref if lvl == 0 else inter_ref[lvl - 1])
         logits = self.vl_align(inter[lvl], features_l, f"class_embed.{lvl}")

@@ -39,8 +39,9 @@ def spec_of(model):
     return [(k, list(v.shape)) for k, v in model.state_dict().items()]
 
 
-def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True):
-    """returns (stages dict, instances dict, spec)"""
+def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name"):
+    """returns (stages dict, instances dict, spec).  prompt="phrase": class names with a space, which the reference
+    routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337)."""
     cfg = CONFIGS[cfg_name]
     model = ref_model.build_reference(cfg, text_feats)
     spec = spec_of(model)
@@ -101,7 +102,7 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
     try:
         h, w = image.shape[-2:]
         inputs = {"image": image, "height": height or h, "width": width or w, "prompt": "text",
-                  "text_prompt": ",".join(f"c{i}" for i in range(text_feats.shape[0]))}
+                  "text_prompt": ",".join((f"c {i}" if prompt == "phrase" else f"c{i}") for i in range(text_feats.shape[0]))}
         with torch.no_grad():
             out = model([inputs])[0]
     finally:

@@ -23,13 +23,15 @@ CASES = {
     "tiny_square": ("tiny", 0, 2, (256, 256), 10, 3),
     "tiny_padded": ("tiny", 1, 5, (200, 144), 7, 6),
     "small_padded": ("small", 0, 2, (384, 512), 10, 3),
+    # phrase prompt: the 6 class tokens + 250 zero bank slots are fused densely with the vision tokens
+    "tiny_phrase": ("tiny", 2, 7, (224, 256), 6, 8, "phrase"),
 }
 FULL = ("pred_logits", "pred_boxes", "topk_proposals", "det_boxes", "det_scores", "det_classes", "det_query",
         "init_reference", "enc_class")
 
 
 def make_inputs(case):
-    cfg, wseed, iseed, (h, w), K, tseed = CASES[case]
+    cfg, wseed, iseed, (h, w), K, tseed = CASES[case][:6]
     image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
     text = torch.randn(K, 1024, generator=torch.Generator().manual_seed(tseed))
     return cfg, wseed, image, text
@@ -48,9 +50,13 @@ def fingerprint(t, nsamp=512):
 
 def main():
     torch.set_num_threads(8)
+    only = sys.argv[1:]                      # optional: regenerate just the named cases
     for case in CASES:
+        if only and case not in only:
+            continue
         cfg, wseed, image, text = make_inputs(case)
-        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text)
+        prompt = CASES[case][6] if len(CASES[case]) > 6 else "name"
+        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt)
         with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
             json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
@@ -64,6 +70,8 @@ def main():
                              "mask_rowsum0": inst["pred_masks"][0].sum(1) if len(inst["pred_masks"]) else None}
         torch.save(gold, os.path.join(HERE, f"ref_{case}.pt"))
         print(case, "->", len(gold["stages"]), "stages,", len(inst["scores"]), "instances")
+    if only:
+        return
     # checkpoint-key contract of the full-size model (no forward: 1-2 min/image on CPU)
     m = ref_model.build_reference(CONFIGS["L_D"], torch.zeros(1, 1024))
     with open(os.path.join(HERE, "state_spec_L_D.json"), "w") as fh:

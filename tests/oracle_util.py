@@ -17,10 +17,14 @@ def load_golden(case):
 
 
 def case_inputs(gold):
-    cfg, wseed, iseed, (h, w), K, tseed = gold["case"]
+    cfg, wseed, iseed, (h, w), K, tseed = gold["case"][:6]
     image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
     text = torch.randn(K, 1024, generator=torch.Generator().manual_seed(tseed))
     return cfg, wseed, image, text
+
+
+def case_prompt(gold):
+    return gold["case"][6] if len(gold["case"]) > 6 else "name"
 
 
 def relerr(a, b):

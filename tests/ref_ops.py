@@ -279,6 +279,27 @@ def vl_pool(scores, x):
     return wl.t() @ x.float()
 
 
+def segment_softmax(scores, nseg, gmax, out_dtype):
+    T, C = scores.shape
+    w = (scores.float() - gmax.float()).clamp(-50000, 50000).reshape(T, nseg, C // nseg)
+    return w.softmax(dim=-1).reshape(T, C).to(out_dtype)
+
+
+def _pad_cols(t, pad):
+    extra = (-t.shape[1]) % pad
+    return F.pad(t, (0, extra)).contiguous() if extra else t.contiguous()
+
+
+def col_softmax_t(scores, gmax, out_dtype, pad=1):
+    w = (scores.float() - gmax.float()).clamp(-50000, 50000)
+    wl = (w - w.max(dim=0, keepdim=True)[0]).clamp(-50000, 50000).softmax(dim=0)
+    return _pad_cols(wl.t().to(out_dtype), pad)
+
+
+def transpose(x, out_dtype=None, pad=1):
+    return _pad_cols(x.t().to(out_dtype or x.dtype), pad)
+
+
 def mask_upsample_bits(logits, h0, w0, size):
     n = logits.shape[0]
     up = F.interpolate(logits.float().reshape(1, n, h0, w0), size=(size, size), mode="bilinear", align_corners=False)[0]

@@ -22,13 +22,14 @@ def test_state_dict_contract_full_size():
     assert not bad, bad[:5]
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "tiny_phrase"])
 def test_fp32_host_pipeline_matches_oracle(fake_ops, case):
     model, orc, image, text, gold = M.build_pair(case)
+    prompt = U.case_prompt(gold)           # tiny_phrase: dense multi-token fusion, fused tokens are the vocabulary
     mv = model.model_vision
     stages = {}
-    mv.forward_single(image, text, stages=stages)
-    orc.forward(image, text)
+    mv.forward_single(image, text, stages=stages, prompt=prompt)
+    orc.forward(image, text, prompt=prompt)
     O = orc.stages
     for k in ("p2", "p3", "p4", "p5", "p6", "enc0_fused_v", "enc0_fused_l", "enc1_out", "memory", "query_l", "output_memory",
               "enc_class", "enc_coord_unact"):
@@ -39,13 +40,13 @@ def test_fp32_host_pipeline_matches_oracle(fake_ops, case):
     assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
     ref_topk = gold["full"]["topk_proposals"][0]
     stages = {}
-    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages, prompt=prompt)
     assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance
     assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
     frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
                               gold["full"]["det_scores"], gold["full"]["det_classes"])
     assert frac >= 0.97
-    orc.forward(image, text, forced_topk=ref_topk[None])
+    orc.forward(image, text, forced_topk=ref_topk[None], prompt=prompt)
     ours = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(out["det_query"], out["det_classes"]))}
     pairs = [(ours[(int(q), int(c))], j) for j, (q, c) in enumerate(zip(orc.stages["det_query"], orc.stages["det_classes"]))
              if (int(q), int(c)) in ours]

@@ -13,14 +13,15 @@ def _run(case, dtype):
     return model, orc, image.cuda(), text.cuda(), gold, image, text
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase"])
 def test_fp32_pipeline_matches_oracle_and_reference(case):
     """T1: every HIP kernel in its fp32 instantiation; tolerance = north_star's 1e-3 on logits / boxes"""
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.float32)
+    prompt = U.case_prompt(gold)           # tiny_phrase: dense multi-token fusion (phrase / expression prompts)
     mv = model.model_vision
     stages = {}
-    mv.forward_single(image, text, stages=stages)
-    orc.forward(image_c, text_c)
+    mv.forward_single(image, text, stages=stages, prompt=prompt)
+    orc.forward(image_c, text_c, prompt=prompt)
     O = orc.stages
     for k in ("p2", "p4", "p6", "enc0_fused_v", "enc0_fused_l", "memory", "query_l", "output_memory", "enc_class", "enc_coord_unact"):
         b = M.token_major(k, O[k])
@@ -32,7 +33,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
     assert ov >= 0.99
     ref_topk = gold["full"]["topk_proposals"][0]
     stages = {}
-    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages)
+    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages, prompt=prompt)
     el = U.relerr(stages["pred_logits"].cpu(), gold["full"]["pred_logits"][0])
     eb = U.relerr(stages["pred_boxes"].cpu(), gold["full"]["pred_boxes"][0])
     print(f"[fp32 {case}] pred_logits {el:.2e} pred_boxes {eb:.2e} (vs reference fixture)")
@@ -41,7 +42,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
                               gold["full"]["det_boxes"], gold["full"]["det_scores"], gold["full"]["det_classes"])
     print(f"[fp32 {case}] detections reproduced: {frac:.3f}")
     assert frac >= 0.97
-    orc.forward(image_c, text_c, forced_topk=ref_topk[None])
+    orc.forward(image_c, text_c, forced_topk=ref_topk[None], prompt=prompt)
     # masks are compared per (query, class) pair: two detections with near-equal scores may swap places
     ours = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(out["det_query"].cpu(), out["det_classes"].cpu()))}
     pairs = [(ours[(int(q), int(c))], j) for j, (q, c) in enumerate(zip(orc.stages["det_query"], orc.stages["det_classes"]))
@@ -54,7 +55,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
     assert mm < 2e-3
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "small_padded"])
+@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase"])
 def test_bf16_pipeline(case):
     """T2/T3: bf16 storage + MFMA, fp32 accumulate.  Checked against (a) the same pipeline evaluated with the torch
     definitions at the same rounding points and (b) the fp32 oracle (reported; the reference's own bf16 run is ~1e-2
@@ -62,9 +63,10 @@ def test_bf16_pipeline(case):
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.bfloat16)
     mv = model.model_vision
     ref_topk = gold["full"]["topk_proposals"][0]
+    prompt = U.case_prompt(gold)
     stages = {}
-    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages)
-    orc.forward(image_c, text_c, forced_topk=ref_topk[None])
+    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages, prompt=prompt)
+    orc.forward(image_c, text_c, forced_topk=ref_topk[None], prompt=prompt)
     O = orc.stages
     errs = {}
     for k in ("p2", "p6", "memory", "enc_class", "pred_logits", "pred_boxes"):
@@ -81,7 +83,7 @@ def test_bf16_pipeline(case):
             setattr(ops, n, getattr(ref_ops, n))
         model_c, _, _, _, _ = M.build_pair(case, device="cpu", dtype=torch.bfloat16)
         st_c = {}
-        model_c.model_vision.forward_single(image_c, text_c, forced_topk=ref_topk, stages=st_c)
+        model_c.model_vision.forward_single(image_c, text_c, forced_topk=ref_topk, stages=st_c, prompt=prompt)
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
@@ -99,3 +101,22 @@ def test_forward_api_on_gpu():
     frac = U.match_detections(res.pred_boxes, res.scores, res.pred_classes, oi["pred_boxes"], oi["scores"], oi["pred_classes"])
     assert frac >= 0.95 and res.pred_masks.shape[1:] == (2 * h, 2 * w)
     assert not res.pred_boxes.is_cuda
+
+
+def test_phrase_prompt_through_graph_runtime():
+    """phrase prompt (dense fusion) through the reference entry point and through the hipGraph runtime: same detections"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_phrase", torch.float32)
+    h, w = image_c.shape[-2:]
+    res = model([{"image": image_c, "height": h, "width": w, "text_features": text_c, "prompt": "phrase"}])[0]["instances"]
+    oi = orc.forward(image_c, text_c, prompt="phrase")["instances"]
+    frac = U.match_detections(res.pred_boxes, res.scores, res.pred_classes, oi["pred_boxes"], oi["scores"], oi["pred_classes"])
+    print(f"[phrase] forward() vs oracle instances: {frac:.3f}")
+    assert frac >= 0.95
+    run = GraphedForward(model.model_vision)
+    for _ in range(2):                       # second call replays the captured graph
+        inst, _ = run(image, text, prompt="phrase")
+    frac = U.match_detections(inst.pred_boxes, inst.scores, inst.pred_classes, res.pred_boxes, res.scores, res.pred_classes)
+    print(f"[phrase] graph replay vs eager: {frac:.3f}")
+    assert frac >= 0.99

@@ -358,6 +358,32 @@ def test_vl_pool(ops, dt):
     assert e < 2e-5
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("T,L", [(341, 9), (5456, 256), (1000, 300)])
+def test_dense_fusion_softmaxes(ops, dt, T, L):
+    """segment_softmax / col_softmax_t / transpose (csrc/softmax.hip) vs fuse_helper.py:89-131 in torch"""
+    nh = 8
+    S = rnd(T, nh * L, seed=3) * 4.0
+    S[0, 0] = -80000.0                       # exercises the +-5e4 clamp after the global-max subtraction
+    gmax = S.max().reshape(1)
+    pv = ops.segment_softmax(S, nh, gmax, dt)
+    ref = ref_ops.segment_softmax(S, nh, gmax, torch.float32)
+    e1 = relerr(pv, ref)
+    assert pv.shape == (T, nh * L) and pv.dtype == dt
+    assert (pv.float().reshape(T, nh, L).sum(-1) - 1).abs().max().item() < (2e-2 if dt == torch.bfloat16 else 1e-5)
+    pl = ops.col_softmax_t(S, gmax, dt, pad=8)
+    refl = ref_ops.col_softmax_t(S, gmax, torch.float32, pad=8)
+    e2 = relerr(pl, refl)
+    Tp = (T + 7) // 8 * 8
+    assert pl.shape == (nh * L, Tp) and pl.dtype == dt and (pl[:, T:] == 0).all()
+    x = rnd(T, 256, dtype=dt, seed=4)
+    xt = ops.transpose(x, pad=8)
+    assert xt.shape == (256, Tp) and torch.equal(xt[:, :T].cpu(), x.t().cpu()) and (xt[:, T:] == 0).all()
+    print(f"dense fusion softmaxes {dt} T={T} L={L}: vision {e1:.2e} language {e2:.2e}")
+    tol = 5e-3 if dt == torch.bfloat16 else 1e-4          # device expf vs libm over a 5456-term online sum
+    assert e1 < tol and e2 < tol
+
+
 def test_mask_postprocess(ops):
     n, h0, S = 7, 64, 256
     logits = rnd(n, h0 * h0, seed=1)

@@ -13,14 +13,15 @@ from oracle.configs import CONFIGS
 FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order)
 
 
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded"])
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
     sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
     orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
     ref_topk = gold["full"]["topk_proposals"]
-    out = orc.forward(image, text)
+    prompt = U.case_prompt(gold)
+    out = orc.forward(image, text, prompt=prompt)
     S = orc.stages
     # stages upstream of the proposal selection: elementwise
     upstream = [k for k in gold["stages"] if k.startswith(("vit_block", "last_feat", "p", "enc", "memory", "query_l",
@@ -31,7 +32,7 @@ def test_oracle_matches_reference_golden(case):
     # the selected proposals: same SET (near-equal scores may swap places between two fp32 implementations)
     assert set(S["topk_proposals"][0].tolist()) == set(ref_topk[0].tolist())
     # downstream with the reference's proposal order injected
-    out = orc.forward(image, text, forced_topk=ref_topk)
+    out = orc.forward(image, text, forced_topk=ref_topk, prompt=prompt)
     S = orc.stages
     for k in ("query_init", "query_pos", "init_reference", "inter_states", "inter_references", "pred_masks"):
         U.check_fingerprint(S[k], gold["stages"][k], 5e-4, k)

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--k", type=int, default=80)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--prompt", default="name")
     args = ap.parse_args()
     t0 = time.time()
     model = init_synthetic(build_ape(args.size), 0).cuda()
@@ -28,10 +29,21 @@ def main():
     for it in range(args.iters):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = mv.forward_single(image, text)
+        out = mv.forward_single(image, text, prompt=args.prompt)
         res = mv.postprocess_instance(out, (S, S), S, S)
         torch.cuda.synchronize()
         print(f"iter {it}: {1e3 * (time.perf_counter() - t0):.1f} ms  ({len(res.scores)} instances)", flush=True)
+    from ape_amd.runtime import GraphedForward
+    run = GraphedForward(mv)
+    for it in range(args.iters):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        inst, _ = run(image, text, prompt=args.prompt)
+        torch.cuda.synchronize()
+        print(f"graphed iter {it}: {1e3 * (time.perf_counter() - t0):.1f} ms  ({len(inst.scores)} instances)", flush=True)
+    print("peak mem GB", torch.cuda.max_memory_allocated() / 1e9)
+    if args.prompt != "name":
+        return
     # per-stage timing (synchronised between stages)
     import ape_amd.modeling.ape_deta.deformable_detr_segm_vl as mod
     torch.cuda.synchronize()
