@@ -176,3 +176,89 @@ extern "C" int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxe
   APE_CHECK_LAUNCH("ape_hip_paste_bits");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Semantic branch (deformable_detr_segm_vl.py:628-666, 875-918): sem[c, y, x] = sum_q P[q, c] * sigmoid(up(mask_q))(y, x).
+//   mask_upsample_sigmoid : pixel-major probabilities  out[(y, x), q] = sigmoid(bilinear_up(logits)[q, y, x])  for the
+//                           un-padded image region only (sem_seg_postprocess crops the padding away, so those pixels are
+//                           never produced).  Input logits are pixel-major [h0*w0, n] (the mask GEMM writes them that
+//                           way), so the 4 taps of a pixel are contiguous n-vectors.  The einsum is then ONE GEMM
+//                           [K, n] x [n, h*w] through ape_hip_gemm.
+//   bilinear_resize       : F.interpolate(bilinear, align_corners=False) of the [C, h, w] result to the output size
+// ---------------------------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void mask_upsample_sigmoid_kernel(const TI* __restrict__ logits, int ldl, int h0, int w0, int S,
+                                                                    int ch, int cw, int n, TO* __restrict__ out, int ldo) {
+  const int ng = (n + 3) / 4;
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)ch * cw * ng) return;
+  const int g = (int)(gid % ng);
+  const size_t pix = gid / ng;
+  const int x = (int)(pix % cw), y = (int)(pix / cw);
+  const float sy = (float)h0 / (float)S, sx = (float)w0 / (float)S;
+  float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy; y0 = y0 < h0 - 1 ? y0 : h0 - 1;
+  int x0 = (int)fx; x0 = x0 < w0 - 1 ? x0 : w0 - 1;
+  const int y1 = y0 + (y0 < h0 - 1 ? 1 : 0), x1 = x0 + (x0 < w0 - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const TI* p00 = logits + ((size_t)y0 * w0 + x0) * ldl;
+  const TI* p01 = logits + ((size_t)y0 * w0 + x1) * ldl;
+  const TI* p10 = logits + ((size_t)y1 * w0 + x0) * ldl;
+  const TI* p11 = logits + ((size_t)y1 * w0 + x1) * ldl;
+  TO* o = out + pix * ldo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = g * 4 + i;
+    if (q < n) {
+      const float v = (1.f - ly) * ((1.f - lx) * ldf<TI>(p00 + q) + lx * ldf<TI>(p01 + q)) +
+                      ly * ((1.f - lx) * ldf<TI>(p10 + q) + lx * ldf<TI>(p11 + q));
+      stf<TO>(o + q, 1.f / (1.f + expf(-v)));
+    }
+  }
+}
+
+extern "C" int ape_hip_mask_upsample_sigmoid(const void* logits, int ldl, int in_dt, int h0, int w0, int S, int crop_h, int crop_w,
+                                             int n, void* out, int ldo, int out_dt, void* stream) {
+  APE_CHECK_ARG(logits && out && h0 > 0 && w0 > 0 && S > 0 && n > 0 && crop_h > 0 && crop_w > 0 && crop_h <= S && crop_w <= S,
+                "ape_hip_mask_upsample_sigmoid: bad args");
+  const size_t total = (size_t)crop_h * crop_w * ((n + 3) / 4);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (in_dt * 2 + out_dt) {
+    case 0: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, float>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); break;
+    case 1: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, bf16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); break;
+    case 2: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); break;
+    case 3: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); break;
+    default: ape_set_error("ape_hip_mask_upsample_sigmoid: bad dtypes"); return -1;
+  }
+  APE_CHECK_LAUNCH("ape_hip_mask_upsample_sigmoid");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void bilinear_resize_kernel(const float* __restrict__ in, int ldc, int ldr, int h, int w, int C,
+                                                              float* __restrict__ out, int H, int W) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)C * H * W) return;
+  const int x = (int)(gid % W), y = (int)((gid / W) % H), c = (int)(gid / ((size_t)W * H));
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy; y0 = y0 < h - 1 ? y0 : h - 1;
+  int x0 = (int)fx; x0 = x0 < w - 1 ? x0 : w - 1;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float* p = in + (size_t)c * ldc;
+  out[gid] = (1.f - ly) * ((1.f - lx) * p[(size_t)y0 * ldr + x0] + lx * p[(size_t)y0 * ldr + x1]) +
+             ly * ((1.f - lx) * p[(size_t)y1 * ldr + x0] + lx * p[(size_t)y1 * ldr + x1]);
+}
+
+extern "C" int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, int w, int C, float* out, int H, int W,
+                                       void* stream) {
+  APE_CHECK_ARG(in && out && h > 0 && w > 0 && C > 0 && H > 0 && W > 0, "ape_hip_bilinear_resize: bad args");
+  const size_t total = (size_t)C * H * W;
+  hipLaunchKernelGGL(bilinear_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ld_channel,
+                     ld_row, h, w, C, out, H, W);
+  APE_CHECK_LAUNCH("ape_hip_bilinear_resize");
+  return 0;
+}

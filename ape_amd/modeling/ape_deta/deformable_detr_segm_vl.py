@@ -84,6 +84,11 @@ class DeformableDETRSegmVL(nn.Module):
         self._mean, self._std = tuple(float(v) for v in pixel_mean), tuple(float(v) for v in pixel_std)
         self.dataset_names, self.dataset_prompts = dataset_names, dataset_prompts
         self.dataset_metas = [dataset_metas] if isinstance(dataset_metas, str) else list(dataset_metas)
+        # MetadataCatalog stand-in (deformable_detr.py:238-272): entries of dataset_metas may be names (resolved through
+        # detectron2 when it is importable) or dicts carrying thing_classes / stuff_classes themselves
+        self.metadata_list = [self._resolve_metadata(m) for m in self.dataset_metas]
+        self.dataset_entities = [self._entity_of(m) for m in self.metadata_list]
+        self.stuff_prob_thing, self.semantic_post_nms = stuff_prob_thing, semantic_post_nms
         self.dataset_name_to_idx = {k: i for i, k in enumerate(self.dataset_names)}
         self.class_names = {}                       # dataset name -> list[str]; filled by set_class_names (MetadataCatalog stand-in)
         self.eval_dataset_id, self.eval_dataset_entity = -1, ""
@@ -136,13 +141,45 @@ class DeformableDETRSegmVL(nn.Module):
     def set_model_language(self, model_language):
         self.model_language = model_language
 
+    @staticmethod
+    def _resolve_metadata(meta):
+        if isinstance(meta, dict):
+            return dict(meta)
+        try:
+            from detectron2.data.catalog import MetadataCatalog
+            m = MetadataCatalog.get(meta)
+            return {k: m.get(k) for k in ("thing_classes", "stuff_classes", "thing_dataset_id_to_contiguous_id") if m.get(k) is not None} | {"name": meta}
+        except ImportError:
+            return {"name": str(meta)}
+
+    @staticmethod
+    def _entity_of(meta):
+        """deformable_detr.py:247-262"""
+        if "stuffonly" in meta.get("name", ""):
+            meta.pop("thing_classes", None)
+        thing, stuff = meta.get("thing_classes"), meta.get("stuff_classes")
+        if thing is not None and stuff is not None:
+            return "thing+stuff"
+        return "stuff" if (thing is None and stuff is not None) else "thing"
+
+    def set_metadata(self, dataset_id, **meta):
+        """attach thing_classes / stuff_classes / thing_dataset_id_to_contiguous_id to a dataset slot"""
+        while len(self.metadata_list) <= dataset_id:
+            self.metadata_list.append({"name": ""})
+            self.dataset_entities.append("thing")
+        self.metadata_list[dataset_id].update(meta)
+        self.dataset_entities[dataset_id] = self._entity_of(self.metadata_list[dataset_id])
+
     def set_eval_dataset(self, dataset_name):
+        """deformable_detr.py:524-532"""
         for d in self.dataset_names:
             if sum([dd in dataset_name for dd in d.split("+")]):
                 self.eval_dataset_id = self.dataset_name_to_idx[d]
+                self.eval_dataset_entity = self.dataset_entities[self.eval_dataset_id] if self.eval_dataset_id < len(self.dataset_entities) else ""
                 break
         else:
             self.eval_dataset_id = -1
+            self.eval_dataset_entity = ""
 
     def set_class_names(self, dataset_id, names):
         self.class_names[dataset_id] = list(names)
@@ -227,8 +264,11 @@ class DeformableDETRSegmVL(nn.Module):
         return self._text[key]
 
     # ------------------------------------------------------------------ the hot path, one image
-    def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name"):
-        """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes)."""
+    def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
+                       semantic=None, detector_columns=None):
+        """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
+        instance: run the detection branch; semantic: metadata dict (entity, thing_classes, stuff_classes) to run the
+        semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes."""
         dt = self.compute_dtype
         P = self.packed(dt)
         h, w = image.shape[-2:]
@@ -262,9 +302,20 @@ class DeformableDETRSegmVL(nn.Module):
         logits = self.class_embed[lvl].forward_tokens(x, tok, cbias, inv_scale)                       # [Q,K] fp32
         boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
         out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
-        det = self.inference_single(logits, boxes, (h, w), geo.box_scale)
-        out.update(det)
-        if with_masks and self.test_mask_on:
+        det = {}
+        if instance:
+            det_logits = logits
+            if detector_columns is not None:                 # (:578-590) thing columns only
+                kind, arg = detector_columns
+                if kind == "first":
+                    det_logits = logits[:, :arg].contiguous()
+                else:
+                    det_logits = torch.full_like(logits, float("-inf"))
+                    det_logits[:, arg] = logits[:, arg]
+            det = self.inference_single(det_logits, boxes, (h, w), geo.box_scale)
+            out.update(det)
+        want_masks = instance and with_masks and self.test_mask_on
+        if want_masks or semantic is not None:
             # maskdino_mask_features (:728-750): lateral 1x1 + GN, + encoder memory of level 0, 3x3 + GN + ReLU, 1x1
             H0, W0 = geo.shapes[0]
             p2 = maps[self.mask_in_features[0]][0]
@@ -274,6 +325,12 @@ class DeformableDETRSegmVL(nn.Module):
             y = ops.groupnorm(y, P["outc"][1], P["outc"][2], P["outc"][3], P["outc"][4], act=ops.ACT_RELU)
             mask_feat = ops.gemm(y, P["maskc"], None)                                                 # [H0*W0, 256]
             membed = self.mask_embed.forward_tokens(x, dt, out_dtype=dt)                              # [Q,256]
+            if stages is not None:
+                stages.update(mask_features=mask_feat, mask_embed=membed)
+        if semantic is not None:
+            out["sem_seg"] = self.semantic_single(logits, boxes, membed, mask_feat, geo, (h, w), semantic, dt, stages)
+        if want_masks:
+            H0, W0 = geo.shapes[0]
             # only the kept queries are decoded / upsampled: the einsum (:510) and F.interpolate (:569-572) act per query
             kept = ops.gather_rows(membed, det["det_query"].to(torch.int32))
             mlog = ops.gemm(kept, mask_feat, None, out_dtype=torch.float32)                           # [n, H0*W0]
@@ -281,12 +338,52 @@ class DeformableDETRSegmVL(nn.Module):
             bits = ops.mask_upsample_bits(mlog, H0, W0, S)
             out["det_masks128"] = ops.roi_align_bits(bits, det["det_boxes"].contiguous(), 128)
             if stages is not None:
-                stages.update(mask_features=mask_feat, mask_embed=membed, det_mask_logits=mlog)
+                stages.update(det_mask_logits=mlog)
         if stages is not None:
             stages.update(pred_logits=logits, pred_boxes=boxes, inter_states=torch.stack(tr["inter_states"])[:, None],
                           inter_references=torch.stack(tr["inter_references"])[:, None], **det)
         self.postprocess_time = time.perf_counter() - t0
         return out
+
+    @staticmethod
+    def stuff_score(logits, meta):
+        """get_stuff_score (deformable_detr_segm_vl.py:1251-1271): with a leading "things" stuff class, the thing columns
+        collapse into one (their minimum)."""
+        thing, stuff, entity = meta.get("thing_classes") or [], meta.get("stuff_classes") or [], meta["entity"]
+        overlap = len(thing) > 0 and len(stuff) > 0 and (set(thing) <= set(stuff) or set(stuff) <= set(thing))
+        if entity == "thing+stuff" and stuff[0] == "things" and not overlap:
+            nt = len(thing)
+            return torch.cat([logits[:, :nt].min(dim=1, keepdim=True)[0], logits[:, nt:]], dim=1).contiguous()
+        return logits
+
+    def semantic_single(self, logits, boxes, membed, mask_feat, geo, image_size, meta, dt, stages=None, pano_temp=0.06):
+        """semantic branch for one image (:628-666 + _postprocess_semantic :875-918) -> [K', h, w] fp32 at the
+        un-padded input resolution (the crop of sem_seg_postprocess is fused: padded pixels are never produced).
+        The kept (query) set comes from a second class-wise NMS on the stuff scores; the einsum over the kept queries
+        is one GEMM against pixel-major sigmoid(upsampled mask) probabilities."""
+        h, w = image_size
+        sem_logits = self.stuff_score(logits, meta)
+        if self.semantic_post_nms:
+            sdet = self.inference_single(sem_logits, boxes, image_size, geo.box_scale)
+            qidx, valid = sdet["det_query"], sdet["det_scores"] >= 0
+        else:
+            qidx = torch.arange(logits.shape[0], device=logits.device)
+            valid = torch.ones_like(qidx, dtype=torch.bool)
+        k = qidx.numel()
+        kp = (k + 7) // 8 * 8
+        cls = torch.softmax(sem_logits[qidx].sigmoid() / pano_temp, dim=-1) * valid[:, None]           # [k, K']  (:891-894)
+        A = torch.zeros((cls.shape[1], kp), dtype=dt, device=cls.device)
+        A[:, :k] = cls.t()
+        kept = torch.zeros((kp, membed.shape[1]), dtype=dt, device=cls.device)
+        kept[:k] = ops.gather_rows(membed, qidx.to(torch.int32))
+        H0, W0 = geo.shapes[0]
+        S = self.backbone.padding_constraints.get("square_size", 0)
+        mlog_t = ops.gemm(mask_feat, kept, None, out_dtype=torch.float32)                               # [H0*W0, kp] pixel-major
+        prob = ops.mask_upsample_sigmoid(mlog_t, H0, W0, S, h, w, dt)                                   # [h*w, kp]   (:569-572, 895)
+        sem = ops.gemm(A, prob, None, out_dtype=torch.float32)                                          # [K', h*w]   (:899)
+        if stages is not None:
+            stages.update(sem_box_cls=sem_logits, sem_query=qidx, sem_valid=valid)
+        return sem.view(-1, h, w)
 
     def inference_single(self, logits, boxes, image_size, scale=None):
         """sigmoid scores, cxcywh -> xyxy * (w,h,w,h), clip, score threshold, class-wise NMS, top-k
@@ -319,17 +416,44 @@ class DeformableDETRSegmVL(nn.Module):
     def forward(self, batched_inputs, do_postprocess=True):
         if self.training:
             raise NotImplementedError("ape_amd implements the inference forward only")
-        if self.semantic_on or self.panoptic_on:
-            raise NotImplementedError("ape_amd: semantic / panoptic tails are not implemented yet (instance branch only)")
+        entity, dataset_id = self.eval_dataset_entity, self.eval_dataset_id
+        if self.panoptic_on and not (entity and "thing+stuff" not in entity):
+            raise NotImplementedError("ape_amd: the panoptic tail is not implemented (instance and semantic branches are)")
+        do_inst = self.instance_on and not (entity and "thing" not in entity)              # (:575-577)
+        do_sem = self.semantic_on and not (entity and "stuff" not in entity)               # (:628-630)
+        meta = None
+        if do_sem:
+            if not self.metadata_list:
+                raise RuntimeError("ape_amd: semantic_on needs dataset metadata (dataset_metas dicts or set_metadata)")
+            meta = dict(self.metadata_list[dataset_id], entity=self.dataset_entities[dataset_id])   # [-1] like the reference
+        cols = None
+        if do_inst and 0 <= dataset_id < len(self.metadata_list):                          # (:578-590)
+            m = self.metadata_list[dataset_id]
+            thing, stuff = m.get("thing_classes") or [], m.get("stuff_classes") or []
+            if thing and stuff and (set(thing) <= set(stuff) or set(stuff) <= set(thing)):
+                ids = list((m.get("thing_dataset_id_to_contiguous_id") or {}).values())
+                cols = ("ids", torch.tensor(ids, dtype=torch.long, device=self.device))
+            elif thing:
+                cols = ("first", len(thing))
         results = []
         for inp in batched_inputs:
             t0 = time.perf_counter()
             image = inp["image"].to(self.device, non_blocking=True).float()
             feats, _, prompt = self.text_features(inp)
             self.preprocess_time = time.perf_counter() - t0
-            out = self.forward_single(image, feats, prompt=prompt)
+            out = self.forward_single(image, feats, prompt=prompt, instance=do_inst, semantic=meta, detector_columns=cols)
             h, w = image.shape[-2:]
-            results.append({"instances": self.postprocess_instance(out, (h, w), inp.get("height", h), inp.get("width", w))})
+            height, width = inp.get("height", h), inp.get("width", w)
+            res = {}
+            if do_inst:
+                res["instances"] = self.postprocess_instance(out, (h, w), height, width)
+            if do_sem:
+                r = ops.bilinear_resize(out["sem_seg"], height, width)                     # sem_seg_postprocess (:916)
+                if (dataset_id >= 0 and meta["entity"] == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
+                        and self.stuff_prob_thing > 0):                                    # (:654-663)
+                    r[0] = math.log(self.stuff_prob_thing / (1 - self.stuff_prob_thing))
+                res["sem_seg"] = r
+            results.append(res)
         return results
 
     def postprocess_instance(self, out, image_size, height, width):

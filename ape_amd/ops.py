@@ -467,3 +467,31 @@ def paste_bits(masks, boxes, ho, wo):
     rc = _lib.load().ape_hip_paste_bits(_p(_u8(masks, "masks")), P, _p(_boxes(boxes)), n, ho, wo, _p(out), _stream())
     _lib.check(rc, "ape_hip_paste_bits")
     return out
+
+
+def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):
+    """sigmoid of the bilinear (align_corners=False) upsample h0 x w0 -> size x size of PIXEL-MAJOR mask logits
+    [h0*w0, n], for the top-left crop_h x crop_w region only -> [crop_h*crop_w, n] (pixel-major probabilities)."""
+    _dev(logits_t)
+    _rowmajor(logits_t, "logits_t")
+    if logits_t.shape[0] != h0 * w0:
+        raise ValueError("ape_amd.ops.mask_upsample_sigmoid: logits_t must be [h0*w0, n]")
+    n = logits_t.shape[1]
+    out = torch.empty((crop_h * crop_w, n), dtype=out_dtype, device=logits_t.device)
+    rc = _lib.load().ape_hip_mask_upsample_sigmoid(_p(logits_t), _ld(logits_t), _dt(logits_t), h0, w0, size, crop_h, crop_w, n,
+                                                   _p(out), _ld(out), _dt(out), _stream())
+    _lib.check(rc, "ape_hip_mask_upsample_sigmoid")
+    return out
+
+
+def bilinear_resize(x, height, width):
+    """F.interpolate(x[None], (height, width), mode="bilinear", align_corners=False)[0] for fp32 x [C, h, w]
+    (rows contiguous; channel / row strides free)."""
+    _dev(x)
+    if x.dtype != torch.float32 or x.dim() != 3 or x.stride(2) != 1:
+        raise ValueError("ape_amd.ops.bilinear_resize: x must be float32 [C, h, w] with contiguous rows")
+    C, h, w = x.shape
+    out = torch.empty((C, height, width), dtype=torch.float32, device=x.device)
+    rc = _lib.load().ape_hip_bilinear_resize(_p(x), x.stride(0), x.stride(1), h, w, C, _p(out), height, width, _stream())
+    _lib.check(rc, "ape_hip_bilinear_resize")
+    return out

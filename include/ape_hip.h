@@ -238,6 +238,18 @@ int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, int h0, int 
 int ape_hip_roi_align_bits(const uint8_t* bits, int H, int W, const float* boxes, int n, int P, uint8_t* out, void* stream);
 int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxes, int n, int Ho, int Wo, uint8_t* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Semantic branch (deformable_detr_segm_vl.py:628-666, _postprocess_semantic :875-918) -- csrc/masks.hip
+ *   mask_upsample_sigmoid: out[(y,x), q] = sigmoid(bilinear_up(logits)[q, y, x]) for y < crop_h, x < crop_w of the
+ *                          S x S upsampled grid; logits are PIXEL-MAJOR [h0*w0, n].  einsum("qc,qhw->chw") is then one
+ *                          ape_hip_gemm of [K, n] x [crop_h*crop_w, n]^T.
+ *   bilinear_resize      : sem_seg_postprocess's F.interpolate(bilinear, align_corners=False) [C,h,w] -> [C,H,W] fp32
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_mask_upsample_sigmoid(const void* logits, int ldl, int in_dt, int h0, int w0, int S, int crop_h, int crop_w, int n,
+                                  void* out, int ldo, int out_dt, void* stream);
+int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, int w, int C, float* out, int H, int W,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

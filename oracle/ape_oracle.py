@@ -512,9 +512,40 @@ class ApeOracle:
     # --------------------------------------------------------------------------------------------
     # whole forward, "name" prompt mode (deformable_detr_segm_vl.py:166-726)
     # --------------------------------------------------------------------------------------------
+    # --------------------------------------------------------------------------------------------
+    # a22: semantic branch (deformable_detr_segm_vl.py:628-666, 875-918, 1251-1271)
+    # --------------------------------------------------------------------------------------------
+    @staticmethod
+    def stuff_score(box_cls, meta):
+        """get_stuff_score (:1251-1271).  meta: dict(entity, thing_classes, stuff_classes)."""
+        thing, stuff, entity = meta.get("thing_classes") or [], meta.get("stuff_classes") or [], meta["entity"]
+        sem = box_cls.clone()
+        if entity == "thing+stuff" and stuff[0] == "things":
+            nt = len(thing)
+            sem = torch.cat([box_cls[..., :nt].min(dim=-1, keepdim=True)[0], box_cls[..., nt:]], dim=-1)
+        overlap = len(thing) > 0 and len(stuff) > 0 and (set(thing) <= set(stuff) or set(stuff) <= set(thing))  # :1215-1226
+        if (entity == "thing+stuff" and overlap) or entity == "stuff":
+            sem = box_cls.clone()
+        return sem
+
+    def semantic_branch(self, logits, coord, pred_masks, padded_size, image_size, height, width, meta, pano_temp=0.06):
+        S = self.stages
+        sem_cls = self.stuff_score(logits, meta)
+        _, _, _, qidx = self.inference(sem_cls[0], coord[0], image_size)          # semantic_post_nms (:638-647)
+        S["sem_query"], S["sem_box_cls"] = qidx, sem_cls
+        up = F.interpolate(pred_masks[:, qidx], size=padded_size, mode="bilinear", align_corners=False)[0]   # (:569-572)
+        mask_cls = F.softmax(sem_cls[0][qidx].sigmoid() / pano_temp, dim=-1)      # (:891-894)
+        result = torch.einsum("qc,qhw->chw", mask_cls, up.sigmoid())              # (:895-899)
+        r = tp.sem_seg_postprocess(result, image_size, height, width)             # (:916)
+        if meta["entity"] == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things" and meta.get("stuff_prob_thing", -1.0) > 0 \
+                and meta.get("dataset_id", -1) >= 0:
+            p = meta["stuff_prob_thing"]
+            r[0, ...] = math.log(p / (1 - p))                                     # (:654-663)
+        return r
+
     @torch.no_grad()
     def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True, prompt="name",
-                phrase_bank=256):
+                phrase_bank=256, semantic=None):
         """prompt="phrase" (also "expression" with text_feature_reduce_before_fusion): the text bank, zero-padded to
         the phrase-bank size (:304-327 with text_feature_bank + text_feature_bank_reset), is FUSED with the vision
         tokens in the encoder and the fused tokens are the classifier's vocabulary (:356-358, 448)."""
@@ -568,4 +599,7 @@ class ApeOracle:
             S["det_masks128"] = masks128
         fb, fs, fc, fm, keep = tp.detector_postprocess(boxes, scores, classes, masks128, (h, w), height, width)
         out["instances"] = {"pred_boxes": fb, "scores": fs, "pred_classes": fc, "pred_masks": fm, "query_index": qidx[keep]}
+        if semantic is not None:
+            out["sem_seg"] = S["sem_seg"] = self.semantic_branch(logits, coord, pred_masks, images.shape[-2:], (h, w), height, width,
+                                                                 semantic)
         return out

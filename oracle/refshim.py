@@ -218,9 +218,14 @@ class _Metadata(dict):
             raise AttributeError(k)
 
 
+METADATA = {}     # name -> dict(thing_classes=..., stuff_classes=...): what MetadataCatalog.get(name) carries in a run
+
+
 class _MetadataCatalog:
     def get(self, name):
-        return _Metadata(name)
+        m = _Metadata(name)
+        m.update(METADATA.get(name, {}))
+        return m
 
 
 # --------------------------------------------------------------------------------- detrex stand-ins

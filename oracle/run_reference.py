@@ -39,11 +39,14 @@ def spec_of(model):
     return [(k, list(v.shape)) for k, v in model.state_dict().items()]
 
 
-def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name"):
+def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name", semantic=None):
     """returns (stages dict, instances dict, spec).  prompt="phrase": class names with a space, which the reference
     routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337)."""
     cfg = CONFIGS[cfg_name]
-    model = ref_model.build_reference(cfg, text_feats)
+    refshim.METADATA.clear()
+    if semantic is not None:        # semantic branch on: the (only) dataset's metadata carries the thing / stuff split
+        refshim.METADATA["coco_2017_val"] = {k: semantic[k] for k in ("thing_classes", "stuff_classes") if semantic.get(k)}
+    model = ref_model.build_reference(cfg, text_feats, semantic_on=semantic is not None)
     spec = spec_of(model)
     sd = weights.make_state_dict(spec, seed)
     weights.load_into(model, sd)
@@ -86,6 +89,10 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         return out
 
     def inf(box_cls, box_pred, image_sizes, use_sigmoid=True):
+        if "pred_logits" in S:      # second call = semantic_post_nms (:638-647)
+            res, filt = old_inf(box_cls, box_pred, image_sizes, use_sigmoid=use_sigmoid)
+            S["sem_box_cls"], S["sem_query"] = box_cls, filt[0]
+            return res, filt
         S["pred_logits"], S["pred_boxes"] = box_cls, box_pred
         res, filt = old_inf(box_cls, box_pred, image_sizes, use_sigmoid=use_sigmoid)
         S["det_boxes"], S["det_scores"] = res[0].pred_boxes.tensor, res[0].scores
@@ -110,6 +117,8 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         mv.maskdino_mask_features, mv.inference, smod.retry_if_cuda_oom = old_mf, old_inf, old_retry
         for hk in hooks:
             hk.remove()
+    if "sem_seg" in out:
+        S["sem_seg"] = out["sem_seg"]
     inst = out["instances"]
     instances = {"pred_boxes": inst.pred_boxes.tensor, "scores": inst.scores, "pred_classes": inst.pred_classes,
                  "pred_masks": inst.pred_masks if inst.has("pred_masks") else None}

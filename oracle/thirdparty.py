@@ -206,6 +206,13 @@ def paste_mask(mask, box, img_h, img_w, threshold=0.5):
     return out >= threshold
 
 
+def sem_seg_postprocess(result, image_size, output_height, output_width):
+    """detectron2.modeling.postprocessing.sem_seg_postprocess: crop the padding away, bilinear resize
+    (align_corners=False) to the output resolution.  result [C, H, W]."""
+    result = result[:, : image_size[0], : image_size[1]].expand(1, -1, -1, -1)
+    return F.interpolate(result, size=(output_height, output_width), mode="bilinear", align_corners=False)[0]
+
+
 def detector_postprocess(boxes, scores, classes, masks128, image_size, output_height, output_width, mask_threshold=0.5):
     """boxes [n,4] in the padded-input frame (image_size = (h,w) before padding); returns the rescaled / clipped /
     non-empty-filtered detections and the pasted masks [n', H, W] bool."""

@@ -25,7 +25,12 @@ CASES = {
     "small_padded": ("small", 0, 2, (384, 512), 10, 3),
     # phrase prompt: the 6 class tokens + 250 zero bank slots are fused densely with the vision tokens
     "tiny_phrase": ("tiny", 2, 7, (224, 256), 6, 8, "phrase"),
+    # semantic branch on (a22): 10 classes = 6 things + ("things", 4 stuff) -> 5 semantic channels; output resized x1.5
+    "tiny_semantic": ("tiny", 3, 9, (208, 240), 10, 4, "name", "semantic"),
 }
+SEMANTIC_META = {"entity": "thing+stuff", "thing_classes": [f"t{i}" for i in range(6)],
+                 "stuff_classes": ["things"] + [f"s{i}" for i in range(4)]}
+FULL_SEM = ("sem_seg", "sem_query", "sem_box_cls")
 FULL = ("pred_logits", "pred_boxes", "topk_proposals", "det_boxes", "det_scores", "det_classes", "det_query",
         "init_reference", "enc_class")
 
@@ -56,15 +61,21 @@ def main():
             continue
         cfg, wseed, image, text = make_inputs(case)
         prompt = CASES[case][6] if len(CASES[case]) > 6 else "name"
-        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt)
+        sem = SEMANTIC_META if len(CASES[case]) > 7 else None
+        h, w = image.shape[-2:]
+        out_hw = (int(1.5 * h), int(1.5 * w)) if sem else (None, None)
+        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt, semantic=sem, height=out_hw[0], width=out_hw[1])
         with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
             json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)
-                if k in FULL:
+                if k in FULL or (k in FULL_SEM and k != "sem_seg"):
                     gold["full"][k] = v.clone()
+        if sem:
+            gold["semantic_meta"], gold["out_hw"] = sem, out_hw
+            gold["full"]["sem_seg_argmax"] = S["sem_seg"].argmax(0).to(torch.uint8)      # [H, W] labels
         gold["instances"] = {"pred_boxes": inst["pred_boxes"], "scores": inst["scores"], "pred_classes": inst["pred_classes"],
                              "mask_area": inst["pred_masks"].flatten(1).sum(1), "mask_shape": list(inst["pred_masks"].shape),
                              "mask_rowsum0": inst["pred_masks"][0].sum(1) if len(inst["pred_masks"]) else None}

@@ -35,3 +35,35 @@ def token_major(k, t):
 def set_overlap(a, b):
     sa, sb = set(a.tolist()), set(b.tolist())
     return len(sa & sb) / max(len(sb), 1)
+
+
+def check_semantic(model, orc, image, text, gold, device, tol=1e-3):
+    """semantic branch of model.forward() vs the oracle and the reference-generated fixture (tests/golden/ref_tiny_semantic.pt)"""
+    mv = model.model_vision
+    meta = gold["semantic_meta"]
+    mv.semantic_on = True
+    mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
+    H, W = gold["out_hw"]
+    ref_topk = gold["full"]["topk_proposals"]
+    # teacher-forced proposals (same convention as the other parity tests): call the single-image path directly
+    sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    assert sem_meta["entity"] == "thing+stuff"
+    stages = {}
+    out = mv.forward_single(image.to(device), text.to(device), forced_topk=ref_topk[0].to(device), stages=stages, semantic=sem_meta)
+    import ape_amd.ops as ops
+    sem = ops.bilinear_resize(out["sem_seg"], H, W).cpu()
+    oo = orc.forward(image, text, forced_topk=ref_topk, semantic=meta, height=H, width=W)
+    assert tuple(sem.shape) == tuple(oo["sem_seg"].shape) == (5, H, W)
+    assert U.relerr(stages["sem_box_cls"].cpu(), gold["full"]["sem_box_cls"][0]) < tol
+    valid = stages["sem_valid"].cpu()
+    assert set(stages["sem_query"].cpu()[valid].tolist()) == set(gold["full"]["sem_query"].tolist())
+    e_or = U.relerr(sem, oo["sem_seg"])
+    U.check_fingerprint(sem, gold["stages"]["sem_seg"], tol, "sem_seg")
+    agree = (sem.argmax(0).to(torch.uint8) == gold["full"]["sem_seg_argmax"]).float().mean().item()
+    print(f"[semantic] vs oracle {e_or:.2e}; label agreement with the reference run {agree:.5f}")
+    assert e_or < tol and agree > 0.999
+    # and through the reference entry point (own proposal selection)
+    res = model([{"image": image, "height": H, "width": W, "text_features": text}])[0]
+    assert set(res) == {"instances", "sem_seg"} and tuple(res["sem_seg"].shape) == (5, H, W)
+    agree = (res["sem_seg"].argmax(0).cpu().to(torch.uint8) == gold["full"]["sem_seg_argmax"]).float().mean().item()
+    assert agree > 0.99, agree

@@ -317,3 +317,13 @@ def paste_bits(masks, boxes, ho, wo):
 
     out = [tp.paste_mask(masks[i].cpu().float(), boxes[i].cpu(), ho, wo).to(torch.uint8) for i in range(masks.shape[0])]
     return torch.stack(out).to(masks.device)
+
+
+def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):
+    n = logits_t.shape[1]
+    up = F.interpolate(logits_t.float().t().reshape(1, n, h0, w0), size=(size, size), mode="bilinear", align_corners=False)[0]
+    return up[:, :crop_h, :crop_w].sigmoid().reshape(n, -1).t().contiguous().to(out_dtype)
+
+
+def bilinear_resize(x, height, width):
+    return F.interpolate(x.float()[None], size=(height, width), mode="bilinear", align_corners=False)[0]

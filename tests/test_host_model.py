@@ -67,6 +67,12 @@ def test_forward_api_matches_oracle_instances(fake_ops):
     assert res.pred_masks.shape[1:] == (2 * h, 2 * w) and res.pred_masks.dtype == torch.bool
 
 
+def test_semantic_branch_matches_oracle_and_reference(fake_ops):
+    """a22 through the reference entry point (semantic_on, thing+stuff metadata with a leading "things" class)"""
+    model, orc, image, text, gold = M.build_pair("tiny_semantic")
+    M.check_semantic(model, orc, image, text, gold, "cpu")
+
+
 def test_bf16_host_pipeline_reported(fake_ops):
     """T3: bf16 storage at the kernels' rounding points vs the fp32 oracle -- reported, loose bound"""
     model, orc, image, text, gold = M.build_pair("tiny_padded", dtype=torch.bfloat16)

@@ -120,3 +120,9 @@ def test_phrase_prompt_through_graph_runtime():
     frac = U.match_detections(inst.pred_boxes, inst.scores, inst.pred_classes, res.pred_boxes, res.scores, res.pred_classes)
     print(f"[phrase] graph replay vs eager: {frac:.3f}")
     assert frac >= 0.99
+
+
+def test_semantic_branch_on_gpu():
+    """a22: second NMS, pixel-major sigmoid(upsample) kernel, class x query GEMM, bilinear resize -- fp32 kernels"""
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_semantic", torch.float32)
+    M.check_semantic(model, orc, image_c, text_c, gold, "cuda")

@@ -412,3 +412,19 @@ def test_mask_postprocess(ops):
 def F_avg(t):
     import torch.nn.functional as F
     return F.avg_pool2d(F.pad(t, (2, 2, 2, 2), mode="replicate"), 5, 1)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_semantic_kernels(ops, dt):
+    """mask_upsample_sigmoid (pixel-major, cropped) and bilinear_resize vs F.interpolate"""
+    h0, w0, S, n = 24, 24, 96, 20
+    lt = rnd(h0 * w0, n, seed=5) * 3.0
+    got = ops.mask_upsample_sigmoid(lt, h0, w0, S, 70, 93, dt)
+    ref = ref_ops.mask_upsample_sigmoid(lt, h0, w0, S, 70, 93, torch.float32)
+    assert got.shape == (70 * 93, n) and got.dtype == dt
+    e = relerr(got, ref)
+    x = rnd(5, 70, 93, seed=6)
+    e2 = relerr(ops.bilinear_resize(x, 105, 140), ref_ops.bilinear_resize(x, 105, 140))
+    e3 = relerr(ops.bilinear_resize(x[:, :33, :40], 20, 17), ref_ops.bilinear_resize(x[:, :33, :40], 20, 17))   # strided view, downscale
+    print("semantic kernels", dt, e, e2, e3)
+    assert e < (5e-3 if dt == torch.bfloat16 else 1e-5) and e2 < 1e-5 and e3 < 1e-5

@@ -48,6 +48,23 @@ def test_oracle_matches_reference_golden(case):
     assert list(oi["pred_masks"].shape[1:]) == gi["mask_shape"][1:]
 
 
+def test_oracle_semantic_branch_matches_reference_golden():
+    """a22: second NMS on the stuff scores, softmax(sigmoid/0.06), einsum with the sigmoid masks, crop + resize"""
+    gold = U.load_golden("tiny_semantic")
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+    orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
+    H, W = gold["out_hw"]
+    out = orc.forward(image, text, forced_topk=gold["full"]["topk_proposals"], semantic=gold["semantic_meta"], height=H, width=W)
+    S = orc.stages
+    assert tuple(out["sem_seg"].shape) == (5, H, W)
+    assert U.relerr(S["sem_box_cls"], gold["full"]["sem_box_cls"]) < 1e-3
+    assert set(S["sem_query"].tolist()) == set(gold["full"]["sem_query"].tolist())
+    U.check_fingerprint(out["sem_seg"], gold["stages"]["sem_seg"], 1e-3, "sem_seg")
+    agree = (out["sem_seg"].argmax(0).to(torch.uint8) == gold["full"]["sem_seg_argmax"]).float().mean().item()
+    assert agree > 0.999, agree
+
+
 def test_state_spec_contract():
     """checkpoint-key contract of the full-size model, as enumerated by the reference itself"""
     spec = dict(U.load_spec("L_D"))

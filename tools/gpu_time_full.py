@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--prompt", default="name")
+    ap.add_argument("--semantic", action="store_true", help="semantic branch on: the K classes are stuff classes")
+    ap.add_argument("--topk", type=int, default=0)
     args = ap.parse_args()
     t0 = time.time()
     model = init_synthetic(build_ape(args.size), 0).cuda()
@@ -25,14 +27,21 @@ def main():
     S = mv.backbone.padding_constraints["square_size"]
     image = torch.randint(0, 256, (3, S, S), generator=torch.Generator().manual_seed(2)).float().cuda()
     text = torch.randn(args.k, 1024, generator=torch.Generator().manual_seed(3)).cuda()
+    if args.topk:
+        mv.test_topk_per_image = args.topk
+    sem = dict(entity="stuff", stuff_classes=[f"s{i}" for i in range(args.k)]) if args.semantic else None
     print(f"build+init {time.time() - t0:.1f}s", flush=True)
     for it in range(args.iters):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = mv.forward_single(image, text, prompt=args.prompt)
+        out = mv.forward_single(image, text, prompt=args.prompt, semantic=sem)
         res = mv.postprocess_instance(out, (S, S), S, S)
         torch.cuda.synchronize()
-        print(f"iter {it}: {1e3 * (time.perf_counter() - t0):.1f} ms  ({len(res.scores)} instances)", flush=True)
+        extra = f", sem_seg {tuple(out['sem_seg'].shape)}" if sem else ""
+        print(f"iter {it}: {1e3 * (time.perf_counter() - t0):.1f} ms  ({len(res.scores)} instances{extra})", flush=True)
+    print("peak mem GB", torch.cuda.max_memory_allocated() / 1e9)
+    if args.semantic:
+        return
     from ape_amd.runtime import GraphedForward
     run = GraphedForward(mv)
     for it in range(args.iters):
