@@ -15,16 +15,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 #define APE_DT_BF16 1
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (same rule as torch's float->bfloat16 cast)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even via gfx950's v_cvt_pk_bf16_f32 (same rule as torch's float->bfloat16 cast; NaN stays NaN)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float a, float b) {
-  return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
 template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }

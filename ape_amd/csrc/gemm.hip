@@ -12,6 +12,7 @@
 // f32 path: plain LDS-tiled FMA kernel with the same epilogue (exact-math validation mode).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -713,6 +714,266 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 MFMA kernel "kres" for K == 256 (the 256-wide deformable encoder / decoder linears over 87 k tokens).
+// The whole K extent of the activation operand stays in REGISTERS: every wave owns 32 rows of A as 2 x 8 MFMA
+// B-operand fragments (64 VGPRs, loaded once, straight from global memory), and a workgroup (4 waves = 128 rows) walks
+// over the output columns in 128-wide chunks.  Only W streams through LDS (ring of four [128 n][64 k] stages filled
+// by global_load_lds behind counted vmcnt waits), so the L2->LDS fill per flop is half that of a 128x128 tile and a
+// quarter of the 64x64 tile these shapes used before, and A is read from HBM exactly once.
+//  * W rows are PERMUTED on their way into LDS: ring row rho = 16 j + 4 g + r holds chunk column 32 g + 4 j + r, so
+//    that after D = W A^T lane (m = lane & 15, g = lane >> 4) owns 32 CONSECUTIVE output columns of its row: the
+//    epilogue stores 16-byte pieces from registers (no LDS round trip) and 4 lanes cover a 256-byte row segment.
+//  * bias lives in LDS (lgkmcnt domain); the residual rows of a chunk are fetched BEFORE the last W stage of the chunk
+//    is requested, so consuming them never drains the W prefetch queue (VMEM returns in issue order).
+//  * the wait immediates count the residual loads / output stores issued between W stages; a chunk or row block that
+//    needs bounds checks takes a predicated epilogue followed by a full drain instead.
+// ------------------------------------------------------------------------------------------
+#define KR_BM 128
+#define KR_CH 128
+#define KR_MAXN 2048
+#define KR_LDS (4 * 16384 + KR_MAXN * 4)
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int RES /*0 none, 1 bf16 (2 = f32: compiles, spills, not instantiated)*/, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem_raw);                     // 4 stages x [128][64] bf16 (swz128 image)
+  float* sbias = reinterpret_cast<float*>(smem_raw + 4 * 16384);          // bias of this block's column range
+  constexpr int NR = RES == 0 ? 0 : (RES == 1 ? 8 : 16);                  // residual loads per lane per chunk
+  constexpr int NE = OUT_F32 ? 16 : 8;                                    // output stores per lane per chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nch_total = (p.N + KR_CH - 1) / KR_CH;
+  const int per = (nch_total + gridDim.y - 1) / gridDim.y;
+  const int cbeg = blockIdx.y * per;
+  const int nch = min(per, nch_total - cbeg);
+  if (nch <= 0) return;
+  const int nbeg = cbeg * KR_CH;
+  for (int i = tid; i < nch * KR_CH; i += 256) sbias[i] = (p.bias != nullptr && nbeg + i < p.N) ? p.bias[nbeg + i] : 0.f;
+  __syncthreads();
+
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+  const int m_wave = blockIdx.x * KR_BM + wave * 32;
+  const bool rows_full = (blockIdx.x + 1) * KR_BM <= p.M;
+
+  // ---- A: 2 row tiles x 8 k-steps of B-operand fragments (lane: row = frow, k = s*32 + fq*8 .. +8)
+  bf16x8_t af[2][8];
+  int mrow[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m_wave + mi * 16 + frow;
+    mrow[mi] = m;
+    const bf16_t* ap = A + (size_t)(m < p.M ? m : p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) af[mi][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(ap + s * 32));
+  }
+  bool masked[2] = {false, false};
+  if (p.rowmask != nullptr) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) masked[mi] = mrow[mi] < p.M && p.rowmask[mrow[mi]] != 0;
+  }
+
+  // ---- W stage loads: wave w issues instructions q = 4w .. 4w+3, each 64 lanes x 16 B = ring rows 8q .. 8q+7
+  int wcol[4], wk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rho = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rho >> 1) & 7);
+    const int idx = rho & 15;
+    wcol[i] = (idx >> 2) * 32 + (rho >> 4) * 4 + (idx & 3);       // chunk column held by ring row rho
+    wk[i] = c * 8;
+  }
+  const int T = nch * 4;
+  auto issue = [&](int t) {
+    t = t < T ? t : T - 1;                                           // past the end: harmless reload, keeps the counts uniform
+    const int cc = t >> 2, ks = t & 3;
+    bf16_t* st = ring + (t & 3) * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int n = nbeg + cc * KR_CH + wcol[i];
+      n = n < p.N ? n : p.N - 1;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(W + (size_t)n * p.ldw + ks * 64 + wk[i]), (lds_void_t*)(st + (wave * 4 + i) * 512), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[2][8];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int t, int ks) {
+    const bf16_t* st = ring + (t & 3) * 8192;
+    // W fragments in half-sets of 4 column tiles (16 VGPRs): set h+1 is read from LDS while the 8 MFMAs of set h run.
+    // The sched_barriers pin that order (left alone, hipcc hoists all 16 reads of a stage and the kernel spills, and
+    // scratch traffic would break the vmcnt bookkeeping).
+    auto rd = [&](int h, bf16x8_t (&wf)[4]) {
+      const int kk = h >> 1, jb = (h & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rho = (jb + j) * 16 + frow;
+        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(st + rho * 64 + (((kk * 4 + fq) ^ ((rho >> 1) & 7)) << 3)));
+      }
+    };
+    auto mm = [&](int h, bf16x8_t (&wf)[4]) {
+      const int kk = h >> 1, jb = (h & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[mi][ks * 2 + kk], acc[mi][jb + j], 0, 0, 0);
+    };
+    bf16x8_t w0[4], w1[4];
+    rd(0, w0);
+    rd(1, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(2, w0);
+    mm(1, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(3, w1);
+    mm(2, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(3, w1);
+  };
+
+  // residual registers of the current chunk: lane owns row mrow[mi], columns n_lane .. n_lane + 31
+  uint4 rres[RES == 0 ? 1 : 2][RES == 2 ? 8 : 4];
+  auto load_res = [&](int n_lane) {
+    if (RES == 0) return;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.residual) + ((size_t)mrow[mi] * p.ldr + n_lane) * (RES == 2 ? 4 : 2);
+#pragma unroll
+      for (int q = 0; q < (RES == 2 ? 8 : 4); ++q) rres[RES == 0 ? 0 : mi][q] = *reinterpret_cast<const uint4*>(rp + q * 16);
+    }
+  };
+  // epilogue arithmetic on one accumulator quad (same order as epi_n4_values); rv = residual values or zeros.
+  // MODE 0: bias (+ masks, residual) only; 1: + ReLU; 2: anything (alpha, clamp, GELU/SiLU) -- chosen once per launch.
+  const bool min_[2] = {masked[0] && p.mask_mode == APE_MASK_ZERO_INPUT, masked[1] && p.mask_mode == APE_MASK_ZERO_INPUT};
+  const bool mout_[2] = {masked[0] && p.mask_mode == APE_MASK_ZERO_OUTPUT, masked[1] && p.mask_mode == APE_MASK_ZERO_OUTPUT};
+  const int mode = (p.alpha == 1.f && p.clamp <= 0.f && (p.act == APE_ACT_NONE || p.act == APE_ACT_RELU)) ? (p.act == APE_ACT_RELU ? 1 : 0) : 2;
+  auto finish = [&](auto mode_tag, f32x4_t a, const float4 b, const float rv[4], int mi, float v[4]) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x = a[r];
+      if (MODE == 2) x *= p.alpha;
+      x = min_[mi] ? 0.f : x;
+      x += bb[r];
+      if (MODE == 1) x = fmaxf(x, 0.f);
+      if (MODE == 2) {
+        x = act_fn(x, p.act);
+        if (p.clamp > 0.f) x = fminf(fmaxf(x, -p.clamp), p.clamp);
+      }
+      if (RES != 0) x += rv[r];
+      x = mout_[mi] ? 0.f : x;
+      v[r] = x;
+    }
+  };
+  auto epilogue_fast = [&](auto mode_tag, int cc) {        // whole chunk in bounds: unconditional 16-byte stores, NE per lane
+    const int ncol = cc * KR_CH + fq * 32;  // relative to nbeg
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      unsigned char* cp = reinterpret_cast<unsigned char*>(p.C) + ((size_t)mrow[mi] * p.ldc + nbeg + ncol) * (OUT_F32 ? 4 : 2);
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        float v[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = jp * 2 + h;
+          const float4 b = *reinterpret_cast<const float4*>(sbias + ncol + j * 4);
+          float rv[4] = {0.f, 0.f, 0.f, 0.f};
+          if (RES == 1) {
+            const uint4 u = rres[RES == 0 ? 0 : mi][jp];
+            const uint32_t lo = h == 0 ? u.x : u.z, hi = h == 0 ? u.y : u.w;
+            rv[0] = __uint_as_float(lo << 16); rv[1] = __uint_as_float(lo & 0xffff0000u);
+            rv[2] = __uint_as_float(hi << 16); rv[3] = __uint_as_float(hi & 0xffff0000u);
+          } else if (RES == 2) {
+            const uint4 u = rres[RES == 0 ? 0 : mi][RES == 2 ? j : 0];
+            rv[0] = __uint_as_float(u.x); rv[1] = __uint_as_float(u.y); rv[2] = __uint_as_float(u.z); rv[3] = __uint_as_float(u.w);
+          }
+          finish(mode_tag, acc[mi][j], b, rv, mi, v[h]);
+        }
+        if (OUT_F32) {
+          *reinterpret_cast<float4*>(cp + jp * 32) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          *reinterpret_cast<float4*>(cp + jp * 32 + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+        } else {
+          *reinterpret_cast<uint4*>(cp + jp * 16) = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]),
+                                                               pack2bf(v[1][0], v[1][1]), pack2bf(v[1][2], v[1][3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);    // one 8-column piece at a time: keeps the live set small (no spills)
+      }
+    }
+  };
+  auto epilogue_edge = [&](int cc) {        // bounds-checked (last row block / partial last chunk), 4 columns at a time
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = mrow[mi], ncol = cc * KR_CH + fq * 32 + j * 4, n = nbeg + ncol;
+        if (m >= p.M || n >= p.N) continue;          // N % 4 == 0 (launcher), so a quad is all in or all out
+        const float4 b = *reinterpret_cast<const float4*>(sbias + ncol);
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (RES == 1) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + (size_t)m * p.ldr + n, rv);
+        if (RES == 2) ld4<float>(reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n, rv);
+        float v[4];
+        finish(std::integral_constant<int, 2>{}, acc[mi][j], b, rv, mi, v);
+        if (OUT_F32) st4<float>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+        else st4<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, v);
+      }
+  };
+
+  issue(0); issue(1); issue(2);
+  bool prev_fast = false;                    // previous chunk took the fast epilogue (its NR + NE ops are in the queue)
+  for (int cc = 0; cc < nch; ++cc) {
+    const int t0 = cc * 4;
+    const bool fast = rows_full && nbeg + (cc + 1) * KR_CH <= p.N;
+    // ks = 0: ops issued after stage t0's request: [t0+1] [R] [t0+2] [E]
+    if (prev_fast) wait_vmcnt<8 + NR + NE>(); else wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    issue(t0 + 3);
+    compute(t0, 0);
+    // ks = 1: after stage t0+1's request: [R] [t0+2] [E] [t0+3]
+    if (prev_fast) wait_vmcnt<8 + NR + NE>(); else wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    issue(t0 + 4);
+    compute(t0 + 1, 1);
+    // ks = 2: after stage t0+2's request: [E] [t0+3] [t0+4]
+    if (prev_fast) wait_vmcnt<8 + NE>(); else wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    issue(t0 + 5);
+    compute(t0 + 2, 2);
+    // ks = 3: after stage t0+3's request: [t0+4] [t0+5]
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    if (fast) load_res(nbeg + cc * KR_CH + fq * 32);
+    issue(t0 + 6);
+    compute(t0 + 3, 3);
+    if (fast) {
+      if (mode == 0) epilogue_fast(std::integral_constant<int, 0>{}, cc);
+      else if (mode == 1) epilogue_fast(std::integral_constant<int, 1>{}, cc);
+      else epilogue_fast(std::integral_constant<int, 2>{}, cc);
+    } else {
+      epilogue_edge(cc);
+      wait_vmcnt<0>();                        // unknown number of predicated ops: drain, the next chunk counts from zero
+    }
+    prev_fast = fast;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
 extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
@@ -761,7 +1022,32 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
         attr_done = true;
       }
-      if (p.splitk > 1) {
+      const char* nk_env = getenv("APE_GEMM_NOKRES");     // read per call so a probe can flip it
+      const int no_kres = nk_env ? atoi(nk_env) : 0;
+      const bool kres = !no_kres && !no_glds && p.K == 256 && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
+                        p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr && p.splitk <= 1 && p.ldc % 8 == 0 &&
+                        (p.residual == nullptr || (p.res_dt == APE_DT_BF16 && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
+      if (kres) {
+        static bool kattr = false;
+        if (!kattr) {
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+          kattr = true;
+        }
+        const int mblk = ceil_div(p.M, KR_BM);
+        const int nch = ceil_div(p.N, KR_CH);
+        int ysplit = ceil_div(nch, KR_MAXN / KR_CH);                  // bias slab in LDS holds KR_MAXN columns
+        while (mblk * ysplit < 512 && ysplit * 2 <= nch) ysplit *= 2;   // few row blocks: spread the column chunks as well
+        const dim3 grid(mblk, ysplit);
+        const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
+        const bool of32 = p.out_dt == APE_DT_F32;
+        if (!res && !of32) hipLaunchKernelGGL((gemm_bf16_kres_kernel<0, false>), grid, dim3(256), KR_LDS, s, p);
+        else if (res && !of32) hipLaunchKernelGGL((gemm_bf16_kres_kernel<1, false>), grid, dim3(256), KR_LDS, s, p);
+        else if (!res) hipLaunchKernelGGL((gemm_bf16_kres_kernel<0, true>), grid, dim3(256), KR_LDS, s, p);
+        else hipLaunchKernelGGL((gemm_bf16_kres_kernel<1, true>), grid, dim3(256), KR_LDS, s, p);
+      } else if (p.splitk > 1) {
         APE_CHECK_ARG(ring && !p.trans_out && p.workspace != nullptr && p.act != APE_ACT_SWIGLU,
                       "ape_hip_gemm: split-K needs bf16, K %% 32 == 0, no trans_out / SwiGLU, and a workspace");
         APE_CHECK_ARG(p.N % 4 == 0 && ((uintptr_t)p.workspace) % 16 == 0, "ape_hip_gemm: split-K needs N %% 4 == 0 and an aligned workspace");

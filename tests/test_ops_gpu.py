@@ -146,6 +146,34 @@ def test_gemm_tile64(ops, trans):
         assert e < 3e-4, (M2, N2, K2, e)
 
 
+def test_gemm_kres(ops):
+    """K == 256 register-resident-A kernel (big-M linears of the deformable encoder): every epilogue it takes, full and
+    ragged row blocks, partial last column chunk, column splits over blockIdx.y, strided operands"""
+    K = 256
+    for (M, N) in [(87296, 256), (21824, 2048), (5000, 480), (2048, 1536), (4100, 64), (6000, 2304)]:
+        a, w = rnd(M, K, dtype=torch.bfloat16, seed=1), rnd(N, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=2)
+        bias, res = rnd(N, seed=3), rnd(M, N, dtype=torch.bfloat16, seed=4)
+        mask = (torch.arange(M) % 5 == 2).to(DEV)
+        cases = [dict(), dict(out_dtype=torch.float32), dict(residual=res), dict(act=ref_ops.ACT_RELU),
+                 dict(rowmask=mask, mask_mode=ref_ops.MASK_ZERO_INPUT), dict(rowmask=mask, mask_mode=ref_ops.MASK_ZERO_OUTPUT, residual=res),
+                 dict(residual=res, out_dtype=torch.float32, alpha=0.5, clamp=2.0)]
+        if M > 50000:
+            cases = cases[:3] + cases[4:5]
+        for kw in cases:
+            got = ops.gemm(a, w, bias, **kw)
+            ref = ref_ops.gemm(a, w, bias, **kw)
+            e = relerr(got, ref)
+            print(f"gemm kres M{M} N{N} {[k for k in kw]}: {e:.3e}")
+            assert e < (3e-4 if kw.get("out_dtype") == torch.float32 else 6e-3), (M, N, kw.keys())
+    # strided A (column slice), output into a wider buffer, no bias
+    big = rnd(4096, 3 * K, dtype=torch.bfloat16, seed=7)
+    w = rnd(512, K, dtype=torch.bfloat16, scale=K ** -0.5, seed=8)
+    out = torch.zeros(4096, 1024, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(big[:, K:2 * K], w, None, out=out[:, 256:768])
+    assert relerr(out[:, 256:768], ref_ops.gemm(big[:, K:2 * K], w, None)) < 6e-3
+    assert out[:, :256].abs().max().item() == 0 and out[:, 768:].abs().max().item() == 0
+
+
 def test_gemv(ops):
     x = rnd(3, 1024, seed=1)
     for dt in (torch.float32, torch.bfloat16):
