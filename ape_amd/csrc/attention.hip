@@ -52,32 +52,38 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   for (int ks = 0; ks < KSTEPS; ++ks)
     qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * N + qrow_c) * p.ldq + h * HD + ks * 32 + fq * 8));
 
-  // staging assignment: K tile 64 rows x KC chunks, Vt tile HD rows x 8 chunks; both HD*8 chunks
-  constexpr int CH = HD * 8;
-  constexpr int PER = CH / 256;  // 2 (HD=64) or 1 (HD=32)
-  uint4 rk[PER], rv[PER];
-  auto gload = [&](int t) {
+  // staging: K tile (64 keys x HD) and Vt tile (HD x 64 keys) go global -> LDS with global_load_lds (no VGPR round trip,
+  // nothing for the compiler to spill: the register-staged version kept the prefetched tile in scratch and waited for
+  // every global load right after issuing it).  The LDS destination of an instruction is lane-linear (64 x 16 B), so the
+  // XOR swizzle of swz_rows() is applied to the per-lane SOURCE chunk instead.
+  constexpr int PER = HD * 8 / 256;  // instructions per wave per operand: 2 (HD=64) or 1 (HD=32)
+  typedef __attribute__((address_space(3))) void lds_void_t;
+  typedef const __attribute__((address_space(1))) void gbl_void_t;
+  const bf16_t* ksrc[PER];
+  const bf16_t* vsrc[PER];
+  int krow[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int slot = (wave * PER + i) * 64 + lane;
+    {
+      const int row = slot / KC, cp = slot % KC;
+      const int c = KC == 8 ? (cp ^ ((row >> 1) & 7)) : (cp ^ (((row >> 3) & 1) << 1));
+      krow[i] = row;
+      ksrc[i] = Kp + (size_t)b * N * p.ldk + h * HD + c * 8;
+    }
+    {
+      const int row = slot >> 3, cp = slot & 7;
+      const int c = cp ^ ((row >> 1) & 7);
+      vsrc[i] = Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * N + c * 8;
+    }
+  }
+  auto issue = [&](int t, int buf) {
     const int key0 = t * 64;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int cid = tid + 256 * i;
-      {
-        const int row = cid / KC, c = cid % KC;
-        int key = key0 + row; key = key < N ? key : N - 1;
-        rk[i] = *reinterpret_cast<const uint4*>(Kp + ((size_t)b * N + key) * p.ldk + h * HD + c * 8);
-      }
-      {
-        const int row = cid >> 3, c = cid & 7;
-        rv[i] = *reinterpret_cast<const uint4*>(Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * N + key0 + c * 8);
-      }
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int cid = tid + 256 * i;
-      *reinterpret_cast<uint4*>(&smem[buf][swz_rows(cid / KC, cid % KC, KC)]) = rk[i];
-      *reinterpret_cast<uint4*>(&smem[buf][64 * HD + swz_rows(cid >> 3, cid & 7, 8)]) = rv[i];
+      int key = key0 + krow[i]; key = key < N ? key : N - 1;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ksrc[i] + (size_t)key * p.ldk), (lds_void_t*)(&smem[buf][(wave * PER + i) * 512]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(vsrc[i] + key0), (lds_void_t*)(&smem[buf][64 * HD + (wave * PER + i) * 512]), 16, 0, 0);
     }
   };
 
@@ -87,12 +93,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   float m_run = -INFINITY, l_run = 0.f;
 
   const int nt = (N + 63) / 64;
-  gload(0);
-  sstore(0);
-  __syncthreads();
+  issue(0, 0);
+  __syncthreads();                       // s_waitcnt vmcnt(0) + barrier: tile 0 has landed for every wave
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
-    if (t + 1 < nt) gload(t + 1);
+    if (t + 1 < nt) issue(t + 1, buf ^ 1);   // lands while this tile is consumed; the buffer was released by the last barrier
     const bf16_t* sK = &smem[buf][0];
     const bf16_t* sV = &smem[buf][64 * HD];
 
@@ -107,29 +112,30 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         sacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[i], 0, 0, 0);
       }
     }
-    // scale (log2 domain), mask keys >= N, running max
-    float pv[4][4];
-    float mx = -INFINITY;
-    const int kbase = t * 64 + fq * 4;
+    // running max on the RAW scores (scale > 0 commutes with max); keys >= N only exist in the last tile
+    if (t == nt - 1 && (N & 63) != 0) {
+      const int kbase = t * 64 + fq * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = sacc[i][r] * p.scale_log2;
-        if (kbase + i * 16 + r >= N) s = -INFINITY;
-        pv[i][r] = s;
-        mx = fmaxf(mx, s);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (kbase + i * 16 + r >= N) sacc[i][r] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+#pragma unroll
+    for (int i = 1; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(sacc[i][0], sacc[i][1]), fmaxf(sacc[i][2], sacc[i][3])));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    // p = 2^(s * scale_log2 - m): one fma + one v_exp_f32 per score
+    float pv[4][4];
     float rs = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(pv[i][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i][r], p.scale_log2, -m_new));
         pv[i][r] = e;
         rs += e;
       }
@@ -162,7 +168,6 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), pf, oacc[d], 0, 0, 0);
       }
     }
-    if (t + 1 < nt) sstore(buf ^ 1);
     __syncthreads();
   }
   // finish: total row sum over the 4 lanes sharing this query
