@@ -38,12 +38,28 @@ class DataParallelRunner:
             dist.broadcast(text, src=0, group=self.group)
         return text
 
+    def _all_gather(self, rec):
+        if self.world == 1:
+            return rec[None]
+        if self._gather is None:
+            self._gather = [torch.empty_like(rec.contiguous()) for _ in range(self.world)]
+        dist.all_gather(self._gather, rec.contiguous(), group=self.group)
+        return torch.stack(self._gather)
+
     def step(self, image, text):
         """one image on this rank; returns (instances, all ranks' records [world, k, 6])"""
         inst, rec = self.forward_fn(image, text)
-        if self.world == 1:
-            return inst, rec[None]
-        if self._gather is None:
-            self._gather = [torch.empty_like(rec) for _ in range(self.world)]
-        dist.all_gather(self._gather, rec.contiguous(), group=self.group)
-        return inst, torch.stack(self._gather)
+        return inst, self._all_gather(rec)
+
+    # pipelined form (forward_fn must offer submit/result, e.g. runtime.GraphedForward): the device->host transfer of
+    # image i and the record all-gather overlap the compute of image i+1
+    def submit(self, image, text):
+        """enqueue one image; returns a ticket for `result`"""
+        ticket = self.forward_fn.submit(image, text)
+        ticket.records = self._all_gather(ticket.rec6)     # stream-ordered behind the forward, no host wait
+        return ticket
+
+    def result(self, ticket):
+        """(instances on the host, all ranks' records [world, k, 6]) of a submitted image"""
+        inst, _ = self.forward_fn.result(ticket)
+        return inst, ticket.records

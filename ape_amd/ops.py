@@ -459,11 +459,14 @@ def roi_align_bits(bits, boxes, p):
     return out
 
 
-def paste_bits(masks, boxes, ho, wo):
+def paste_bits(masks, boxes, ho, wo, out=None):
     """paste_masks_in_image: masks uint8 [n,P,P], boxes [n,4] (output frame) -> uint8 [n,ho,wo]."""
-    _dev(masks, boxes)
+    _dev(masks, boxes, out)
     n, P, _ = masks.shape
-    out = torch.empty((n, ho, wo), dtype=torch.uint8, device=masks.device)
+    if out is None:
+        out = torch.empty((n, ho, wo), dtype=torch.uint8, device=masks.device)
+    elif out.dtype != torch.uint8 or tuple(out.shape) != (n, ho, wo) or not out.is_contiguous():
+        raise ValueError("ape_amd.ops.paste_bits: out must be a contiguous uint8 [n, ho, wo] tensor")
     rc = _lib.load().ape_hip_paste_bits(_p(_u8(masks, "masks")), P, _p(_boxes(boxes)), n, ho, wo, _p(out), _stream())
     _lib.check(rc, "ape_hip_paste_bits")
     return out

@@ -1,10 +1,17 @@
-"""hipGraph-replayed forward: the per-image launch sequence (~700 kernels) is captured once per (image size,
-vocabulary size) and replayed, so the host does not pace the GPU.
+"""hipGraph-replayed, double-buffered forward: the per-image launch sequence (~700 kernels) is captured once per
+(image size, vocabulary, prompt mode) and replayed, and the results of image i travel to the host on a copy stream
+while image i+1 is being computed.
 
 The forward of DeformableDETRSegmVL.forward_single is a fixed sequence of launches with fixed shapes and no host
 synchronisation (data-dependent selection / NMS / top-k are fixed-shape device code), which makes it capturable with
 torch.cuda.CUDAGraph (a hipGraph on ROCm): our C-ABI launchers enqueue on torch's current stream, which is the
-capturing stream inside `torch.cuda.graph`.  Results leave the device through pinned host buffers.
+capturing stream inside `torch.cuda.graph`.
+
+Results leave the device through TWO slots (device staging + pinned host buffers).  The last kernel of the forward
+(paste_bits, which writes the [k, H, W] instance masks: 105 MB for 100 detections at 1024^2) runs outside the graph and
+writes straight into the slot's staging buffer; a copy stream then moves the slot to pinned memory behind an event.
+`submit()` enqueues an image and returns a ticket, `result(ticket)` waits for that slot's copy only -- so the ~2 ms
+PCIe transfer of one image overlaps the compute of the next.  `__call__` = result(submit(...)) is the synchronous form.
 """
 from types import SimpleNamespace
 
@@ -12,14 +19,19 @@ import torch
 
 
 class GraphedForward:
+    SLOTS = 2
+
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True):
         self.mv = model_vision
         self.use_graph = use_graph
         self.max_graphs = max_graphs
         self.with_masks = with_masks
         self._graphs = {}
+        self._copy_stream = None
 
+    # ------------------------------------------------------------------ device work of one image
     def _device_part(self, image, text, height, width, prompt="name"):
+        """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame)"""
         mv = self.mv
         h, w = image.shape[-2:]
         out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt)
@@ -29,11 +41,7 @@ class GraphedForward:
         keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
         rec = torch.cat([boxes, out["det_scores"][:, None], out["det_classes"][:, None].float(),
                          out["det_query"][:, None].float(), keep[:, None].float()], 1).contiguous()   # [k, 8]
-        masks = None
-        if "det_masks128" in out:
-            from . import ops
-            masks = ops.paste_bits(out["det_masks128"], boxes.contiguous(), height, width)
-        return rec, masks, rec[:, :6].contiguous()
+        return rec, out.get("det_masks128"), boxes.contiguous()
 
     def _build(self, image, text, height, width, prompt):
         mv = self.mv
@@ -47,18 +55,31 @@ class GraphedForward:
         if self.use_graph:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph):
-                entry.rec, entry.masks, entry.rec6 = self._device_part(entry.image, text, height, width, prompt)
+                entry.rec, entry.masks128, entry.boxes = self._device_part(entry.image, text, height, width, prompt)
         else:
             entry.graph = None
         k = mv.test_topk_per_image
-        entry.h_rec = torch.empty((k, 8), dtype=torch.float32, pin_memory=True)
-        entry.h_masks = torch.empty((k, height, width), dtype=torch.uint8, pin_memory=True) if self.with_masks and mv.test_mask_on else None
+        has_masks = self.with_masks and mv.test_mask_on
+        entry.slots = []
+        for _ in range(self.SLOTS):
+            s = SimpleNamespace()
+            s.d_rec = torch.empty((k, 8), dtype=torch.float32, device=dev)
+            s.h_rec = torch.empty((k, 8), dtype=torch.float32, pin_memory=True)
+            s.d_masks = torch.empty((k, height, width), dtype=torch.uint8, device=dev) if has_masks else None
+            s.h_masks = torch.empty((k, height, width), dtype=torch.uint8, pin_memory=True) if has_masks else None
+            s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
+            s.busy = False
+            entry.slots.append(s)
+        entry.next_slot = 0
+        entry.size = (height, width)
         return entry
 
+    # ------------------------------------------------------------------ pipelined interface
     @torch.no_grad()
-    def __call__(self, image, text, height=None, width=None, prompt="name"):
-        """image [3,h,w] fp32 on the device, text [K, D] on the device -> (instances on the host, device record [k,6]).
-        prompt: "name" (bank feeds the classifier only) or "phrase" / "expression" (bank fused in the encoder)."""
+    def submit(self, image, text, height=None, width=None, prompt="name"):
+        """enqueue one image [3,h,w] (fp32, device) against the text bank [K, D] (device); returns a ticket.
+        At most SLOTS tickets may be outstanding per (size, vocabulary) entry."""
+        from . import ops
         h, w = image.shape[-2:]
         height, width = height or h, width or w
         key = (h, w, height, width, text.data_ptr(), tuple(text.shape), prompt)
@@ -67,20 +88,48 @@ class GraphedForward:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
             e = self._graphs[key] = self._build(image, text, height, width, prompt)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=image.device)
+        s = e.slots[e.next_slot]
+        if s.busy:
+            raise RuntimeError("GraphedForward.submit: every result slot is outstanding -- call result() on an earlier ticket first")
+        e.next_slot = (e.next_slot + 1) % self.SLOTS
+        cur = torch.cuda.current_stream()
         if e.graph is not None:
             e.image.copy_(image, non_blocking=True)
             e.graph.replay()
-            rec, masks, rec6 = e.rec, e.masks, e.rec6
+            rec, masks128, boxes = e.rec, e.masks128, e.boxes
         else:
-            rec, masks, rec6 = self._device_part(image, text, height, width, prompt)
-        e.h_rec.copy_(rec, non_blocking=True)
-        if masks is not None and e.h_masks is not None:
-            e.h_masks.copy_(masks, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        keep = e.h_rec[:, 7] > 0.5
-        inst = SimpleNamespace(image_size=(height, width), pred_boxes=e.h_rec[keep, :4].clone(), scores=e.h_rec[keep, 4].clone(),
-                               pred_classes=e.h_rec[keep, 5].long(), query_index=e.h_rec[keep, 6].long())
-        if masks is not None and e.h_masks is not None:
-            # zero-copy view of the pinned staging buffer (valid until the next call with the same key)
-            inst.pred_masks = e.h_masks.view(torch.bool) if bool(keep.all()) else e.h_masks[keep].view(torch.bool)
-        return inst, rec6
+            rec, masks128, boxes = self._device_part(image, text, height, width, prompt)
+        cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
+        s.d_rec.copy_(rec, non_blocking=True)
+        if masks128 is not None and s.d_masks is not None:
+            ops.paste_bits(masks128, boxes, height, width, out=s.d_masks)     # detector_postprocess (:869-871), into the slot
+        s.computed.record(cur)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(s.computed)
+            s.h_rec.copy_(s.d_rec, non_blocking=True)
+            if s.d_masks is not None and masks128 is not None:
+                s.h_masks.copy_(s.d_masks, non_blocking=True)
+            s.copied.record(self._copy_stream)
+        s.busy = True
+        s.has_masks = masks128 is not None and s.d_masks is not None
+        return SimpleNamespace(entry=e, slot=s, rec6=s.d_rec[:, :6])
+
+    def result(self, ticket):
+        """wait for the ticket's transfer; returns (instances on the host, device record view [k,6]).
+        pred_masks is a zero-copy view of the slot's pinned buffer: valid until SLOTS further submits."""
+        e, s = ticket.entry, ticket.slot
+        s.copied.synchronize()
+        s.busy = False
+        height, width = e.size
+        keep = s.h_rec[:, 7] > 0.5
+        inst = SimpleNamespace(image_size=(height, width), pred_boxes=s.h_rec[keep, :4].clone(), scores=s.h_rec[keep, 4].clone(),
+                               pred_classes=s.h_rec[keep, 5].long(), query_index=s.h_rec[keep, 6].long())
+        if s.has_masks:
+            inst.pred_masks = s.h_masks.view(torch.bool) if bool(keep.all()) else s.h_masks[keep].view(torch.bool)
+        return inst, ticket.rec6
+
+    def __call__(self, image, text, height=None, width=None, prompt="name"):
+        """synchronous form: image -> (instances on the host, device record [k,6])"""
+        return self.result(self.submit(image, text, height, width, prompt))

@@ -144,18 +144,33 @@ def main():
     # rank r owns images r, r+N, ... of the synthetic stream
     images = make_images(args.stream_images, S, seed=100 + rank, device=dev)
 
+    # One step = one image per rank, submitted to the double-buffered runtime: the forward of image i is enqueued (hipGraph
+    # replay + mask paste + record all-gather), then the host collects image i-1, whose device->host transfer ran on the
+    # copy stream meanwhile.  K timed steps = K submits + K collected results (the last one is flushed inside the timed
+    # region), so `value` counts K complete images per rank, masks on the host included.
+    pending = [None]
+
     def step(i):
-        inst, _ = dp.step(images[i % len(images)], text)   # all-gathers the fixed-size detection records [k, 6]
-        return inst
+        ticket = dp.submit(images[i % len(images)], text)
+        done = dp.result(pending[0]) if pending[0] is not None else None
+        pending[0] = ticket
+        return done
+
+    def flush():
+        done = dp.result(pending[0]) if pending[0] is not None else None
+        pending[0] = None
+        return done
 
     for i in range(args.warmup):
         step(i)
+    flush()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    flush()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

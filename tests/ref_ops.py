@@ -312,11 +312,15 @@ def roi_align_bits(bits, boxes, p):
     return tp.bitmasks_crop_and_resize(bits.cpu().bool(), boxes.cpu(), p).to(torch.uint8).to(bits.device)
 
 
-def paste_bits(masks, boxes, ho, wo):
+def paste_bits(masks, boxes, ho, wo, out=None):
     from oracle import thirdparty as tp
 
-    out = [tp.paste_mask(masks[i].cpu().float(), boxes[i].cpu(), ho, wo).to(torch.uint8) for i in range(masks.shape[0])]
-    return torch.stack(out).to(masks.device)
+    res = [tp.paste_mask(masks[i].cpu().float(), boxes[i].cpu(), ho, wo).to(torch.uint8) for i in range(masks.shape[0])]
+    res = torch.stack(res).to(masks.device)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
 
 
 def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):

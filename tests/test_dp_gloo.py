@@ -43,6 +43,25 @@ def _worker(rank, world, port, ret):
     for i in mine:
         _, allrec = runner.step(images[i], text)
         gathered.append(allrec)
+
+    # the pipelined form (submit image i, collect image i-1) must deliver the same records in the same order
+    class Pipelined:
+        def submit(self, image, text):
+            from types import SimpleNamespace
+            return SimpleNamespace(rec6=fwd(image, text)[1])
+
+        def result(self, ticket):
+            return None, ticket.rec6
+
+    prunner = DataParallelRunner(Pipelined(), mv.test_topk_per_image, torch.device("cpu"))
+    piped, pending = [], None
+    for i in mine:
+        t = prunner.submit(images[i], text)
+        if pending is not None:
+            piped.append(prunner.result(pending)[1])
+        pending = t
+    piped.append(prunner.result(pending)[1])
+    same = all(torch.equal(a, b) for a, b in zip(piped, gathered)) and len(piped) == len(gathered)
     if rank == 0:
         # single-process ground truth for every image
         want = [fwd(img, text)[1] for img in images]
@@ -50,7 +69,7 @@ def _worker(rank, world, port, ret):
         for step, allrec in enumerate(gathered):
             for r in range(world):
                 ok &= torch.allclose(allrec[r], want[step * world + r], atol=1e-5)
-        ret["ok"] = bool(ok)
+        ret["ok"] = bool(ok) and same
         ret["text_sum"] = float(text.sum())
     else:
         ret[f"text_sum_{rank}"] = float(text.sum())
