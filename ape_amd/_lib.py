@@ -55,6 +55,7 @@ SIGNATURES = {
     "ape_hip_abi_version": (c_int, []),
     "ape_hip_sizeof_args": (c_int, [c_int]),
     "ape_hip_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
+    "ape_hip_gemm_last_kernel": (c_char_p, []),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),
     "ape_hip_layernorm": (c_int, [POINTER(LayerNormArgs), c_void_p]),

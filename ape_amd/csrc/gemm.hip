@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 //    deformable encoder store-bound).
 // ------------------------------------------------------------------------------------------
 #define GEMM_T64_LDS (4 * 128 * 32 * 2)  /* 64x64 ring: 4 stages x (64+64) rows x 64 B = 32 KiB >= the 64 x (64*4+16) B fp32 epilogue tile */
+#define GEMM_T128x64_LDS (4 * (128 + 64) * 32 * 2)  /* 48 KiB of stages >= the 128 x (64*4+16) B epilogue tile */
 #define GEMM_V2_LDS (GB_M * (GB_N * 4 + 16))  /* 67584 B: fp32 epilogue tile; >= the 64 KiB operand buffers */
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -443,8 +444,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams
   };
   // wait until this wave's loads of tile `t` have landed, given that tiles up to min(t+2, nk-1) were issued after it
   auto wait_n_tiles_in_flight = [&](int tiles) {   // allow `tiles` younger K-tiles (LPT loads each) to stay outstanding
-    if (tiles >= 2) { if (LPT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else if (tiles == 1) { if (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    if (tiles >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+    else if (tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   auto wait_tile = [&](int t) { wait_n_tiles_in_flight(t + 2 < nk ? 2 : (t + 1 < nk ? 1 : 0)); };
@@ -976,6 +977,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
 // ------------------------------------------------------------------------------------------
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
+static thread_local const char* g_last_gemm_kernel = "";
+extern "C" const char* ape_hip_gemm_last_kernel(void) { return g_last_gemm_kernel; }
+#define LAUNCH_GEMM(NAME, KERNEL, GRID, LDS) do { g_last_gemm_kernel = NAME; hipLaunchKernelGGL(KERNEL, GRID, dim3(256), LDS, s, p); } while (0)
+
 extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(a != nullptr, "ape_hip_gemm: null args");
   ApeGemmArgs p = *a;
@@ -1043,37 +1048,42 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
         const dim3 grid(mblk, ysplit);
         const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
         const bool of32 = p.out_dt == APE_DT_F32;
-        if (!res && !of32) hipLaunchKernelGGL((gemm_bf16_kres_kernel<0, false>), grid, dim3(256), KR_LDS, s, p);
-        else if (res && !of32) hipLaunchKernelGGL((gemm_bf16_kres_kernel<1, false>), grid, dim3(256), KR_LDS, s, p);
-        else if (!res) hipLaunchKernelGGL((gemm_bf16_kres_kernel<0, true>), grid, dim3(256), KR_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_kres_kernel<1, true>), grid, dim3(256), KR_LDS, s, p);
+        if (!res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false>", (gemm_bf16_kres_kernel<0, false>), grid, KR_LDS);
+        else if (res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<1, false>", (gemm_bf16_kres_kernel<1, false>), grid, KR_LDS);
+        else if (!res) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, true>", (gemm_bf16_kres_kernel<0, true>), grid, KR_LDS);
+        else LAUNCH_GEMM("gemm_bf16_kres_kernel<1, true>", (gemm_bf16_kres_kernel<1, true>), grid, KR_LDS);
       } else if (p.splitk > 1) {
         APE_CHECK_ARG(ring && !p.trans_out && p.workspace != nullptr && p.act != APE_ACT_SWIGLU,
                       "ape_hip_gemm: split-K needs bf16, K %% 32 == 0, no trans_out / SwiGLU, and a workspace");
         APE_CHECK_ARG(p.N % 4 == 0 && ((uintptr_t)p.workspace) % 16 == 0, "ape_hip_gemm: split-K needs N %% 4 == 0 and an aligned workspace");
-        if (p.tile64) hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64, p.splitk), dim3(256), GEMM_T64_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk, p.splitk), dim3(256), GEMM_V2_LDS, s, p);
+        if (p.tile64 == 2) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2>), dim3(ceil_div(p.M, 128) * ceil_div(p.N, 64), p.splitk), GEMM_T128x64_LDS);
+        else if (p.tile64) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64, p.splitk), GEMM_T64_LDS);
+        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk, p.splitk), GEMM_V2_LDS);
         const size_t groups = (size_t)p.M * ((p.N + 3) / 4);
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
+      } else if (ring && p.tile64 == 2 && !p.trans_out) {
+        // 128 x 64 tiles: twice the workgroups of a 128 x 128 tiling at 3/4 of its operand traffic per flop
+        const int nblk_mn = ceil_div(p.M, 128) * ceil_div(p.N, 64);
+        LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2>), dim3(nblk_mn), GEMM_T128x64_LDS);
       } else if (ring && p.tile64) {
-        if (p.trans_out) hipLaunchKernelGGL((gemm_bf16_ring_kernel<true, 2, 2>), dim3(nblk64), dim3(256), GEMM_T64_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64), dim3(256), GEMM_T64_LDS, s, p);
+        if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 2, 2>", (gemm_bf16_ring_kernel<true, 2, 2>), dim3(nblk64), GEMM_T64_LDS);
+        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64), GEMM_T64_LDS);
       } else if (ring && (use_ring_always || nblk < 64)) {
-        if (p.trans_out) hipLaunchKernelGGL((gemm_bf16_ring_kernel<true, 4, 4>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 4, 4>", (gemm_bf16_ring_kernel<true, 4, 4>), dim3(nblk), GEMM_V2_LDS);
+        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk), GEMM_V2_LDS);
       } else if (p.trans_out) {
-        if (glds) hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, true>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<true, false>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<true, true>", (gemm_bf16_v2_kernel<true, true>), dim3(nblk), GEMM_V2_LDS);
+        else LAUNCH_GEMM("gemm_bf16_v2_kernel<true, false>", (gemm_bf16_v2_kernel<true, false>), dim3(nblk), GEMM_V2_LDS);
       } else {
-        if (glds) hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, true>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
-        else hipLaunchKernelGGL((gemm_bf16_v2_kernel<false, false>), dim3(nblk), dim3(256), GEMM_V2_LDS, s, p);
+        if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<false, true>", (gemm_bf16_v2_kernel<false, true>), dim3(nblk), GEMM_V2_LDS);
+        else LAUNCH_GEMM("gemm_bf16_v2_kernel<false, false>", (gemm_bf16_v2_kernel<false, false>), dim3(nblk), GEMM_V2_LDS);
       }
-    } else if (p.trans_out) hipLaunchKernelGGL(gemm_bf16_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_bf16_kernel<false>, dim3(nblk), dim3(256), 0, s, p);
+    } else if (p.trans_out) LAUNCH_GEMM("gemm_bf16_kernel<true>", gemm_bf16_kernel<true>, dim3(nblk), 0);
+    else LAUNCH_GEMM("gemm_bf16_kernel<false>", gemm_bf16_kernel<false>, dim3(nblk), 0);
   } else {
     const int nblk = ceil_div(p.M, 64) * ceil_div(p.N, 64);
-    if (p.trans_out) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(nblk), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(nblk), dim3(256), 0, s, p);
+    if (p.trans_out) LAUNCH_GEMM("gemm_f32_kernel<true>", gemm_f32_kernel<true>, dim3(nblk), 0);
+    else LAUNCH_GEMM("gemm_f32_kernel<false>", gemm_f32_kernel<false>, dim3(nblk), 0);
   }
   APE_CHECK_LAUNCH("ape_hip_gemm");
   return 0;

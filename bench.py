@@ -51,10 +51,13 @@ def make_images(n, S, seed, device):
 
 
 class GemmMeter:
-    """wraps ape_amd.ops.gemm with HIP event pairs (torch.cuda.Event on the launch stream = torch's current stream)"""
+    """wraps ape_amd.ops.gemm with HIP event pairs (torch.cuda.Event on the launch stream = torch's current stream) and
+    asks the library which kernel symbol each call launched (ape_hip_gemm_last_kernel)"""
 
     def __init__(self, ops):
+        from ape_amd import _lib
         self.ops, self.orig, self.records = ops, ops.gemm, []
+        self.lib = _lib.load()
 
     def __enter__(self):
         def wrapped(a, w, *args, **kw):
@@ -62,8 +65,8 @@ class GemmMeter:
             s.record()
             out = self.orig(a, w, *args, **kw)
             e.record()
-            if a.dtype == torch.bfloat16 and not kw.get("trans_out", False):
-                self.records.append((s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0]))
+            name = self.lib.ape_hip_gemm_last_kernel().decode()
+            self.records.append((name, s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0]))
             return out
         self.ops.gemm = wrapped
         return self
@@ -72,10 +75,32 @@ class GemmMeter:
         self.ops.gemm = self.orig
 
     def summary(self):
+        """per kernel symbol: (launches, seconds, flops), sorted by time"""
         torch.cuda.synchronize()
-        t = sum(s.elapsed_time(e) for s, e, _ in self.records) * 1e-3
-        fl = sum(f for _, _, f in self.records)
-        return len(self.records), t, fl
+        groups = {}
+        for name, s, e, fl in self.records:
+            g = groups.setdefault(name, [0, 0.0, 0.0])
+            g[0] += 1
+            g[1] += s.elapsed_time(e) * 1e-3
+            g[2] += fl
+        return sorted(groups.items(), key=lambda kv: -kv[1][1])
+
+
+def pmc_traffic_bytes(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh ->
+    profiles/r01_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950).  None when the summary does not list the kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
+    if not os.path.exists(path):
+        return None
+    for line in open(path):
+        cols = [c.strip() for c in line.split("|")]
+        if len(cols) > 3 and cols[0] == kernel:
+            try:
+                return float(cols[-1]) * 1024.0 * 1024.0
+            except ValueError:
+                return None
+    return None
 
 
 def cpu_baseline(model, size, image, text, max_threads=32):
@@ -182,25 +207,32 @@ def main():
 
     result = None
     if rank == 0:
-        # instrumented pass (eager, NOT part of the timed region): HIP events around every bf16 GEMM launch
+        # instrumented pass (eager, NOT part of the timed region): HIP events around every GEMM launch, grouped by the
+        # kernel symbol the library reports; the roofline object is about the symbol with the largest total time
+        reps = 3
         with GemmMeter(ops) as meter:
-            for i in range(3):
+            for i in range(reps):
                 out = mv.forward_single(images[i % len(images)], text)
                 mv.postprocess_instance(out, (S, S), S, S)
-            n_launch, t_gemm, flops = meter.summary()
-        achieved = flops / t_gemm / 1e12
+            groups = meter.summary()
+        dom_name, (dom_n, dom_t, dom_fl) = groups[0]
+        all_t, all_fl = sum(g[1][1] for g in groups), sum(g[1][2] for g in groups)
+        achieved = dom_fl / dom_t / 1e12
         result = {
             "metric": "images/sec @1024^2 APE-L_D fwd", "value": world * args.steps / elapsed, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"APE-{args.size} forward, 1x{S}x{S} image per rank per step, {args.classes} classes "
                                    "(name prompt), masks on, top-100 detections; seeded synthetic weights",
-                       "parallelism": f"dp{world}", "graph": not args.no_graph},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<false>", "achieved": achieved,
+                       "parallelism": f"dp{world}", "graph": not args.no_graph, "pipelined_d2h": True},
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": None, "launches_per_image": n_launch // 3,
-                         "avg_launch_us": 1e6 * t_gemm / max(n_launch, 1), "gemm_ms_per_image": 1e3 * t_gemm / 3,
-                         "flops_per_image": flops / 3},
+                         "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n // reps,
+                         "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
+                         "flops_per_launch": dom_fl / max(dom_n, 1),
+                         "all_gemm_kernels": {"ms_per_image": 1e3 * all_t / reps, "tflops": all_fl / all_t / 1e12,
+                                              "flops_per_image": all_fl / reps,
+                                              "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups}}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -76,6 +76,8 @@ typedef struct ApeGemmArgs {
   float* workspace;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
+/* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */
+const char* ape_hip_gemm_last_kernel(void);
 
 /* out[m][n] = alpha * x[m,:] . W[n,:] + bias[n], fp32 x/out, W f32 or bf16; for M <= a few rows
  * (the L=1 language side of ape/layers/fuse_helper.py:70-73,160-161). */

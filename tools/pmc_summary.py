@@ -1,0 +1,22 @@
+"""Per-kernel means of the rocprofv3 PMC passes written by tools/gpu_pmc.sh (counter_collection.csv files)."""
+import collections
+import csv
+import glob
+import sys
+
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+rows = []
+for name, cs in agg.items():
+    n = max(len(v) for v in cs.values())
+    mean = {k: sum(v) / len(v) for k, v in cs.items()}
+    rows.append((name, n, mean))
+keys = sorted({k for _, _, m in rows for k in m})
+print("kernel | launches | " + " | ".join(keys) + " | HBM MB/launch = (2*FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction)")
+for name, n, m in sorted(rows, key=lambda r: -r[2].get("FETCH_SIZE", 0) * r[1])[:25]:
+    hbm = (2 * m.get("FETCH_SIZE", 0) + m.get("WRITE_SIZE", 0)) / 1024.0
+    print(f"{name[:60]:60s} | {n:5d} | " + " | ".join(f"{m.get(k, float('nan')):.4g}" for k in keys) + f" | {hbm:.1f}")
