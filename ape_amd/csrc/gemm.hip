@@ -36,27 +36,49 @@ __device__ __forceinline__ void store_n(T* dst, const float* v, int cnt, bool ve
 
 // Epilogue arithmetic for 4 consecutive output columns n0..n0+3 (n0 % 4 == 0) of row m (m < M, n0 < N).
 // On return v[0..cnt) are the final values for output columns ocol..ocol+cnt (SwiGLU halves the column index).
+// p.vec_ok bits (launcher): 1 = C / residual rows allow 16-byte accesses, 2 = bias is 16-byte aligned,
+// 4 = RoPE tables 16-byte aligned, power-of-two head dim, rope_rows >= M or a power of two (masks replace the modulo).
+// For short-K GEMMs (the ViT at M = 4096) this code is as long as the main loop, so it is written for few VALU ops:
+// vector loads for bias / RoPE / residual, uniform conditions tested once per quad.
 __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0, float v[4], int& ocol, int& cnt) {
   const bool masked = p.rowmask != nullptr && p.rowmask[m] != 0;
+  const bool full = n0 + 3 < p.N;
+  if (p.alpha != 1.f) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x = v[r] * p.alpha;
-    if (masked && p.mask_mode == APE_MASK_ZERO_INPUT) x = 0.f;
-    if (p.bias != nullptr && n0 + r < p.N) x += p.bias[n0 + r];
-    v[r] = x;
+    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
+  }
+  if (masked && p.mask_mode == APE_MASK_ZERO_INPUT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = 0.f;
+  }
+  if (p.bias != nullptr) {
+    if ((p.vec_ok & 2) && full) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
+    }
   }
   if (p.rope_cos != nullptr && n0 < p.rope_cols) {
     const int hd = p.rope_hd;
-    const int d0 = n0 % hd;
-    const size_t trow = (size_t)(m % p.rope_rows) * hd + d0;
-    const float c0 = p.rope_cos[trow], c1 = p.rope_cos[trow + 1], c2 = p.rope_cos[trow + 2], c3 = p.rope_cos[trow + 3];
-    const float s0 = p.rope_sin[trow], s1 = p.rope_sin[trow + 1], s2 = p.rope_sin[trow + 2], s3 = p.rope_sin[trow + 3];
+    float c[4], sn[4];
+    if (p.vec_ok & 4) {
+      const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;   // rows >= M or a power of two
+      const size_t trow = (size_t)(m & rmask) * hd + (n0 & (hd - 1));
+      const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + trow), s4 = *reinterpret_cast<const float4*>(p.rope_sin + trow);
+      c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w; sn[0] = s4.x; sn[1] = s4.y; sn[2] = s4.z; sn[3] = s4.w;
+    } else {
+      const size_t trow = (size_t)(m % p.rope_rows) * hd + n0 % hd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { c[r] = p.rope_cos[trow + r]; sn[r] = p.rope_sin[trow + r]; }
+    }
     const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
     // t*cos + rotate_half(t)*sin with rotate_half pairs (2i,2i+1) -> (-x[2i+1], x[2i])
-    v[0] = x0 * c0 - x1 * s0;
-    v[1] = x1 * c1 + x0 * s1;
-    v[2] = x2 * c2 - x3 * s2;
-    v[3] = x3 * c3 + x2 * s3;
+    v[0] = x0 * c[0] - x1 * sn[0];
+    v[1] = x1 * c[1] + x0 * sn[1];
+    v[2] = x2 * c[2] - x3 * sn[2];
+    v[3] = x3 * c[3] + x2 * sn[3];
   }
   if (p.act == APE_ACT_SWIGLU) {
     // interleaved (gate, up) pairs -> N/2 output columns
@@ -68,16 +90,21 @@ __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0
     return;
   }
   ocol = n0;
-  cnt = (p.N - n0) < 4 ? (p.N - n0) : 4;
+  cnt = full ? 4 : (p.N - n0);
+  if (p.act == APE_ACT_RELU) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float x = act_fn(v[r], p.act);
-    if (p.clamp > 0.f) x = fminf(fmaxf(x, -p.clamp), p.clamp);
-    v[r] = x;
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if (p.act != APE_ACT_NONE) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r], p.act);
+  }
+  if (p.clamp > 0.f) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -p.clamp), p.clamp);
   }
   if (p.residual != nullptr) {
     const size_t roff = (size_t)m * p.ldr + n0;
-    const bool vec = p.vec_ok != 0;
+    const bool vec = (p.vec_ok & 1) != 0;
     float rv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.res_dt == APE_DT_F32) {
       const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
@@ -100,10 +127,10 @@ __device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float
   if (m >= p.M || n0 >= p.N) return;
   int ocol, cnt;
   epi_n4_values(p, m, n0, v, ocol, cnt);
-  const bool vec = p.vec_ok != 0 && cnt == 4;
+  const bool vec = (p.vec_ok & 1) != 0 && cnt == 4;
   const size_t off = (size_t)m * p.ldc + ocol;
   if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, vec);
-  else if (cnt == 2 && p.vec_ok) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = pack2bf(v[0], v[1]);
+  else if (cnt == 2 && (p.vec_ok & 1)) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = pack2bf(v[0], v[1]);
   else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, vec);
 }
 
@@ -119,8 +146,8 @@ __device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float
   epi_m4_values(p, n, v);
   const int cnt = (p.M - m0) < 4 ? (p.M - m0) : 4;
   const size_t off = (size_t)n * p.ldc + m0;
-  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, p.vec_ok != 0);
-  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, p.vec_ok != 0);
+  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
+  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -311,8 +338,9 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&
   const int cpr = tcols * esz / 16;
   const int per = 16 / esz;  // elements per chunk
   const int trows = TRANS ? BN : BM;
+  const int cpr_sh = __ffs(cpr) - 1;   // tile widths are 32/64/128 columns of 2 or 4 bytes: cpr is a power of two
   for (int cid = tid; cid < trows * cpr; cid += 256) {
-    const int lrow = cid / cpr, cc = cid % cpr;
+    const int lrow = cid >> cpr_sh, cc = cid & (cpr - 1);
     const int grow = orow0 + lrow;
     const int gcol = ocol0 + cc * per;
     if (grow >= out_rows || gcol >= out_cols) continue;
@@ -998,6 +1026,9 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   int vec = (p.ldc % 4 == 0) && (((uintptr_t)p.C) % 16 == 0);
   if (p.residual) vec = vec && (p.ldr % 4 == 0) && (((uintptr_t)p.residual) % 16 == 0);
   (void)esz_out; (void)esz_res;
+  if (p.bias != nullptr && ((uintptr_t)p.bias) % 16 == 0) vec |= 2;
+  if (p.rope_cos != nullptr && ((uintptr_t)p.rope_cos) % 16 == 0 && ((uintptr_t)p.rope_sin) % 16 == 0 &&
+      (p.rope_hd & (p.rope_hd - 1)) == 0 && (p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)) vec |= 4;
   p.vec_ok = vec;
   hipStream_t s = (hipStream_t)stream;
   if (p.in_dt == APE_DT_BF16) {
@@ -1014,7 +1045,8 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
                        (p.act != APE_ACT_SWIGLU || p.N % 4 == 0);
     const bool glds = v2_ok && !no_glds && p.K % GB_K == 0;
     static const int no_ring = getenv("APE_GEMM_NORING") ? atoi(getenv("APE_GEMM_NORING")) : 0;
-    static const int use_ring_always = getenv("APE_GEMM_RING") ? atoi(getenv("APE_GEMM_RING")) : 0;
+    const char* ring_env = getenv("APE_GEMM_RING");     // read per call so a probe can flip it
+    const int use_ring_always = ring_env ? atoi(ring_env) : 0;
     const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
     if (v2_ok) {
       static bool attr_done = false;

@@ -60,7 +60,8 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
     * K <= 512: 64x64 tiles always -- 32 KiB of LDS per workgroup lets 4-5 workgroups overlap on a CU, which is what
       a 4..16-iteration K loop needs (87296x2048x256: 369 vs 480 us; 900x256x256: 7 vs 20 us);
     * few output tiles: 64x64 tiles plus split-K up to ~256 workgroups (900x256x2048: 11 vs 38 us);
-    * one 128x128 tile per CU: 64x64 tiles for K <= 1024 (4096x1024x1024: 24 vs 29 us), split-K 2 for long K."""
+    * one 128x128 tile per CU: 64x64 tiles for K <= 1024 (4096x1024x1024: 26 vs 30 us; the transposed-output variant
+      prefers 128x128: 19 vs 21 us); long K stays on the 128x128 kernel unsplit (4096x1024x2752: 48 vs 50 us split)."""
     if dtype != torch.bfloat16 or K % 32 != 0:
         return 0, 1
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
@@ -70,11 +71,8 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
         return 1, 1
     if t128 < 96:
         return 1, (max(1, min(K // 512, 256 // t64)) if splittable else 1)
-    if t128 <= 256:
-        if K <= 1024:
-            return 1, 1
-        if splittable and K >= 2048:
-            return 0, 2
+    if t128 <= 256 and K <= 1024 and not trans_out:
+        return 1, 1
     return 0, 1
 
 

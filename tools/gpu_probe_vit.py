@@ -37,5 +37,8 @@ for name, N, K, kind in cases:
             except Exception as ex:
                 res[(t64, sk)] = float("nan")
     res["auto"] = bench(lambda: ops.gemm(a, w, b, **kw))
+    os.environ["APE_GEMM_RING"] = "1"
+    res["ring128"] = bench(lambda: ops.gemm(a, w, b, tile64=0, splitk=1, **kw))
+    os.environ["APE_GEMM_RING"] = "0"
     best = min(v for v in res.values() if v == v)
     print(f"{name:14s} N{N} K{K}: " + "  ".join(f"{k}={v:.1f}" for k, v in res.items()), f" best {2*M*N*K/best/1e6:.0f} TF", flush=True)
