@@ -145,6 +145,18 @@ __global__ __launch_bounds__(256) void paste_bits_kernel(const uint8_t* __restri
   auto at = [&](int yy, int xx) -> float { return (yy >= 0 && yy < P && xx >= 0 && xx < P) ? (float)img[yy * P + xx] : 0.f; };
   uint8_t* dst = out + ((size_t)q * Ho + y) * Wo + xb;
   uint8_t b[16];
+  {
+    // most pixels lie outside the detection's box: if no tap of this 16-pixel run can touch the P x P mask, store zeros
+    // (fx is monotonic in x for x1 > x0; degenerate boxes take the general path)
+    const float fxa = ((((float)xb + 0.5f - x0) / (x1 - x0) * 2.f - 1.f) + 1.f) * (float)P * 0.5f - 0.5f;
+    const float fxb = ((((float)(xb + 15) + 0.5f - x0) / (x1 - x0) * 2.f - 1.f) + 1.f) * (float)P * 0.5f - 0.5f;
+    const bool yout = iy1 < 0 || iy0 >= P;
+    const bool xout = (x1 > x0) && (fxb < -1.f || fxa >= (float)P);
+    if ((yout || xout) && xb + 16 <= Wo && (Wo % 16) == 0) {
+      *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int x = xb + i;

@@ -173,38 +173,60 @@ extern "C" int ape_hip_layernorm(const ApeLayerNormArgs* a, void* stream) {
 // ------------------------------------------------------------------------------------------
 #define GN_ROWS_PER_BLOCK 128
 
+// thread layout for C % 8 == 0: (C/8) column groups of 8 channels (one 16-byte access) x 256/(C/8) row lanes
 template <typename TX>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const TX* __restrict__ x, int ldx, int HW, int C, int G,
                                                          float* __restrict__ partial) {
-  __shared__ float sh[256];
+  __shared__ float sh[8 * 256 + 256];     // row-lane partials [<= 8][C], then per-column totals
   __shared__ float smean[64];
   const int t = threadIdx.x;
   const int cg = C / G;
   const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
   const int r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
   const int nrows = r1 - r0;
-  float s = 0.f;
-  if (t < C) for (int r = r0; r < r1; ++r) s += ldf<TX>(x + (size_t)r * ldx + t);
-  sh[t] = s;
-  __syncthreads();
-  if (t < G) {
-    float a = 0.f;
-    for (int j = 0; j < cg; ++j) a += sh[t * cg + j];
-    smean[t] = a / (float)(nrows * cg);
-  }
-  __syncthreads();
-  float q = 0.f;
-  if (t < C) {
-    const float m = smean[t / cg];
-    for (int r = r0; r < r1; ++r) { const float d = ldf<TX>(x + (size_t)r * ldx + t) - m; q = fmaf(d, d, q); }
-  }
-  sh[t] = q;
-  __syncthreads();
-  if (t < G) {
-    float a = 0.f;
-    for (int j = 0; j < cg; ++j) a += sh[t * cg + j];
-    partial[((size_t)blockIdx.x * G + t) * 2 + 0] = smean[t];
-    partial[((size_t)blockIdx.x * G + t) * 2 + 1] = a;
+  const bool vec = (C % 8 == 0) && (256 % (C / 8) == 0) && (256 / (C / 8) <= 8) && (ldx % 8 == 0) && (((uintptr_t)x) % 16 == 0);
+  const int ncg = vec ? C / 8 : 0, nrl = vec ? 256 / ncg : 0;
+  const int cgi = vec ? t % ncg : 0, rl = vec ? t / ncg : 0;
+  float* tot = sh + 8 * 256;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (vec) {
+      float a[8];
+      float mu[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { a[c] = 0.f; mu[c] = pass ? smean[(cgi * 8 + c) / cg] : 0.f; }
+      for (int r = r0 + rl; r < r1; r += nrl) {
+        float v[8];
+        ld8<TX>(x + (size_t)r * ldx + cgi * 8, v);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float d = v[c] - mu[c]; a[c] += pass ? d * d : d; }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) sh[rl * 256 + cgi * 8 + c] = a[c];
+      __syncthreads();
+      if (t < C) {
+        float z = 0.f;
+        for (int k = 0; k < nrl; ++k) z += sh[k * 256 + t];
+        tot[t] = z;
+      }
+    } else {
+      float z = 0.f;
+      if (t < C) {
+        const float m = pass ? smean[t / cg] : 0.f;
+        for (int r = r0; r < r1; ++r) { const float d = ldf<TX>(x + (size_t)r * ldx + t) - m; z += pass ? d * d : d; }
+      }
+      tot[t] = z;
+    }
+    __syncthreads();
+    if (t < G) {
+      float z = 0.f;
+      for (int j = 0; j < cg; ++j) z += tot[t * cg + j];
+      if (pass == 0) smean[t] = z / (float)(nrows * cg);
+      else {
+        partial[((size_t)blockIdx.x * G + t) * 2 + 0] = smean[t];
+        partial[((size_t)blockIdx.x * G + t) * 2 + 1] = z;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -249,11 +271,42 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const TX* __restrict__ x,
                                                        int ldadd, TY* __restrict__ y, int ldy) {
   const int t = threadIdx.x;
   const int cg = C / G;
+  const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
+  const int r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
+  const bool vec = (C % 8 == 0) && (256 % (C / 8) == 0) && (ldx % 8 == 0) && (ldy % 8 == 0) && (((uintptr_t)x) % 16 == 0) &&
+                   (((uintptr_t)y) % 16 == 0) && (add == nullptr || (ldadd % 8 == 0 && ((uintptr_t)add) % 16 == 0));
+  if (vec) {
+    const int ncg = C / 8, nrl = 256 / ncg;
+    const int cgi = t % ncg, rl = t / ncg;
+    float wt[8], bt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = cgi * 8 + c;
+      const float m = stats[(ch / cg) * 2 + 0], rs = stats[(ch / cg) * 2 + 1];
+      wt[c] = w[ch] * rs; bt[c] = b[ch] - m * rs * w[ch];
+    }
+    for (int r = r0 + rl; r < r1; r += nrl) {
+      float v[8];
+      ld8<TX>(x + (size_t)r * ldx + cgi * 8, v);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = fmaf(v[c], wt[c], bt[c]);
+      if (add != nullptr) {
+        float av[8];
+        ld8<TA>(add + (size_t)r * ldadd + cgi * 8, av);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] += av[c];
+      }
+      if (act == APE_ACT_RELU) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      st8<TY>(y + (size_t)r * ldy + cgi * 8, v);
+    }
+    return;
+  }
   if (t >= C) return;
   const float m = stats[(t / cg) * 2 + 0], rs = stats[(t / cg) * 2 + 1];
   const float wt = w[t] * rs, bt = b[t] - m * rs * w[t];
-  const int r0 = blockIdx.x * GN_ROWS_PER_BLOCK;
-  const int r1 = min(r0 + GN_ROWS_PER_BLOCK, HW);
   for (int r = r0; r < r1; ++r) {
     float v = fmaf(ldf<TX>(x + (size_t)r * ldx + t), wt, bt);
     if (add != nullptr) v += ldf<TA>(add + (size_t)r * ldadd + t);
