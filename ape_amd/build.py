@@ -13,7 +13,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libape_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file); without it hipcc parks them in AGPRs and
+# the softmax / epilogue code pays a v_accvgpr_read/write per value (176 of ~500 VALU slots per attention key tile)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _sources():

@@ -29,7 +29,9 @@ __device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
   /* 4 chunks (64-byte rows) */ return row * 32 + ((c ^ (((row >> 3) & 1) << 1)) << 3);
 }
 
-template <int HD>
+// QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
+// workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
+template <int HD, int QT>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
@@ -44,13 +46,17 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   const bf16_t* Kp = reinterpret_cast<const bf16_t*>(p.K);
   const bf16_t* Vp = reinterpret_cast<const bf16_t*>(p.Vt);
 
-  // Q fragment (B operand of S^T = K.Q^T): query = frow, d = ks*32 + fq*8 .. +8
-  const int qrow = qblk * 64 + wave * 16 + frow;
-  const int qrow_c = qrow < N ? qrow : N - 1;
-  bf16x8_t qf[KSTEPS];
+  // Q fragments (B operand of S^T = K.Q^T): query = frow of tile u, d = ks*32 + fq*8 .. +8
+  int qrow[QT];
+  bf16x8_t qf[QT][KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks)
-    qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * N + qrow_c) * p.ldq + h * HD + ks * 32 + fq * 8));
+  for (int u = 0; u < QT; ++u) {
+    qrow[u] = qblk * (64 * QT) + (wave * QT + u) * 16 + frow;
+    const int qc = qrow[u] < N ? qrow[u] : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+      qf[u][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * N + qc) * p.ldq + h * HD + ks * 32 + fq * 8));
+  }
 
   // staging: K tile (64 keys x HD) and Vt tile (HD x 64 keys) go global -> LDS with global_load_lds (no VGPR round trip,
   // nothing for the compiler to spill: the register-staged version kept the prefetched tile in scratch and waited for
@@ -87,10 +93,19 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     }
   };
 
-  f32x4_t oacc[DT];
+  // lacc: the softmax denominator, accumulated by the matrix core as one more output tile of O^T = [V^T ; 1] P^T (an
+  // all-ones A operand needs no LDS read): sums the SAME bf16-rounded probabilities the numerator uses and takes 16 adds
+  // per key tile off the VALU, which bounds this kernel.
+  f32x4_t oacc[QT][DT], lacc[QT];
+  float m_run[QT];
+  const uint32_t one2 = 0x3f803f80u;   // (1.0bf16, 1.0bf16)
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(one2, one2, one2, one2));
 #pragma unroll
-  for (int d = 0; d < DT; ++d) oacc[d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int u = 0; u < QT; ++u) {
+    m_run[u] = -INFINITY; lacc[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < DT; ++d) oacc[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nt = (N + 63) / 64;
   issue(0, 0);
@@ -101,85 +116,99 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     const bf16_t* sK = &smem[buf][0];
     const bf16_t* sV = &smem[buf][64 * HD];
 
-    // S^T[key][query] for the 64 keys of this tile: 4 key tiles x KSTEPS
-    f32x4_t sacc[4];
+    // S^T[key][query] for the 64 keys of this tile: 4 key tiles x KSTEPS, every K fragment feeds QT MFMAs
+    f32x4_t sacc[QT][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      sacc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QT; ++u) sacc[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[swz_rows(i * 16 + frow, ks * 4 + fq, KC)]));
-        sacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[i], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][i], 0, 0, 0);
       }
     }
-    // running max on the RAW scores (scale > 0 commutes with max); keys >= N only exist in the last tile
+    // keys >= N only exist in the last tile
     if (t == nt - 1 && (N & 63) != 0) {
       const int kbase = t * 64 + fq * 4;
 #pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + i * 16 + r >= N) sacc[u][i][r] = -INFINITY;
+    }
+    uint4 pk[QT][2];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+      // running max on the RAW scores (scale > 0 commutes with max)
+      float mx = fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), fmaxf(sacc[u][0][2], sacc[u][0][3]));
+#pragma unroll
+      for (int i = 1; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(sacc[u][i][0], sacc[u][i][1]), fmaxf(sacc[u][i][2], sacc[u][i][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx * p.scale_log2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
+      // p = 2^(s * scale_log2 - m): one fma + one v_exp_f32 per score
+      float pv[4][4];
+#pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kbase + i * 16 + r >= N) sacc[i][r] = -INFINITY;
-    }
-    float mx = fmaxf(fmaxf(sacc[0][0], sacc[0][1]), fmaxf(sacc[0][2], sacc[0][3]));
+        for (int r = 0; r < 4; ++r) pv[i][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[u][i][r], p.scale_log2, -m_new));
+      m_run[u] = m_new;
+      // rescale only when some query of the wave raised its maximum (alpha == 1 exactly otherwise): after the first few
+      // key tiles this branch is rarely taken
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0ull) {
+        lacc[u][0] *= alpha; lacc[u][1] *= alpha; lacc[u][2] *= alpha; lacc[u][3] *= alpha;
 #pragma unroll
-    for (int i = 1; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(sacc[i][0], sacc[i][1]), fmaxf(sacc[i][2], sacc[i][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * p.scale_log2);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    // p = 2^(s * scale_log2 - m): one fma + one v_exp_f32 per score
-    float pv[4][4];
-    float rs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[i][r], p.scale_log2, -m_new));
-        pv[i][r] = e;
-        rs += e;
+        for (int d = 0; d < DT; ++d) {
+          oacc[u][d][0] *= alpha; oacc[u][d][1] *= alpha; oacc[u][d][2] *= alpha; oacc[u][d][3] *= alpha;
+        }
       }
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      oacc[d][0] *= alpha; oacc[d][1] *= alpha; oacc[d][2] *= alpha; oacc[d][3] *= alpha;
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pk[u][s2].x = pack2bf(pv[2 * s2][0], pv[2 * s2][1]);
+        pk[u][s2].y = pack2bf(pv[2 * s2][2], pv[2 * s2][3]);
+        pk[u][s2].z = pack2bf(pv[2 * s2 + 1][0], pv[2 * s2 + 1][1]);
+        pk[u][s2].w = pack2bf(pv[2 * s2 + 1][2], pv[2 * s2 + 1][3]);
+      }
     }
     // O^T[d][query] += Vt[d][key] P^T[key][query]; k-step s covers key tiles 2s, 2s+1 with the permuted
-    // in-step order e<4 -> key (2s)*16 + fq*4 + e ; e>=4 -> key (2s+1)*16 + fq*4 + (e-4)
+    // in-step order e<4 -> key (2s)*16 + fq*4 + e ; e>=4 -> key (2s+1)*16 + fq*4 + (e-4); every V fragment feeds QT MFMAs
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      uint4 pk;
-      pk.x = pack2bf(pv[2 * s][0], pv[2 * s][1]);
-      pk.y = pack2bf(pv[2 * s][2], pv[2 * s][3]);
-      pk.z = pack2bf(pv[2 * s + 1][0], pv[2 * s + 1][1]);
-      pk.w = pack2bf(pv[2 * s + 1][2], pv[2 * s + 1][3]);
-      const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pk);
+    for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+      for (int u = 0; u < QT; ++u)
+        lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pk[u][s2]), lacc[u], 0, 0, 0);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const int row = d * 16 + frow;
         // keys (2s)*16 + fq*4 .. +4 : byte offset in the 128-byte row = s*64 + fq*8 -> chunk s*4 + (fq>>1)
-        const int o0 = swz_rows(row, s * 4 + (fq >> 1), 8) + (fq & 1) * 4;
-        const int o1 = swz_rows(row, s * 4 + 2 + (fq >> 1), 8) + (fq & 1) * 4;
+        const int o0 = swz_rows(row, s2 * 4 + (fq >> 1), 8) + (fq & 1) * 4;
+        const int o1 = swz_rows(row, s2 * 4 + 2 + (fq >> 1), 8) + (fq & 1) * 4;
         uint4 vk;
         const uint2 a0 = *reinterpret_cast<const uint2*>(&sV[o0]);
         const uint2 a1 = *reinterpret_cast<const uint2*>(&sV[o1]);
         vk.x = a0.x; vk.y = a0.y; vk.z = a1.x; vk.w = a1.y;
-        oacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), pf, oacc[d], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < QT; ++u)
+          oacc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), __builtin_bit_cast(bf16x8_t, pk[u][s2]), oacc[u][d], 0, 0, 0);
       }
     }
     __syncthreads();
   }
-  // finish: total row sum over the 4 lanes sharing this query
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_run;
-  if (qrow < N) {
-    bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * N + qrow) * p.ldo + h * HD + fq * 4;
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      const float v[4] = {oacc[d][0] * inv, oacc[d][1] * inv, oacc[d][2] * inv, oacc[d][3] * inv};
-      st4<bf16_t>(o + d * 16, v);
+  for (int u = 0; u < QT; ++u) {
+    const float inv = 1.f / lacc[u][0];    // every row of the ones-tile holds the full sum over keys for query frow
+    if (qrow[u] < N) {
+      bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * N + qrow[u]) * p.ldo + h * HD + fq * 4;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
+        st4<bf16_t>(o + d * 16, v);
+      }
     }
   }
 }
@@ -262,14 +291,17 @@ extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk,
   p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H;
   p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid(ceil_div(N, 64), H, B);
+  dim3 grid(ceil_div(N, 64), H, B);
   if (dt == APE_DT_BF16) {
     APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "ape_hip_attention(bf16): ld alignment");
     APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 8 == 0,
                   "ape_hip_attention(bf16): pointer alignment");
     APE_CHECK_ARG(B == 1 || N % 8 == 0, "ape_hip_attention(bf16): batched windows need N %% 8 == 0");
-    if (HD == 64) hipLaunchKernelGGL(attn_bf16_kernel<64>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(attn_bf16_kernel<32>, grid, dim3(256), 0, s, p);
+    // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
+    const bool big = (size_t)ceil_div(N, 128) * H * B >= 512;
+    if (big) grid.x = ceil_div(N, 128);
+    if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p); }
+    else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
   } else {
     if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
