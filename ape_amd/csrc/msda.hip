@@ -142,9 +142,130 @@ __global__ __launch_bounds__(256) void msda_kernel(const MsdaParams p) {
   st8<TO>(o, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused variant with QUAD-SHARED sampling arithmetic.  The 4 lanes of a (query, head) used to repeat the softmax and
+// the location / bilinear-corner arithmetic of all L*4 samples (the kernel is VALU bound: ~3000 instructions per wave).
+// Here lane `sub` evaluates only the samples of point `sub` (one per level): logit -> softmax weight (max / sum over
+// the quad with DPP), location, the 4 corner row indices and the 4 corner weights (attention weight folded in, 0 for
+// corners outside the level).  The gather loop then broadcasts (index, weight) of every corner across the quad with
+// DPP quad_perm moves -- 2 instructions per corner instead of ~15.  Memory access pattern is unchanged: per corner the
+// quad reads one 64-byte head row.
+// ---------------------------------------------------------------------------------------------------------------
+template <int P> __device__ __forceinline__ float quad_bcast_f(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), P * 0x55, 0xf, 0xf, true));
+}
+template <int P> __device__ __forceinline__ int quad_bcast_i(int v) { return __builtin_amdgcn_mov_dpp(v, P * 0x55, 0xf, 0xf, true); }
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }
+
+template <typename TV, int P, int L>
+__device__ __forceinline__ void quad_gather(const TV* __restrict__ vb, int ldv, const float (&cw)[L][4], const int (&ci)[L][4], int l,
+                                            float acc[8]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float w = quad_bcast_f<P>(cw[l][c]);
+    const int idx = quad_bcast_i<P>(ci[l][c]);
+    if (w != 0.f) corner_acc<TV>(vb, ldv, idx, w, acc);
+  }
+}
+
+template <typename TV, typename TO, int L>
+__global__ __launch_bounds__(256) void msda_fused_quad_kernel(const MsdaParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  int chunk;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    chunk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int batch = blockIdx.y;
+  const int g = lane >> 2, sub = lane & 3;
+  int qi = chunk * 8 + wave * 2 + (g >> 3);
+  const bool live = qi < p.Q;
+  qi = live ? qi : p.Q - 1;               // keep whole quads active for the DPP exchanges; the store is predicated
+  const int h = g & 7;
+  const size_t qg = (size_t)batch * p.Q + qi;
+  const TV* vb = reinterpret_cast<const TV*>(p.value) + (size_t)batch * p.S * p.ldv + h * MS_D + sub * 8;
+  constexpr int LP = L * MS_P;
+
+  // ---- phase 1: this lane's samples (point `sub` of every level)
+  const float* lg = p.offw + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
+  float wv[L];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int l = 0; l < L; ++l) { wv[l] = lg[l * MS_P + sub]; mx = fmaxf(mx, wv[l]); }
+  mx = fmaxf(mx, quad_xor1(mx));
+  mx = fmaxf(mx, quad_xor2(mx));
+  float sum = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) { wv[l] = expf(wv[l] - mx); sum += wv[l]; }
+  sum += quad_xor1(sum);
+  sum += quad_xor2(sum);
+  const float inv = 1.f / sum;
+  const float* of = p.offw + qg * p.ldoffw + h * LP * 2 + sub * 2;
+  const float* rf = p.ref + qg * L * p.refdim;
+  float cw[L][4];
+  int ci[L][4];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int H = p.H[l], W = p.W[l];
+    const float2 o = *reinterpret_cast<const float2*>(of + l * 8);
+    const float rx = rf[l * p.refdim], ry = rf[l * p.refdim + 1];
+    float lx, ly;
+    if (p.refdim == 2) {                       // loc = ref + off / (W, H)            (multi_scale_deform_attn.py:298-303)
+      lx = rx + o.x / (float)W; ly = ry + o.y / (float)H;
+    } else {                                   // loc = ref_xy + off / P * ref_wh / 2 (multi_scale_deform_attn.py:304-311)
+      const float rw = rf[l * p.refdim + 2], rh = rf[l * p.refdim + 3];
+      lx = rx + o.x / (float)MS_P * rw * 0.5f; ly = ry + o.y / (float)MS_P * rh * 0.5f;
+    }
+    const float aw = wv[l] * inv;
+    const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
+    const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+    const float hf = floorf(h_im), wf = floorf(w_im);
+    const int h_low = (int)hf, w_low = (int)wf;
+    const int h_high = h_low + 1, w_high = w_low + 1;
+    const float lh = h_im - hf, lw = w_im - wf;
+    const float hh = 1.f - lh, hw = 1.f - lw;
+    const bool t_ok = inside && h_low >= 0, b_ok = inside && h_high <= H - 1;
+    const bool l_ok = w_low >= 0, r_ok = w_high <= W - 1;
+    const int base = p.start[l];
+    cw[l][0] = (t_ok && l_ok) ? aw * hh * hw : 0.f; ci[l][0] = (t_ok && l_ok) ? base + h_low * W + w_low : 0;
+    cw[l][1] = (t_ok && r_ok) ? aw * hh * lw : 0.f; ci[l][1] = (t_ok && r_ok) ? base + h_low * W + w_high : 0;
+    cw[l][2] = (b_ok && l_ok) ? aw * lh * hw : 0.f; ci[l][2] = (b_ok && l_ok) ? base + h_high * W + w_low : 0;
+    cw[l][3] = (b_ok && r_ok) ? aw * lh * lw : 0.f; ci[l][3] = (b_ok && r_ok) ? base + h_high * W + w_high : 0;
+  }
+  // ---- phase 2: gather; (index, weight) of each corner broadcast from the lane that owns the sample's point
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    quad_gather<TV, 0, L>(vb, p.ldv, cw, ci, l, acc);
+    quad_gather<TV, 1, L>(vb, p.ldv, cw, ci, l, acc);
+    quad_gather<TV, 2, L>(vb, p.ldv, cw, ci, l, acc);
+    quad_gather<TV, 3, L>(vb, p.ldv, cw, ci, l, acc);
+  }
+  if (live) {
+    TO* o = reinterpret_cast<TO*>(p.out) + qg * p.ldout + h * MS_D + sub * 8;
+    st8<TO>(o, acc);
+  }
+}
+
 template <typename TV, typename TO, bool FUSED>
 static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
   const dim3 grid(ceil_div(p.Q, 8), B), block(256);
+  if (FUSED) {
+    switch (L) {
+      case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1>), grid, block, 0, s, p); return 0;
+      case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2>), grid, block, 0, s, p); return 0;
+      case 3: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 3>), grid, block, 0, s, p); return 0;
+      case 4: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 4>), grid, block, 0, s, p); return 0;
+      case 5: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 5>), grid, block, 0, s, p); return 0;
+      default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
+    }
+  }
   switch (L) {
     case 1: hipLaunchKernelGGL((msda_kernel<TV, TO, 1, FUSED>), grid, block, 0, s, p); break;
     case 2: hipLaunchKernelGGL((msda_kernel<TV, TO, 2, FUSED>), grid, block, 0, s, p); break;
