@@ -734,9 +734,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  const TW* w = W + (size_t)n * ldw;
+  // 4 elements per lane per step when the rows allow 16-byte (fp32) / 8-byte (bf16) accesses
+  const bool vec = (K % 4 == 0) && (ldw % 4 == 0) && (ldx % 4 == 0) && (((uintptr_t)W) % 16 == 0) && (((uintptr_t)x) % 16 == 0);
   for (int m = 0; m < M; ++m) {
+    const float* xr = x + (size_t)m * ldx;
     float s = 0.f;
-    for (int k = lane; k < K; k += 64) s = fmaf(x[(size_t)m * ldx + k], ldf<TW>(W + (size_t)n * ldw + k), s);
+    if (vec) {
+      for (int k = lane * 4; k < K; k += 256) {
+        float wv[4], xv[4];
+        ld4<TW>(w + k, wv);
+        ld4<float>(xr + k, xv);
+        s = fmaf(xv[0], wv[0], s); s = fmaf(xv[1], wv[1], s); s = fmaf(xv[2], wv[2], s); s = fmaf(xv[3], wv[3], s);
+      }
+    } else {
+      for (int k = lane; k < K; k += 64) s = fmaf(xr[k], ldf<TW>(w + k), s);
+    }
     s = wave_sum(s);
     if (lane == 0) out[(size_t)m * ldo + n] = s * alpha + (bias != nullptr ? bias[n] : 0.f);
   }

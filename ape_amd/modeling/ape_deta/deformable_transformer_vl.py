@@ -101,8 +101,8 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         out = query
         outp = (query.float() + query_pos.float()).to(dt)
         inter, inter_ref = [], []
+        _, ref_in = ops.box_refine(None, reference.contiguous(), vr4)      # reference * valid ratios per level (:203-210)
         for i, layer in enumerate(self.layers):
-            ref_in = (reference[:, None, :] * vr4[None]).contiguous()
             x1 = layer.attentions[0].forward_tokens(out, outp, dt, vt_buf)
             x2, x2p = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt, add=query_pos)
             x3 = layer.attentions[1].forward_tokens(x2p, x2, ref_in, geo.shapes, geo.starts, dt,
@@ -112,7 +112,7 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
             out, outp = ops.layernorm(x5, *layer.norm_params(2), out_dtype=dt, add=query_pos)
             if self.bbox_embed is not None:
                 tmp = self.bbox_embed[i].forward_tokens(out, dt, out_dtype=torch.float32)
-                reference = (tmp + G.inverse_sigmoid(reference)).sigmoid()
+                reference, ref_in = ops.box_refine(tmp, reference, vr4)           # (:232-246), one kernel
             inter.append(out)
             inter_ref.append(reference)
         return inter, inter_ref

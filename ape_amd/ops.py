@@ -496,3 +496,22 @@ def bilinear_resize(x, height, width):
     rc = _lib.load().ape_hip_bilinear_resize(_p(x), x.stride(0), x.stride(1), h, w, C, _p(out), height, width, _stream())
     _lib.check(rc, "ape_hip_bilinear_resize")
     return out
+
+
+def box_refine(delta, ref, vr4, eps=1e-3):
+    """Decoder box refinement: new_ref = sigmoid(delta + inverse_sigmoid(ref, eps)) (delta None -> new_ref = ref) and the
+    per-level MSDA reference ref_in[q, l, :] = new_ref[q, :] * vr4[l, :].  fp32 [Q,4] / [L,4] -> ([Q,4], [Q,L,4])."""
+    _dev(delta, ref, vr4)
+    if ref.dtype != torch.float32 or vr4.dtype != torch.float32 or not ref.is_contiguous() or not vr4.is_contiguous():
+        raise TypeError("ape_amd.ops.box_refine: ref / vr4 must be contiguous float32")
+    if delta is not None:
+        _rowmajor(delta, "delta")
+        if delta.dtype != torch.float32 or delta.shape != ref.shape:
+            raise TypeError("ape_amd.ops.box_refine: delta must be float32 [Q,4]")
+    Q, L = ref.shape[0], vr4.shape[0]
+    new_ref = torch.empty_like(ref) if delta is not None else ref
+    ref_in = torch.empty((Q, L, 4), dtype=torch.float32, device=ref.device)
+    rc = _lib.load().ape_hip_box_refine(_p(delta), _ld(delta) if delta is not None else 0, _p(ref), _p(vr4), L, Q, float(eps),
+                                        _p(new_ref) if delta is not None else None, _p(ref_in), _stream())
+    _lib.check(rc, "ape_hip_box_refine")
+    return new_ref, ref_in

@@ -252,6 +252,14 @@ int ape_hip_mask_upsample_sigmoid(const void* logits, int ldl, int in_dt, int h0
 int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, int w, int C, float* out, int H, int W,
                             void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Decoder box refinement (deformable_transformer_vl.py:203-210, 232-246):
+ * new_ref = sigmoid(delta + inverse_sigmoid(ref, eps)), ref_in[q, l, :] = new_ref[q, :] * vr4[l, :].
+ * delta may be NULL (new_ref = ref).  -- csrc/boxes.hip
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_box_refine(const float* delta, int ldd, const float* ref, const float* vr4, int L, int Q, float eps, float* new_ref,
+                       float* ref_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

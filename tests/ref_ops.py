@@ -331,3 +331,11 @@ def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):
 
 def bilinear_resize(x, height, width):
     return F.interpolate(x.float()[None], size=(height, width), mode="bilinear", align_corners=False)[0]
+
+
+def box_refine(delta, ref, vr4, eps=1e-3):
+    new_ref = ref
+    if delta is not None:
+        x = ref.clamp(min=0, max=1)
+        new_ref = (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()
+    return new_ref, (new_ref[:, None, :] * vr4[None]).contiguous()

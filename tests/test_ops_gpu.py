@@ -456,3 +456,18 @@ def test_semantic_kernels(ops, dt):
     e3 = relerr(ops.bilinear_resize(x[:, :33, :40], 20, 17), ref_ops.bilinear_resize(x[:, :33, :40], 20, 17))   # strided view, downscale
     print("semantic kernels", dt, e, e2, e3)
     assert e < (5e-3 if dt == torch.bfloat16 else 1e-5) and e2 < 1e-5 and e3 < 1e-5
+
+
+def test_box_refine(ops):
+    Q, L = 900, 5
+    g = torch.Generator().manual_seed(5)
+    ref = torch.rand(Q, 4, generator=g).to(DEV)
+    ref[0] = torch.tensor([0.0, 1.0, 1e-5, 0.99999])          # the eps clamps of inverse_sigmoid
+    big = rnd(Q, 8, seed=6) * 2.0
+    delta = big[:, 2:6]                                       # strided rows (ld 8)
+    vr4 = torch.rand(L, 4, generator=g).to(DEV)
+    for d in (delta, None):
+        got_ref, got_in = ops.box_refine(d, ref, vr4)
+        want_ref, want_in = ref_ops.box_refine(d, ref, vr4)
+        assert got_in.shape == (Q, L, 4)
+        assert relerr(got_ref, want_ref) < 1e-6 and relerr(got_in, want_in) < 1e-6
