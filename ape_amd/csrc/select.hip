@@ -51,54 +51,91 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-#define NMS_PF 16
-// segments: wave g scans candidates [seg[g], seg[g+1]) in order; valid[i]==0 candidates are skipped entirely.
-// The bit-matrix rows of chunk c+1 are fetched while chunk c is being decided (software pipelined).
-struct NmsRows { unsigned long long r0[NMS_PF], r1[NMS_PF]; };
-
-__device__ __forceinline__ void nms_load_rows(NmsRows& R, const unsigned long long* __restrict__ mask, int nw, int base, int s1,
-                                              int w0, int nws, int lane) {
+// segments: wave g scans candidates [seg[g], seg[g+1]) in index order; valid[i]==0 candidates are skipped entirely.
+// Chunked greedy scan, one 64-candidate word at a time:
+//   1. removed-word of the chunk = OR over the survivors of EARLIER chunks of their row's word for this chunk: lane j
+//      tests bit j of each earlier chunk's survivor mask and loads at most one word per earlier chunk -- all loads are
+//      independent, then a wave-wide OR (the one-candidate-per-step scan paid ~250 ns of load latency per candidate);
+//   2. lane j holds the word of row j that covers the chunk itself; the sequential part walks only over the candidates
+//      that SURVIVE (find-first-set on the alive mask, one uniform v_readlane per survivor).
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  unsigned lo = (unsigned)(v & 0xffffffffull), hi = (unsigned)(v >> 32);
 #pragma unroll
-  for (int u = 0; u < NMS_PF; ++u) {
-    const int i = base + u;
-    R.r0[u] = (i < s1 && lane < nws) ? mask[(size_t)i * nw + w0 + lane] : 0ull;
-    R.r1[u] = (i < s1 && lane + 64 < nws) ? mask[(size_t)i * nw + w0 + lane + 64] : 0ull;
-  }
+  for (int o = 32; o > 0; o >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, o, 64); hi |= (unsigned)__shfl_xor((int)hi, o, 64); }
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ __forceinline__ void nms_decide_rows(const NmsRows& R, int base, int s1, int w0, int lane, const uint8_t* __restrict__ valid,
-                                                uint8_t* __restrict__ keep, unsigned long long& rem0, unsigned long long& rem1) {
-#pragma unroll
-  for (int u = 0; u < NMS_PF; ++u) {
-    const int i = base + u;
-    if (i < s1) {  // wave-uniform
-      const int word = (i >> 6) - w0, bit = i & 63;
-      const unsigned long long rv = (word >= 64) ? rem1 : rem0;
-      const unsigned long long r = readlane64(rv, word & 63);   // `word` is wave-uniform: v_readlane, not a bpermute
-      const bool ok = (valid == nullptr) || (valid[i] != 0);
-      const bool kept = ok && !((r >> bit) & 1ull);
-      if (kept) { rem0 |= R.r0[u]; rem1 |= R.r1[u]; }
-      if (lane == 0) keep[i] = kept ? 1 : 0;
-    }
-  }
-}
-
-__global__ __launch_bounds__(64) void nms_scan_segments_kernel(const unsigned long long* __restrict__ mask, int nw,
-                                                               const int* __restrict__ seg, const uint8_t* __restrict__ valid,
-                                                               uint8_t* __restrict__ keep) {
-  const int lane = threadIdx.x;
+// USE_LDS: the segment's sub-matrix (rows s0..s1-1 x words w0..w1, 125 KiB for 1000 candidates) is first copied to LDS by
+// the whole workgroup (bulk, pipelined loads); the scan, which is a chain of dependent reads, then never waits on
+// global memory (with 5 waves on the GPU every such read used to be a ~2 us L2 miss).
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void nms_scan_segments_kernel(const unsigned long long* __restrict__ mask, int nw, int n,
+                                                                const int* __restrict__ seg, const uint8_t* __restrict__ valid,
+                                                                uint8_t* __restrict__ keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sub[];
   const int s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
   if (s1 <= s0) return;
-  const int w0 = s0 >> 6, w1 = (s1 - 1) >> 6;
-  const int nws = w1 - w0 + 1;  // <= 128 (checked by the launcher through max segment length)
-  unsigned long long rem0 = 0ull, rem1 = 0ull;
-  NmsRows A, B;
-  nms_load_rows(A, mask, nw, s0, s1, w0, nws, lane);
-  for (int base = s0; base < s1; base += 2 * NMS_PF) {
-    nms_load_rows(B, mask, nw, base + NMS_PF, s1, w0, nws, lane);
-    nms_decide_rows(A, base, s1, w0, lane, valid, keep, rem0, rem1);
-    nms_load_rows(A, mask, nw, base + 2 * NMS_PF, s1, w0, nws, lane);
-    nms_decide_rows(B, base + NMS_PF, s1, w0, lane, valid, keep, rem0, rem1);
+  const int w0 = s0 >> 6, w1 = (s1 - 1) >> 6;   // <= 128 words (checked by the launcher through max segment length)
+  const int nws = w1 - w0 + 1;
+  const int r_base = w0 * 64;                    // sub-matrix row 0 = candidate w0*64 (chunk aligned)
+  if (USE_LDS) {
+    const int nrows = (w1 + 1) * 64 - r_base;
+    for (int e = threadIdx.x; e < nrows * nws; e += 256) {
+      const int r = e / nws, w = e - r * nws;
+      const int row = r_base + r;
+      sub[e] = row < n ? mask[(size_t)row * nw + w0 + w] : 0ull;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  auto word = [&](int row, int c) -> unsigned long long {      // mask[row][c] for rows / words of this segment
+    if (USE_LDS) return sub[(size_t)(row - r_base) * nws + (c - w0)];
+    return mask[(size_t)(row < n ? row : n - 1) * nw + c];
+  };
+  unsigned long long kept0 = 0ull, kept1 = 0ull;   // lane w stores the survivor mask of chunk w0 + w (and w0 + w + 64)
+  for (int c = w0; c <= w1; ++c) {
+    // 1. what the survivors so far remove from this chunk
+    unsigned long long acc = 0ull;
+    for (int cp = w0; cp < c; cp += 8) {                           // 8 independent reads per step
+      unsigned long long t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int cq = cp + u;
+        const int cqc = cq < c ? cq : cp;                          // uniform; out-of-range steps re-read `cp` and are masked
+        const int rel = cqc - w0;
+        const unsigned long long km = readlane64(rel >= 64 ? kept1 : kept0, rel & 63);
+        const bool take = cq < c && ((km >> lane) & 1ull);
+        const unsigned long long v = word(cqc * 64 + lane, c);     // unconditional read, masked afterwards (predicated loads
+        t[u] = take ? v : 0ull;                                    //  made hipcc wait on each one)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc |= t[u];
+    }
+    // readfirstlane tells hipcc the value is wave-uniform, so the resolve loop below runs on the scalar unit
+    // (s_ff1 / s_andn2 + one v_readlane pair per survivor) instead of a ~20-instruction VALU chain per step
+    const unsigned long long remc = uniform64(wave_or64(acc));
+    // 2. resolve the chunk
+    const int i = c * 64 + lane;                                   // this lane's candidate
+    const bool in_seg = i >= s0 && i < s1;
+    const bool ok = in_seg && (valid == nullptr || valid[i] != 0);
+    const unsigned long long row_c = ok ? word(i, c) : 0ull;       // intra-chunk suppression word of row i
+    unsigned long long alive = __builtin_amdgcn_ballot_w64(ok) & ~remc;
+    unsigned long long kept = 0ull;
+    while (alive != 0ull) {                                        // uniform loop over the survivors of this chunk
+      const int j = __builtin_ctzll(alive);
+      kept |= 1ull << j;
+      alive &= ~(1ull << j);
+      alive &= ~readlane64(row_c, j);
+    }
+    if (in_seg) keep[i] = (uint8_t)((kept >> lane) & 1ull);
+    const int rel = c - w0;
+    if (lane == (rel & 63)) { if (rel >= 64) kept1 = kept; else kept0 = kept; }
   }
 }
 
@@ -149,8 +186,21 @@ extern "C" int ape_hip_nms_scan_segments(const uint64_t* mask, int n, const int*
                                          const uint8_t* valid, uint8_t* keep, void* stream) {
   APE_CHECK_ARG(mask && seg_offsets && keep && n > 0 && num_segments > 0, "ape_hip_nms_scan_segments: bad args");
   APE_CHECK_ARG(max_segment <= 126 * 64, "ape_hip_nms_scan_segments: segment longer than %d candidates", 126 * 64);
-  hipLaunchKernelGGL(nms_scan_segments_kernel, dim3(num_segments), dim3(64), 0, (hipStream_t)stream,
-                     (const unsigned long long*)mask, ceil_div(n, 64), seg_offsets, valid, keep);
+  // LDS copy of a segment's sub-matrix: (max_segment rounded out to chunks + 64) rows x (max_segment / 64 + 2) words
+  const size_t sub_rows = (size_t)(ceil_div(max_segment, 64) + 1) * 64, sub_words = (size_t)ceil_div(max_segment, 64) + 1;
+  const size_t lds = sub_rows * sub_words * 8;
+  if (lds <= 160 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute((const void*)nms_scan_segments_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(nms_scan_segments_kernel<true>, dim3(num_segments), dim3(256), lds, (hipStream_t)stream,
+                       (const unsigned long long*)mask, ceil_div(n, 64), n, seg_offsets, valid, keep);
+  } else {
+    hipLaunchKernelGGL(nms_scan_segments_kernel<false>, dim3(num_segments), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)mask, ceil_div(n, 64), n, seg_offsets, valid, keep);
+  }
   APE_CHECK_LAUNCH("ape_hip_nms_scan_segments");
   return 0;
 }

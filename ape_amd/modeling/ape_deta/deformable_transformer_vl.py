@@ -203,7 +203,11 @@ class DeformableDetrTransformerVL(nn.Module):
         ar = torch.arange(L, device=dev)
         counts = (lv[None, :] == ar[:, None]).sum(1)
         seg = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
-        keep_s = ops.nms_segments(bx[order].float().contiguous(), lv[order].to(torch.int32).contiguous(), seg, n, self.nms_thresh_enc)
+        # static bound on a level's segment: its own top-k plus the zero-score fillers the short levels borrow (all of
+        # which may come from one level); lets the scan kernel stage the segment's bit matrix in LDS when it fits
+        max_seg = min(n, k + sum(max(0, k - h * w) for h, w in geo.shapes))
+        keep_s = ops.nms_segments(bx[order].float().contiguous(), lv[order].to(torch.int32).contiguous(), seg, max_seg,
+                                  self.nms_thresh_enc)
         keep1 = torch.zeros(n, dtype=torch.bool, device=dev)
         keep1[o2] = keep_s.bool()                                     # flags in o1 (score) order
         cand1, lv1 = cand[o1], lv[o1]
