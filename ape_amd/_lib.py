@@ -28,6 +28,7 @@ class GemmArgs(Structure):
         ("rope_rows", c_int32), ("rope_hd", c_int32), ("rope_cols", c_int32), ("vec_ok", c_int32),
         ("alpha", c_float), ("clamp", c_float),
         ("splitk", c_int32), ("tile64", c_int32), ("workspace", c_void_p),
+        ("rowscale", c_void_p), ("rowshift", c_void_p), ("colvec", c_void_p),
     ]
 
 
@@ -56,6 +57,7 @@ SIGNATURES = {
     "ape_hip_sizeof_args": (c_int, [c_int]),
     "ape_hip_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "ape_hip_gemm_last_kernel": (c_char_p, []),
+    "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),
     "ape_hip_layernorm": (c_int, [POINTER(LayerNormArgs), c_void_p]),

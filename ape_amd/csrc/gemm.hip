@@ -47,6 +47,16 @@ __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
   }
+  if (p.rowscale != nullptr) {             // folded LayerNorm of the A operand: acc * rstd_m - rstd_m mean_m * rowsum(W')_n
+    const float rs = p.rowscale[m], sh = p.rowshift[m];
+    if ((p.vec_ok & 8) && full) {
+      const float4 c = *reinterpret_cast<const float4*>(p.colvec + n0);
+      v[0] = fmaf(v[0], rs, sh * c.x); v[1] = fmaf(v[1], rs, sh * c.y); v[2] = fmaf(v[2], rs, sh * c.z); v[3] = fmaf(v[3], rs, sh * c.w);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] = fmaf(v[r], rs, sh * p.colvec[n0 + r]);
+    }
+  }
   if (masked && p.mask_mode == APE_MASK_ZERO_INPUT) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = 0.f;
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams
     // raw fp32 partial tile -> workspace plane of this split; gemm_splitk_reduce_kernel finishes the job
     GemmParams q = p;
     q.C = p.workspace + (size_t)blockIdx.y * p.M * p.N;
-    q.ldc = p.N; q.out_dt = APE_DT_F32; q.bias = nullptr; q.residual = nullptr; q.rowmask = nullptr; q.rope_cos = nullptr;
+    q.ldc = p.N; q.out_dt = APE_DT_F32; q.bias = nullptr; q.residual = nullptr; q.rowmask = nullptr; q.rope_cos = nullptr; q.rowscale = nullptr;
     q.act = APE_ACT_NONE; q.alpha = 1.f; q.clamp = 0.f;
     if (nk <= 0) {
 #pragma unroll
@@ -1034,12 +1044,16 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(p.splitk <= 1 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: split-K is implemented for the bf16 kernel only");
   APE_CHECK_ARG(p.rope_cos == nullptr || (p.rope_sin != nullptr && p.rope_rows > 0 && p.rope_hd > 0 && p.rope_hd % 4 == 0),
                 "ape_hip_gemm: bad rope args");
+  APE_CHECK_ARG((p.rowscale == nullptr) == (p.rowshift == nullptr) && (p.rowscale == nullptr) == (p.colvec == nullptr),
+                "ape_hip_gemm: rowscale / rowshift / colvec go together");
+  APE_CHECK_ARG(p.rowscale == nullptr || (!p.trans_out && p.act != APE_ACT_SWIGLU), "ape_hip_gemm: folded LayerNorm needs a plain (non-transposed, non-SwiGLU) epilogue");
   const int esz_out = p.out_dt == APE_DT_F32 ? 4 : 2;
   const int esz_res = p.res_dt == APE_DT_F32 ? 4 : 2;
   int vec = (p.ldc % 4 == 0) && (((uintptr_t)p.C) % 16 == 0);
   if (p.residual) vec = vec && (p.ldr % 4 == 0) && (((uintptr_t)p.residual) % 16 == 0);
   (void)esz_out; (void)esz_res;
   if (p.bias != nullptr && ((uintptr_t)p.bias) % 16 == 0) vec |= 2;
+  if (p.colvec != nullptr && ((uintptr_t)p.colvec) % 16 == 0) vec |= 8;
   if (p.rope_cos != nullptr && ((uintptr_t)p.rope_cos) % 16 == 0 && ((uintptr_t)p.rope_sin) % 16 == 0 &&
       (p.rope_hd & (p.rope_hd - 1)) == 0 && (p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)) vec |= 4;
   p.vec_ok = vec;
@@ -1074,7 +1088,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
       }
       const char* nk_env = getenv("APE_GEMM_NOKRES");     // read per call so a probe can flip it
       const int no_kres = nk_env ? atoi(nk_env) : 0;
-      const bool kres = !no_kres && !no_glds && p.K == 256 && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
+      const bool kres = !no_kres && !no_glds && p.K == 256 && p.rowscale == nullptr && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
                         p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr && p.splitk <= 1 && p.ldc % 8 == 0 &&
                         (p.residual == nullptr || (p.res_dt == APE_DT_BF16 && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
       if (kres) {

@@ -349,3 +349,44 @@ extern "C" int ape_hip_groupnorm(const ApeGroupNormArgs* a, void* stream) {
   APE_CHECK_LAUNCH("ape_hip_groupnorm");
   return 0;
 }
+
+
+// per-row LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM, see ApeGemmArgs):
+// one wave per row, two passes (the second one re-reads the 5 KB row from L1/L2)
+template <typename TX>
+__global__ __launch_bounds__(256) void row_stats_kernel(const TX* __restrict__ x, int ldx, int M, int C, float eps,
+                                                        float* __restrict__ rowscale, float* __restrict__ rowshift) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const TX* xr = x + (size_t)row * ldx;
+  const int C8 = (ldx % 8 == 0 && ((uintptr_t)x) % 16 == 0) ? (C & ~7) : 0;
+  float s = 0.f;
+  for (int c = lane * 8; c < C8; c += 512) {
+    float v[8];
+    ld8<TX>(xr + c, v);
+    s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  }
+  for (int c = C8 + lane; c < C; c += 64) s += ldf<TX>(xr + c);
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+  for (int c = lane * 8; c < C8; c += 512) {
+    float v[8];
+    ld8<TX>(xr + c, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  }
+  for (int c = C8 + lane; c < C; c += 64) { const float d = ldf<TX>(xr + c) - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) { rowscale[row] = rstd; rowshift[row] = -mean * rstd; }
+}
+
+extern "C" int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, float eps, float* rowscale, float* rowshift,
+                                 void* stream) {
+  APE_CHECK_ARG(x && rowscale && rowshift && M > 0 && C > 0, "ape_hip_row_stats: bad args");
+  const dim3 grid(ceil_div(M, 4)), block(256);
+  if (dt == APE_DT_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, eps, rowscale, rowshift);
+  else hipLaunchKernelGGL(row_stats_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, M, C, eps, rowscale, rowshift);
+  APE_CHECK_LAUNCH("ape_hip_row_stats");
+  return 0;
+}

@@ -15,6 +15,8 @@ GEMMs over token-major maps (the pixel-shuffle and window orders are folded into
 import math
 from functools import partial
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -87,8 +89,9 @@ class Block(nn.Module):
             a, m = self.attn, self.mlp
             E = a.q_proj.weight.shape[0]
             hid = m.w1.weight.shape[0]
-            n12 = round_up(2 * hid, 4)
-            w12 = torch.zeros((n12, E), dtype=torch.float32, device=m.w1.weight.device)
+            hid_pad = round_up(hid, 64)
+            n12 = 2 * hid_pad          # zero (gate, up) rows beyond 2*hid: the fused SwiGLU epilogue writes exact zeros into the
+            w12 = torch.zeros((n12, E), dtype=torch.float32, device=m.w1.weight.device)   # K padding of the down projection
             w12[0:2 * hid:2] = m.w1.weight.detach().float()
             w12[1:2 * hid:2] = m.w2.weight.detach().float()
             b12 = torch.zeros((n12,), dtype=torch.float32, device=w12.device)
@@ -99,14 +102,28 @@ class Block(nn.Module):
                 bqk=torch.cat([a.q_bias.detach().float(), torch.zeros_like(a.q_bias, dtype=torch.float32)]).contiguous(),
                 wv=pack_matrix(a.v_proj.weight, dt), bv=f32(a.v_bias),
                 wproj=pack_matrix(a.proj.weight, dt), bproj=f32(a.proj.bias),
-                w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=round_up(max(hid, n12 // 2), 64),
+                w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=hid_pad,
                 w3=pack_matrix(m.w3.weight, dt, kpad=64), b3=f32(m.w3.bias),
+                **self._folded_subln(m, dt),
                 n1=(f32(self.norm1.weight), f32(self.norm1.bias), self.norm1.eps),
                 n2=(f32(self.norm2.weight), f32(self.norm2.bias), self.norm2.eps),
                 nin=(f32(a.inner_attn_ln.weight), f32(a.inner_attn_ln.bias), a.inner_attn_ln.eps),
                 nffn=(f32(m.ffn_ln.weight), f32(m.ffn_ln.bias), m.ffn_ln.eps),
             )
         return self._pack.get(self, dt, build)
+
+    @staticmethod
+    def _folded_subln(m, dt):
+        """bf16 production mode: the SwiGLU sub-LayerNorm (vit_eva_clip.py:129-131) is folded into the down projection,
+        LN(h) W3^T = rstd (h W'^T) - rstd mean rowsum(W') + W3 b_ln  with  W' = W3 diag(gamma)  (ApeGemmArgs.rowscale ...):
+        the 2730-wide activation is read once (statistics) instead of read + written + read again."""
+        if dt != torch.bfloat16 or not isinstance(m.ffn_ln, nn.LayerNorm) or os.environ.get("APE_NO_LNFOLD") == "1":
+            return {}
+        w3 = m.w3.weight.detach().float()
+        g, b = m.ffn_ln.weight.detach().float(), m.ffn_ln.bias.detach().float()
+        w3f = pack_matrix(w3 * g[None, :], dt, kpad=64)
+        return dict(w3f=w3f, c1=w3f.float().sum(dim=1).contiguous(),                 # row sums of the ROUNDED folded weight
+                    c2=(w3 @ b + m.w3.bias.detach().float()).contiguous())
 
     def forward_tokens(self, x, dt, rope, nwin, ntok_win, vt_buf, last=False):
         """x [N, E] fp32 residual stream (window-major). rope = (cos, sin, rows). Returns the new stream."""
@@ -126,6 +143,10 @@ class Block(nn.Module):
         xn = ops.layernorm(x, P["n2"][0], P["n2"][1], P["n2"][2], out_dtype=dt)
         hbuf = torch.empty((x.shape[0], P["hid_pad"]), dtype=dt, device=x.device)
         ops.gemm(xn, P["w12"], P["b12"], act=ops.ACT_SWIGLU, out=hbuf)
+        if "w3f" in P:
+            stats = ops.row_stats(hbuf[:, :P["hid"]], P["nffn"][2])
+            return ops.gemm(hbuf, P["w3f"], P["c2"], residual=x, rownorm=(stats[0], stats[1], P["c1"]),
+                            out_dtype=dt if last else torch.float32)
         hn = ops.layernorm(hbuf[:, :P["hid"]], P["nffn"][0], P["nffn"][1], P["nffn"][2], out_dtype=dt, cpad=P["hid_pad"])
         return ops.gemm(hn, P["w3"], P["b3"], residual=x, out_dtype=dt if last else torch.float32)
 

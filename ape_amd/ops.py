@@ -77,8 +77,11 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None):
     """C = epi(alpha * a @ w.T); see ApeGemmArgs in include/ape_hip.h for the epilogue order.
+
+    rownorm = (rowscale [M], rowshift [M], colvec [N]) fp32: acc * rowscale[m] + rowshift[m] * colvec[n] right after alpha
+    (a LayerNorm of `a` folded into this GEMM: statistics from `row_stats`, gamma folded into w, colvec = row sums of w).
 
     a [M,K], w [N,K] (same dtype).  rope = (cos, sin, rows, head_dim, cols).  trans_out returns C^T as
     [N, m_pad or M].  act=ACT_SWIGLU expects interleaved (gate, up) rows in w and returns N/2 columns.
@@ -121,6 +124,13 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         args.rope_cos, args.rope_sin = _f32vec(cos, "rope cos").data_ptr(), _f32vec(sin, "rope sin").data_ptr()
         args.rope_rows, args.rope_hd, args.rope_cols = rows, hd, cols
     args.alpha, args.clamp = float(alpha), float(clamp)
+    if rownorm is not None:
+        rs, sh, cv = rownorm
+        _dev(rs, sh, cv)
+        if rs.numel() != M or sh.numel() != M or cv.numel() != N:
+            raise ValueError("ape_amd.ops.gemm: rownorm = (rowscale [M], rowshift [M], colvec [N])")
+        args.rowscale, args.rowshift, args.colvec = (_f32vec(rs, "rowscale").data_ptr(), _f32vec(sh, "rowshift").data_ptr(),
+                                                     _f32vec(cv, "colvec").data_ptr())
     t64, sk = _auto_tiling(M, N, K, a.dtype, trans_out, act)
     if splitk is not None:
         sk = int(splitk)
@@ -132,6 +142,18 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         args.splitk, args.workspace = sk, ws.data_ptr()
     _lib.check(_lib.load().ape_hip_gemm(ctypes.byref(args), _stream()), "ape_hip_gemm")
     return out
+
+
+def row_stats(x, eps):
+    """LayerNorm statistics of the rows of x [M, C] (row-major view): (rstd [M], -mean*rstd [M]) fp32 -- the row terms of a
+    LayerNorm folded into the consuming GEMM (`gemm(..., rownorm=...)`)."""
+    _dev(x)
+    _rowmajor(x, "x")
+    M, C = x.shape
+    out = torch.empty((2, M), dtype=torch.float32, device=x.device)
+    rc = _lib.load().ape_hip_row_stats(_p(x), _ld(x), _dt(x), M, C, float(eps), _p(out[0]), _p(out[1]), _stream())
+    _lib.check(rc, "ape_hip_row_stats")
+    return out[0], out[1]
 
 
 def gemv(x, w, bias=None, alpha=1.0):

@@ -74,10 +74,21 @@ typedef struct ApeGemmArgs {
   int32_t splitk;
   int32_t tile64; /* 1: 64x64 block tiles (4x more blocks; for launches with few output tiles), needs K % 32 == 0 */
   float* workspace;
+  /* LayerNorm folded into the GEMM that consumes it (the SwiGLU sub-LN, vit_eva_clip.py:129-131): with W' = W diag(g),
+   * LN(h) W^T = rstd_m (h W'^T)[m,n] - rstd_m mean_m (sum_k W'[n,k]) + (W b_ln)[n].  The epilogue applies, right after
+   * alpha:  acc = acc * rowscale[m] + rowshift[m] * colvec[n]   (rowscale = rstd, rowshift = -rstd*mean from
+   * ape_hip_row_stats, colvec = row sums of W'; the constant term travels in `bias`).  All three NULL = off. */
+  const float* rowscale;
+  const float* rowshift;
+  const float* colvec;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */
 const char* ape_hip_gemm_last_kernel(void);
+
+/* per-row LayerNorm statistics of x [M, C] (row stride ldx): rowscale[m] = rsqrt(var_m + eps), rowshift[m] = -mean_m * rowscale[m]
+ * (biased variance, two passes) -- the row terms of the folded LayerNorm above.  -- csrc/norm.hip */
+int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, float eps, float* rowscale, float* rowshift, void* stream);
 
 /* out[m][n] = alpha * x[m,:] . W[n,:] + bias[n], fp32 x/out, W f32 or bf16; for M <= a few rows
  * (the L=1 language side of ape/layers/fuse_helper.py:70-73,160-161). */

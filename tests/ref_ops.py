@@ -33,10 +33,13 @@ def _rotate_half(x):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None):
     M, K = a.shape
     N = w.shape[0]
     x = (a.float() @ w.float().t()) * alpha
+    if rownorm is not None:
+        rs, sh, cv = rownorm
+        x = x * rs.float()[:, None] + sh.float()[:, None] * cv.float()[None, :]
     rm = rowmask.bool() if rowmask is not None else None
     if rm is not None and mask_mode == MASK_ZERO_INPUT:
         x = x.masked_fill(rm[:, None], 0.0)
@@ -72,6 +75,13 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         out[:, : x.shape[1]] = x.to(odt)
         return out
     return x.to(odt)
+
+
+def row_stats(x, eps):
+    xf = x.float()
+    mean = xf.mean(dim=1)
+    rstd = torch.rsqrt(xf.var(dim=1, unbiased=False) + eps)
+    return rstd, -mean * rstd
 
 
 def gemv(x, w, bias=None, alpha=1.0):

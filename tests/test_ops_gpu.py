@@ -471,3 +471,35 @@ def test_box_refine(ops):
         want_ref, want_in = ref_ops.box_refine(d, ref, vr4)
         assert got_in.shape == (Q, L, 4)
         assert relerr(got_ref, want_ref) < 1e-6 and relerr(got_in, want_in) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_folded_layernorm(ops, dtype):
+    """row_stats + gemm(rownorm=...) == LayerNorm(h) @ W^T + b  (the SwiGLU sub-LN folded into the down projection)"""
+    M, C, Cp, N = 1000, 2730, 2752, 1024
+    h = torch.zeros(M, Cp)
+    h[:, :C] = torch.randn(M, C, generator=torch.Generator().manual_seed(1)) * 2.0 + 0.3
+    h = h.to(dtype).to(DEV)
+    g = (1.0 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))).to(DEV)
+    b = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(3))).to(DEV)
+    w = (torch.randn(N, C, generator=torch.Generator().manual_seed(4)) / C ** 0.5).to(DEV)
+    bias = rnd(N, seed=5)
+    res = rnd(M, N, seed=6)
+    eps = 1e-6
+    rs, sh = ops.row_stats(h[:, :C], eps)
+    rrs, rsh = ref_ops.row_stats(h[:, :C], eps)
+    assert relerr(rs, rrs) < 1e-5 and relerr(sh, rsh) < 1e-4
+    wf = torch.zeros(N, Cp, device=DEV)
+    wf[:, :C] = w * g[None, :]
+    wf = wf.to(dtype)
+    c1 = wf.float().sum(1).contiguous()
+    c2 = (w @ b + bias).contiguous()
+    got = ops.gemm(h, wf, c2, residual=res, rownorm=(rs, sh, c1), out_dtype=torch.float32)
+    want = torch.nn.functional.layer_norm(h[:, :C].float(), (C,), g, b, eps) @ w.t() + bias + res
+    e = relerr(got, want)
+    print(f"folded LayerNorm GEMM {dtype}: {e:.3e}")
+    assert e < (1.5e-2 if dtype == torch.bfloat16 else 1e-4)
+    # split-K path applies the row terms in the reduce kernel only
+    if dtype == torch.bfloat16:
+        got2 = ops.gemm(h, wf, c2, residual=res, rownorm=(rs, sh, c1), out_dtype=torch.float32, splitk=2, tile64=0)
+        assert relerr(got2, got) < 1e-5
