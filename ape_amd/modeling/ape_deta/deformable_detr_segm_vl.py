@@ -440,6 +440,10 @@ class DeformableDETRSegmVL(nn.Module):
             t0 = time.perf_counter()
             image = inp["image"].to(self.device, non_blocking=True).float()
             feats, _, prompt = self.text_features(inp)
+            # detections kept per image (:183-194): 1 for referring expressions, else the configured number(s)
+            self.test_topk_per_image = 1 if prompt == "expression" else self.select_box_nums_for_evaluation
+            if self.select_box_nums_for_evaluation_list is not None:
+                self.test_topk_per_image = self.select_box_nums_for_evaluation_list[dataset_id]
             self.preprocess_time = time.perf_counter() - t0
             out = self.forward_single(image, feats, prompt=prompt, instance=do_inst, semantic=meta, detector_columns=cols)
             h, w = image.shape[-2:]

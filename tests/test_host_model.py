@@ -73,6 +73,19 @@ def test_semantic_branch_matches_oracle_and_reference(fake_ops):
     M.check_semantic(model, orc, image, text, gold, "cpu")
 
 
+def test_expression_prompt_keeps_one_detection(fake_ops):
+    """referring expressions: dense fusion like phrases, and exactly one detection per image (:183-194)"""
+    model, orc, image, text, gold = M.build_pair("tiny_phrase")
+    h, w = image.shape[-2:]
+    res = model([{"image": image, "height": h, "width": w, "text_features": text, "prompt": "expression"}])[0]["instances"]
+    oi = orc.forward(image, text, prompt="phrase")["instances"]
+    assert len(res.scores) == 1
+    assert abs(float(res.scores[0]) - float(oi["scores"][0])) < 1e-3 and int(res.pred_classes[0]) == int(oi["pred_classes"][0])
+    assert model.model_vision.test_topk_per_image == 1
+    model([{"image": image, "height": h, "width": w, "text_features": text, "prompt": "phrase"}])
+    assert model.model_vision.test_topk_per_image == model.model_vision.select_box_nums_for_evaluation
+
+
 def test_bf16_host_pipeline_reported(fake_ops):
     """T3: bf16 storage at the kernels' rounding points vs the fp32 oracle -- reported, loose bound"""
     model, orc, image, text, gold = M.build_pair("tiny_padded", dtype=torch.bfloat16)
