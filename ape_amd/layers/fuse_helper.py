@@ -131,14 +131,20 @@ class BiAttentionBlock(nn.Module):
         l_new = l_n + P["gl"] * dl
         return v_new, qp, l_new
 
-    def forward_tokens(self, x, lvl_pos, l, dt):
+    def forward_tokens(self, x, lvl_pos, l, dt, defer_language=False):
+        """-> (v_new, v_new + lvl_pos, l_new).  defer_language: l_new comes back as a handle whose .join() yields it -- in the
+        single-token path the language update only feeds the NEXT layer's fusion, so it runs as a parallel graph branch
+        next to this layer's deformable attention / FFN."""
         if l.shape[0] == 1:
-            return self.forward_tokens_single(x, lvl_pos, l, dt)
-        return self.forward_tokens_dense(x, lvl_pos, l, dt)
+            v_new, qp, ljob = self.forward_tokens_single(x, lvl_pos, l, dt)
+        else:
+            v_new, qp, l_new = self.forward_tokens_dense(x, lvl_pos, l, dt)
+            ljob = ops._Joined(l_new)
+        return (v_new, qp, ljob) if defer_language else (v_new, qp, ljob.join())
 
     def forward_tokens_single(self, x, lvl_pos, l, dt):
         """x [T,256] vision tokens, lvl_pos [T,256], l [1, l_dim] fp32 ->
-        (v_new [T,256], v_new + lvl_pos [T,256], l_new [1, l_dim])"""
+        (v_new [T,256], v_new + lvl_pos [T,256], handle of l_new [1, l_dim])"""
         P = self.packed(dt)
         a = self.attn
         l_n = ops.layernorm(l, P["lnl"][0], P["lnl"][1], P["lnl"][2], out_dtype=torch.float32)
@@ -147,16 +153,19 @@ class BiAttentionBlock(nn.Module):
         dv = ops.gemv(vl, P["wov"], P["bov"])                    # out_v_proj (softmax over one token == 1)
         gdv = (P["gv"] * dv[0]).contiguous()                     # gamma_v * delta_v [v_dim]
         v_new, qp = ops.layernorm(x, P["lnv"][0], (P["lnv"][1] + gdv).contiguous(), P["lnv"][2], out_dtype=dt, add=lvl_pos)
-        kh = k.view(a.num_heads, a.head_dim)
-        u = torch.einsum("hd,hdi->hi", kh, P["wv"])              # W_v,h^T k_h       [8, v_dim]
-        c = (P["bv"] * kh).sum(-1)                               # b_v,h . k_h       [8]
-        sbias = (a.scale * (c - u @ gdv)).contiguous()           # scores are taken on LN_v(v) = v_new - gdv
-        S = ops.gemm(v_new, u.to(dt).contiguous(), sbias, alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
-        pooled = ops.vl_pool(S, v_new) - gdv[None, :]            # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
-        ol = torch.einsum("hi,hdi->hd", pooled, P["wvv"]) + P["bvv"]   # values_v_proj per head   [8, hd]
-        dl = ops.gemv(ol.reshape(1, -1).contiguous(), P["wol"], P["bol"])
-        l_new = l_n + P["gl"] * dl
-        return v_new, qp, l_new
+
+        def language_side():
+            kh = k.view(a.num_heads, a.head_dim)
+            u = torch.einsum("hd,hdi->hi", kh, P["wv"])              # W_v,h^T k_h       [8, v_dim]
+            c = (P["bv"] * kh).sum(-1)                               # b_v,h . k_h       [8]
+            sbias = (a.scale * (c - u @ gdv)).contiguous()           # scores are taken on LN_v(v) = v_new - gdv
+            S = ops.gemm(v_new, u.to(dt).contiguous(), sbias, alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
+            pooled = ops.vl_pool(S, v_new) - gdv[None, :]            # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
+            ol = torch.einsum("hi,hdi->hd", pooled, P["wvv"]) + P["bvv"]   # values_v_proj per head   [8, hd]
+            dl = ops.gemv(ol.reshape(1, -1).contiguous(), P["wol"], P["bol"])
+            return l_n + P["gl"] * dl
+
+        return v_new, qp, ops.fork(language_side)
 
     def forward(self, v, l, attention_mask_v=None, attention_mask_l=None):
         """reference signature (fuse_helper.py:221-232); the text bank carries no mask (reduced tokens, :266/:303)"""

@@ -78,8 +78,9 @@ class SelfAttention(nn.Module):
         P = self.packed(dt)
         E, nh = self.embed_dim, self.num_heads
         hd = E // nh
+        vjob = ops.fork(lambda: ops.gemm(x, P["wv"], P["bv"], trans_out=True, out=vt_buf))   # parallel graph branch
         qk = ops.gemm(x_pos, P["wqk"], P["bqk"])
-        vt = ops.gemm(x, P["wv"], P["bv"], trans_out=True, out=vt_buf)
+        vt = vjob.join()
         o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=1, n=x.shape[0], heads=nh, head_dim=hd, scale=hd ** -0.5)
         return ops.gemm(o, P["wo"], P["bo"], residual=x, out_dtype=out_dtype or dt)
 

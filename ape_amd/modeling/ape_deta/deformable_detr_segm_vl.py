@@ -280,15 +280,38 @@ class DeformableDETRSegmVL(nn.Module):
         geo = self.geometry((h, w), level_shapes)
         t0 = time.perf_counter()
         src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
-        for i, f in enumerate(names):
+        def neck_level(i, f):
             wn, bn, gw, gb, groups, eps = P["neck"][i]
             t = ops.gemm(maps[f][0], wn, bn)
             ops.groupnorm(t, gw, gb, groups, eps, out=src[geo.starts[i]:geo.starts[i] + t.shape[0]])
+
+        jobs = [ops.fork(lambda i=i, f=f: neck_level(i, f)) for i, f in enumerate(names) if i > 0]   # small levels: parallel branches
+        neck_level(0, names[0])
+        for j in jobs:
+            j.join()
         if stages is not None:
             stages.update({k: v[0] for k, v in maps.items()})
             stages["enc_input"] = src
         l0 = self.fusion_tokens(text_feats, prompt)
-        tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages)
+        want_masks = instance and with_masks and self.test_mask_on
+        mask_job = []
+
+        def mask_features(memory):
+            # maskdino_mask_features (:728-750): lateral 1x1 + GN, + encoder memory of level 0, 3x3 + GN + ReLU, 1x1.
+            # Needs only p2 and the encoder memory: forked here, it overlaps proposal selection and the decoder.
+            H0, W0 = geo.shapes[0]
+            p2 = maps[self.mask_in_features[0]][0]
+            lat = ops.gemm(p2, P["lat"][0], None)
+            lat = ops.groupnorm(lat, P["lat"][1], P["lat"][2], P["lat"][3], P["lat"][4], add=memory[: H0 * W0])
+            y = ops.gemm(ops.im2col3x3(lat, None, H0, W0), P["outc"][0], None)
+            y = ops.groupnorm(y, P["outc"][1], P["outc"][2], P["outc"][3], P["outc"][4], act=ops.ACT_RELU)
+            return ops.gemm(y, P["maskc"], None)                                                      # [H0*W0, 256]
+
+        def after_encoder(memory):
+            if want_masks or semantic is not None:
+                mask_job.append(ops.fork(lambda: mask_features(memory)))
+
+        tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages, after_encoder=after_encoder)
         self.transformer_time = time.perf_counter() - t0
         t0 = time.perf_counter()
         # last decoder level only feeds inference (:519-524); "name" mode classifies against the RAW text bank (:446)
@@ -314,16 +337,8 @@ class DeformableDETRSegmVL(nn.Module):
                     det_logits[:, arg] = logits[:, arg]
             det = self.inference_single(det_logits, boxes, (h, w), geo.box_scale)
             out.update(det)
-        want_masks = instance and with_masks and self.test_mask_on
         if want_masks or semantic is not None:
-            # maskdino_mask_features (:728-750): lateral 1x1 + GN, + encoder memory of level 0, 3x3 + GN + ReLU, 1x1
-            H0, W0 = geo.shapes[0]
-            p2 = maps[self.mask_in_features[0]][0]
-            lat = ops.gemm(p2, P["lat"][0], None)
-            lat = ops.groupnorm(lat, P["lat"][1], P["lat"][2], P["lat"][3], P["lat"][4], add=tr["memory"][: H0 * W0])
-            y = ops.gemm(ops.im2col3x3(lat, None, H0, W0), P["outc"][0], None)
-            y = ops.groupnorm(y, P["outc"][1], P["outc"][2], P["outc"][3], P["outc"][4], act=ops.ACT_RELU)
-            mask_feat = ops.gemm(y, P["maskc"], None)                                                 # [H0*W0, 256]
+            mask_feat = mask_job[0].join()
             membed = self.mask_embed.forward_tokens(x, dt, out_dtype=dt)                              # [Q,256]
             if stages is not None:
                 stages.update(mask_features=mask_feat, mask_embed=membed)

@@ -44,16 +44,18 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
     def forward_tokens(self, x, geo, lvl_pos, l, dt, stages=None):
         """x [T,256], l [1, l_dim] fp32 -> (memory [T,256], l) -- reference loop :84-115"""
         for i, (vl, layer) in enumerate(zip(self.vl_layers, self.layers)):
-            v_new, qp, l = vl.b_attn.forward_tokens(x, lvl_pos, l, dt)
-            if stages is not None:
-                stages[f"enc{i}_fused_v"], stages[f"enc{i}_fused_l"] = v_new, l
+            # the language update feeds only the next layer's fusion: it runs as a parallel branch next to this layer's
+            # deformable attention and FFN and is joined at the end of the layer
+            v_new, qp, ljob = vl.b_attn.forward_tokens(x, lvl_pos, l, dt, defer_language=True)
             # BaseTransformerLayer ("self_attn", "norm", "ffn", "norm"): value = fused tokens (no pos), identity = same
             x1 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
                                                     mask=geo.mask_u8)
             x2 = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt)
             x3 = layer.ffns[0].forward_tokens(x2, dt)
             x = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
+            l = ljob.join()
             if stages is not None:
+                stages[f"enc{i}_fused_v"], stages[f"enc{i}_fused_l"] = v_new, l
                 stages[f"enc{i}_out"] = x
         if self.post_norm_layer is not None:
             x = ops.layernorm(x, f32(self.post_norm_layer.weight), f32(self.post_norm_layer.bias), self.post_norm_layer.eps, out_dtype=dt)
@@ -102,19 +104,27 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         outp = (query.float() + query_pos.float()).to(dt)
         inter, inter_ref = [], []
         _, ref_in = ops.box_refine(None, reference.contiguous(), vr4)      # reference * valid ratios per level (:203-210)
+        refjob = ops._Joined((reference, ref_in))
         for i, layer in enumerate(self.layers):
             x1 = layer.attentions[0].forward_tokens(out, outp, dt, vt_buf)
             x2, x2p = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt, add=query_pos)
+            reference, ref_in = refjob.join()                  # the previous layer's box head ran next to this self-attention
+            if i > 0:
+                inter_ref.append(reference)
             x3 = layer.attentions[1].forward_tokens(x2p, x2, ref_in, geo.shapes, geo.starts, dt,
                                                     value=value_all[:, i * E:(i + 1) * E])
             x4 = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
             x5 = layer.ffns[0].forward_tokens(x4, dt)
             out, outp = ops.layernorm(x5, *layer.norm_params(2), out_dtype=dt, add=query_pos)
             if self.bbox_embed is not None:
-                tmp = self.bbox_embed[i].forward_tokens(out, dt, out_dtype=torch.float32)
-                reference, ref_in = ops.box_refine(tmp, reference, vr4)           # (:232-246), one kernel
+                # box head (3-layer MLP) + refinement (:232-246) feed only the NEXT layer's cross-attention: parallel branch
+                def refine(i=i, out=out, reference=reference):
+                    tmp = self.bbox_embed[i].forward_tokens(out, dt, out_dtype=torch.float32)
+                    return ops.box_refine(tmp, reference, vr4)
+                refjob = ops.fork(refine)
             inter.append(out)
-            inter_ref.append(reference)
+        reference, _ = refjob.join()
+        inter_ref.append(reference)
         return inter, inter_ref
 
 
@@ -231,11 +241,15 @@ class DeformableDetrTransformerVL(nn.Module):
         return out[:nq]
 
     # ------------------------------------------------------------------ forward (:422-699), batch 1
-    def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None):
-        """src [T,256] neck output (token-major, levels concatenated), l [1, l_dim] fp32 fusion token(s)."""
+    def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None, after_encoder=None):
+        """src [T,256] neck output (token-major, levels concatenated), l [1, l_dim] fp32 fusion token(s).
+        after_encoder(memory): hook called as soon as the encoder memory exists (the caller forks the mask-feature branch
+        there, so that it runs next to the latency-bound selection + decoder)."""
         P = self.packed(dt)
         lvl_pos = self.lvl_pos(geo, dt)
         memory, l_out = self.encoder.forward_tokens(src, geo, lvl_pos, l, dt, stages)
+        if after_encoder is not None:
+            after_encoder(memory)
         # gen_encoder_output_proposals (:321-369): rows of padded / out-of-range anchors enter enc_output as zeros
         om = ops.gemm(memory, P["wenc"], P["benc"], rowmask=geo.invalid_u8, mask_mode=ops.MASK_ZERO_INPUT)
         om = ops.layernorm(om, *P["nenc"], out_dtype=dt)

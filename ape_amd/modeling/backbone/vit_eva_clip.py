@@ -132,8 +132,10 @@ class Block(nn.Module):
         nh = self.attn.num_heads
         hd = E // nh
         xn = ops.layernorm(x, P["n1"][0], P["n1"][1], P["n1"][2], out_dtype=dt)
+        # V^T on a parallel graph branch: two M = 4096 GEMMs fill the chip better together than one after the other
+        vjob = ops.fork(lambda: ops.gemm(xn, P["wv"], P["bv"], trans_out=True, out=vt_buf))
         qk = ops.gemm(xn, P["wqk"], P["bqk"], rope=(rope[0], rope[1], rope[2], hd, 2 * E))
-        vt = ops.gemm(xn, P["wv"], P["bv"], trans_out=True, out=vt_buf)
+        vt = vjob.join()
         if self.window_size > 0:
             o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=nwin, n=ntok_win, heads=nh, head_dim=hd, scale=hd ** -0.5)
         else:
@@ -375,19 +377,32 @@ class SimpleFeaturePyramid(Backbone):
         hw = P["hw"]
         x = self.net.forward_tokens(image, mean, std)          # [hw*hw, E] window-major
         out = {}
+        # The four scales only share the ViT output: stride 8 / 16 / 32 run as parallel graph branches next to the heavy
+        # stride-4 chain (their kernels are small launches that leave most of the chip idle).
+        def s3():
+            t = ops.gemm(x, P["s3_d0"][0], P["s3_d0"][1]).view(hw * hw * 4, -1)
+            return self._conv_ln_pair(t, P["perm3"], 2 * hw, 2 * hw, P["s3_c1"], P["s3_c3"], dt)
+
+        def s5():
+            t = ops.maxpool2x2(x, P["perm4"], hw, hw)
+            p5 = self._conv_ln_pair(t, None, hw // 2, hw // 2, P["s5_c1"], P["s5_c3"], dt)
+            return p5, (ops.gather_rows(p5, P["idx6"]) if self.top_block is not None else None)
+
+        j3 = ops.fork(s3)
+        j4 = ops.fork(lambda: self._conv_ln_pair(x, P["perm4"], hw, hw, P["s4_c1"], P["s4_c3"], dt))
+        j5 = ops.fork(s5)
         # stride 4: deconv -> LN -> GELU -> deconv -> 1x1+LN -> 3x3+LN   (rows stay in nested order until the im2col)
         t = ops.gemm(x, P["s2_d0"][0], P["s2_d0"][1])
         t = t.view(hw * hw * 4, -1)
         t = ops.layernorm(t, P["s2_ln"][0], P["s2_ln"][1], P["s2_ln"][2], out_dtype=dt, act=ops.ACT_GELU)
         t = ops.gemm(t, P["s2_d1"][0], P["s2_d1"][1]).view(hw * hw * 16, -1)
         out["p2"] = (self._conv_ln_pair(t, P["perm2"], 4 * hw, 4 * hw, P["s2_c1"], P["s2_c3"], dt), (4 * hw, 4 * hw))
-        t = ops.gemm(x, P["s3_d0"][0], P["s3_d0"][1]).view(hw * hw * 4, -1)
-        out["p3"] = (self._conv_ln_pair(t, P["perm3"], 2 * hw, 2 * hw, P["s3_c1"], P["s3_c3"], dt), (2 * hw, 2 * hw))
-        out["p4"] = (self._conv_ln_pair(x, P["perm4"], hw, hw, P["s4_c1"], P["s4_c3"], dt), (hw, hw))
-        t = ops.maxpool2x2(x, P["perm4"], hw, hw)
-        out["p5"] = (self._conv_ln_pair(t, None, hw // 2, hw // 2, P["s5_c1"], P["s5_c3"], dt), (hw // 2, hw // 2))
+        out["p3"] = (j3.join(), (2 * hw, 2 * hw))
+        out["p4"] = (j4.join(), (hw, hw))
+        p5, p6 = j5.join()
+        out["p5"] = (p5, (hw // 2, hw // 2))
         if self.top_block is not None:
-            out["p6"] = (ops.gather_rows(out["p5"][0], P["idx6"]), (hw // 4, hw // 4))
+            out["p6"] = (p6, (hw // 4, hw // 4))
         return out
 
     def forward(self, x):

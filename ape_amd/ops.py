@@ -5,6 +5,7 @@ PyTorch is used here only as the allocator / stream provider.  Every function la
 the library is missing -- there is no CPU or PyTorch fallback in the product path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -537,3 +538,48 @@ def box_refine(delta, ref, vr4, eps=1e-3):
                                         _p(new_ref) if delta is not None else None, _p(ref_in), _stream())
     _lib.check(rc, "ape_hip_box_refine")
     return new_ref, ref_in
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Fork / join of independent launch sequences.  Inside a hipGraph capture the side streams become parallel branches
+# of the graph, which the GPU executes concurrently (measured: 40 small GEMMs 219 -> 170 us, 4096x1024x1024 GEMM pairs
+# -25 %): the decoder / language-side kernels are latency bound and leave most CUs idle, and two M = 4096 GEMMs
+# together fill the chip better than one after the other.  Discipline: a branch starts behind everything the caller has
+# enqueued so far and the caller joins before it consumes the branch's outputs, so the caching allocator's per-stream
+# reuse stays safe.  APE_NO_FORK=1 (or no HIP device) runs the branches inline.
+# ------------------------------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+_FORK_DEPTH = [0]
+
+
+class _Joined:
+    def __init__(self, result, done=None, keep=None):
+        # `keep` (the branch closure, i.e. its input tensors) stays referenced until join(): the caller's stream must not
+        # recycle those blocks while the branch may still be reading them
+        self.result, self.done, self.keep = result, done, keep
+
+    def join(self):
+        if self.done is not None:
+            torch.cuda.current_stream().wait_event(self.done)
+            self.done = None
+        self.keep = None
+        return self.result
+
+
+def fork(fn):
+    """run fn() on a side stream, concurrent with whatever the caller enqueues next; returns a handle with .join()"""
+    if not torch.cuda.is_available() or os.environ.get("APE_NO_FORK") == "1":
+        return _Joined(fn())
+    dev = torch.cuda.current_device()
+    pool = _SIDE_STREAMS.setdefault(dev, [torch.cuda.Stream(device=dev) for _ in range(6)])
+    cur = torch.cuda.current_stream()
+    side = pool[_FORK_DEPTH[0] % len(pool)]
+    _FORK_DEPTH[0] += 1
+    start = torch.cuda.Event()
+    start.record(cur)
+    side.wait_event(start)
+    with torch.cuda.stream(side):
+        result = fn()
+        done = torch.cuda.Event()
+        done.record(side)
+    return _Joined(result, done, keep=fn)
