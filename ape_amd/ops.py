@@ -566,13 +566,30 @@ class _Joined:
         return self.result
 
 
-def fork(fn):
+_FORK_INLINE = [False]
+
+
+class inline_forks:
+    """context: nested ops.fork calls run inline (used when whole images are already parallel branches of one graph)"""
+
+    def __enter__(self):
+        self.prev = _FORK_INLINE[0]
+        _FORK_INLINE[0] = True
+
+    def __exit__(self, *exc):
+        _FORK_INLINE[0] = self.prev
+
+
+def fork(fn, force=False):
     """run fn() on a side stream, concurrent with whatever the caller enqueues next; returns a handle with .join()"""
-    if not torch.cuda.is_available() or os.environ.get("APE_NO_FORK") == "1":
+    if not torch.cuda.is_available() or os.environ.get("APE_NO_FORK") == "1" or (_FORK_INLINE[0] and not force):
         return _Joined(fn())
     dev = torch.cuda.current_device()
-    pool = _SIDE_STREAMS.setdefault(dev, [torch.cuda.Stream(device=dev) for _ in range(6)])
     cur = torch.cuda.current_stream()
+    # one pool of side streams PER PARENT stream: a branch's outputs are consumed by its parent, and the next branch on the
+    # same side stream starts behind the parent's position -- two pipelines forked from different parents (two images in
+    # flight inside one graph) must therefore never share side streams
+    pool = _SIDE_STREAMS.setdefault((dev, cur.cuda_stream), [torch.cuda.Stream(device=dev) for _ in range(8)])
     side = pool[_FORK_DEPTH[0] % len(pool)]
     _FORK_DEPTH[0] += 1
     start = torch.cuda.Event()

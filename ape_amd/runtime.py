@@ -12,6 +12,10 @@ Results leave the device through TWO slots (device staging + pinned host buffers
 writes straight into the slot's staging buffer; a copy stream then moves the slot to pinned memory behind an event.
 `submit()` enqueues an image and returns a ticket, `result(ticket)` waits for that slot's copy only -- so the ~2 ms
 PCIe transfer of one image overlaps the compute of the next.  `__call__` = result(submit(...)) is the synchronous form.
+
+`images_per_step = B > 1`: the forwards of B images are captured as PARALLEL BRANCHES of one graph (ops.fork), so the
+latency-bound phases of one image (proposal selection, decoder, NMS: mostly idle CUs) run next to the GEMM-heavy phases
+of another.  Every image still goes through the batch-1 pipeline; nothing is batched numerically.
 """
 from types import SimpleNamespace
 
@@ -21,11 +25,12 @@ import torch
 class GraphedForward:
     SLOTS = 2
 
-    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True):
+    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1):
         self.mv = model_vision
         self.use_graph = use_graph
         self.max_graphs = max_graphs
         self.with_masks = with_masks
+        self.B = int(images_per_step)
         self._graphs = {}
         self._copy_stream = None
 
@@ -43,19 +48,33 @@ class GraphedForward:
                          out["det_query"][:, None].float(), keep[:, None].float()], 1).contiguous()   # [k, 8]
         return rec, out.get("det_masks128"), boxes.contiguous()
 
-    def _build(self, image, text, height, width, prompt):
+    def _device_all(self, images, text, height, width, prompt):
+        """the B forwards: image 0 on the current stream, the others as forked branches"""
+        from . import ops
+        if len(images) == 1:
+            return [self._device_part(images[0], text, height, width, prompt)]
+        # whole images are the parallel branches; the finer-grained forks inside a forward run inline (nested fork/join
+        # made hipStreamEndCapture crash on this ROCm, and the image-level overlap already fills the idle phases)
+        with ops.inline_forks():
+            jobs = [ops.fork(lambda b=b: self._device_part(images[b], text, height, width, prompt), force=True)
+                    for b in range(1, len(images))]
+            outs = [self._device_part(images[0], text, height, width, prompt)]
+            return outs + [j.join() for j in jobs]
+
+    def _build(self, images, text, height, width, prompt):
         mv = self.mv
-        dev = image.device
+        dev = images[0].device
+        B = len(images)
         entry = SimpleNamespace()
-        entry.image = image.clone()
+        entry.images = [im.clone() for im in images]
         entry.text = text
         for _ in range(2):            # warm every cache (weight packing, geometry, text side) outside the capture
-            self._device_part(entry.image, text, height, width, prompt)
+            self._device_all(entry.images, text, height, width, prompt)
         torch.cuda.synchronize()
         if self.use_graph:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph):
-                entry.rec, entry.masks128, entry.boxes = self._device_part(entry.image, text, height, width, prompt)
+                entry.outs = self._device_all(entry.images, text, height, width, prompt)
         else:
             entry.graph = None
         k = mv.test_topk_per_image
@@ -63,10 +82,10 @@ class GraphedForward:
         entry.slots = []
         for _ in range(self.SLOTS):
             s = SimpleNamespace()
-            s.d_rec = torch.empty((k, 8), dtype=torch.float32, device=dev)
-            s.h_rec = torch.empty((k, 8), dtype=torch.float32, pin_memory=True)
-            s.d_masks = torch.empty((k, height, width), dtype=torch.uint8, device=dev) if has_masks else None
-            s.h_masks = torch.empty((k, height, width), dtype=torch.uint8, pin_memory=True) if has_masks else None
+            s.d_rec = torch.empty((B, k, 8), dtype=torch.float32, device=dev)
+            s.h_rec = torch.empty((B, k, 8), dtype=torch.float32, pin_memory=True)
+            s.d_masks = torch.empty((B, k, height, width), dtype=torch.uint8, device=dev) if has_masks else None
+            s.h_masks = torch.empty((B, k, height, width), dtype=torch.uint8, pin_memory=True) if has_masks else None
             s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
             s.busy = False
             entry.slots.append(s)
@@ -77,58 +96,75 @@ class GraphedForward:
     # ------------------------------------------------------------------ pipelined interface
     @torch.no_grad()
     def submit(self, image, text, height=None, width=None, prompt="name"):
-        """enqueue one image [3,h,w] (fp32, device) against the text bank [K, D] (device); returns a ticket.
-        At most SLOTS tickets may be outstanding per (size, vocabulary) entry."""
+        """enqueue one image [3,h,w] (fp32, device) -- or a list of `images_per_step` images of one size -- against the text
+        bank [K, D] (device); returns a ticket.  At most SLOTS tickets may be outstanding per (size, vocabulary) entry."""
         from . import ops
-        h, w = image.shape[-2:]
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        if len(images) != self.B:
+            raise ValueError(f"GraphedForward.submit: expected {self.B} image(s) per step, got {len(images)}")
+        h, w = images[0].shape[-2:]
+        if any(tuple(im.shape[-2:]) != (h, w) for im in images):
+            raise ValueError("GraphedForward.submit: the images of one step must share a size")
         height, width = height or h, width or w
         key = (h, w, height, width, text.data_ptr(), tuple(text.shape), prompt)
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.max_graphs:
                 self._graphs.pop(next(iter(self._graphs)))
-            e = self._graphs[key] = self._build(image, text, height, width, prompt)
+            e = self._graphs[key] = self._build(images, text, height, width, prompt)
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=image.device)
+            self._copy_stream = torch.cuda.Stream(device=images[0].device)
         s = e.slots[e.next_slot]
         if s.busy:
             raise RuntimeError("GraphedForward.submit: every result slot is outstanding -- call result() on an earlier ticket first")
         e.next_slot = (e.next_slot + 1) % self.SLOTS
         cur = torch.cuda.current_stream()
         if e.graph is not None:
-            e.image.copy_(image, non_blocking=True)
+            for buf, im in zip(e.images, images):
+                buf.copy_(im, non_blocking=True)
             e.graph.replay()
-            rec, masks128, boxes = e.rec, e.masks128, e.boxes
+            outs = e.outs
         else:
-            rec, masks128, boxes = self._device_part(image, text, height, width, prompt)
+            outs = self._device_all(images, text, height, width, prompt)
         cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
-        s.d_rec.copy_(rec, non_blocking=True)
-        if masks128 is not None and s.d_masks is not None:
-            ops.paste_bits(masks128, boxes, height, width, out=s.d_masks)     # detector_postprocess (:869-871), into the slot
+        has_masks = s.d_masks is not None and outs[0][1] is not None
+        for b, (rec, masks128, boxes) in enumerate(outs):
+            s.d_rec[b].copy_(rec, non_blocking=True)
+            if has_masks:
+                ops.paste_bits(masks128, boxes, height, width, out=s.d_masks[b])     # detector_postprocess (:869-871), into the slot
         s.computed.record(cur)
         with torch.cuda.stream(self._copy_stream):
             self._copy_stream.wait_event(s.computed)
             s.h_rec.copy_(s.d_rec, non_blocking=True)
-            if s.d_masks is not None and masks128 is not None:
+            if has_masks:
                 s.h_masks.copy_(s.d_masks, non_blocking=True)
             s.copied.record(self._copy_stream)
         s.busy = True
-        s.has_masks = masks128 is not None and s.d_masks is not None
-        return SimpleNamespace(entry=e, slot=s, rec6=s.d_rec[:, :6])
+        s.has_masks = has_masks
+        rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
+        return SimpleNamespace(entry=e, slot=s, rec6=rec6, single=not isinstance(image, (list, tuple)))
 
     def result(self, ticket):
-        """wait for the ticket's transfer; returns (instances on the host, device record view [k,6]).
-        pred_masks is a zero-copy view of the slot's pinned buffer: valid until SLOTS further submits."""
+        """wait for the ticket's transfer; returns (instances on the host, device record view [k,6]) -- lists / [B,k,6] when the
+        step was submitted as a list.  pred_masks is a zero-copy view of the slot's pinned buffer: valid until SLOTS further
+        submits."""
         e, s = ticket.entry, ticket.slot
         s.copied.synchronize()
         s.busy = False
         height, width = e.size
-        keep = s.h_rec[:, 7] > 0.5
-        inst = SimpleNamespace(image_size=(height, width), pred_boxes=s.h_rec[keep, :4].clone(), scores=s.h_rec[keep, 4].clone(),
-                               pred_classes=s.h_rec[keep, 5].long(), query_index=s.h_rec[keep, 6].long())
-        if s.has_masks:
-            inst.pred_masks = s.h_masks.view(torch.bool) if bool(keep.all()) else s.h_masks[keep].view(torch.bool)
-        return inst, ticket.rec6
+        insts = []
+        for b in range(self.B):
+            hr = s.h_rec[b]
+            keep = hr[:, 7] > 0.5
+            inst = SimpleNamespace(image_size=(height, width), pred_boxes=hr[keep, :4].clone(), scores=hr[keep, 4].clone(),
+                                   pred_classes=hr[keep, 5].long(), query_index=hr[keep, 6].long())
+            if s.has_masks:
+                hm = s.h_masks[b]
+                inst.pred_masks = hm.view(torch.bool) if bool(keep.all()) else hm[keep].view(torch.bool)
+            insts.append(inst)
+        if ticket.single:
+            return insts[0], ticket.rec6
+        return insts, ticket.rec6
 
     def __call__(self, image, text, height=None, width=None, prompt="name"):
         """synchronous form: image -> (instances on the host, device record [k,6])"""

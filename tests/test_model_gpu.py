@@ -126,3 +126,26 @@ def test_semantic_branch_on_gpu():
     """a22: second NMS, pixel-major sigmoid(upsample) kernel, class x query GEMM, bilinear resize -- fp32 kernels"""
     model, orc, image, text, gold, image_c, text_c = _run("tiny_semantic", torch.float32)
     M.check_semantic(model, orc, image_c, text_c, gold, "cuda")
+
+
+def test_parallel_images_in_one_graph():
+    """images_per_step = 2: two batch-1 forwards as parallel branches of one hipGraph give the same detections and masks
+    as two sequential single-image replays"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_padded", torch.float32)
+    image2 = torch.flip(image, dims=[2]).contiguous()
+    one = GraphedForward(model.model_vision)
+    ref = []
+    for im in (image, image2):
+        inst, _ = one(im, text)
+        ref.append((inst.pred_boxes.clone(), inst.scores.clone(), inst.pred_classes.clone(), inst.pred_masks.clone()))
+    two = GraphedForward(model.model_vision, images_per_step=2)
+    for _ in range(2):                                  # second call replays the captured graph
+        insts, rec6 = two([image, image2], text)
+    assert rec6.shape[0] == 2 and len(insts) == 2
+    for inst, (b, s, c, m) in zip(insts, ref):
+        frac = U.match_detections(inst.pred_boxes, inst.scores, inst.pred_classes, b, s, c)
+        assert frac >= 0.99, frac
+        assert inst.pred_masks.shape == m.shape
+        assert (inst.pred_masks != m).float().mean().item() < 1e-3
