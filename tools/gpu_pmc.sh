@@ -6,9 +6,11 @@ export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES"; do
+groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES")
+ngrp=${2:-3}
+for grp in "${groups[@]:0:$ngrp}"; do
   name=$(echo $grp | tr ' ' '+' | cut -c1-40)
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph > $out/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --images-per-step 1 > $out/$name.log 2>&1
   echo "pass [$grp] rc=$?"
 done
 cd $GRAFT_REPO_ROOT
