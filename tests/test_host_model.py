@@ -86,6 +86,39 @@ def test_expression_prompt_keeps_one_detection(fake_ops):
     assert model.model_vision.test_topk_per_image == model.model_vision.select_box_nums_for_evaluation
 
 
+def test_dataset_metadata_routes_the_branches(fake_ops):
+    """eval-dataset metadata decides which branches run and which class columns the detector sees (:575-590, 628-630,
+    654-663): a "stuff" dataset runs only the semantic branch; a thing+stuff dataset restricts the detector to the things"""
+    model, orc, image, text, gold = M.build_pair("tiny_semantic")
+    mv = model.model_vision
+    h, w = image.shape[-2:]
+    inp = [{"image": image, "height": h, "width": w, "text_features": text}]
+    mv.semantic_on = True
+    mv.dataset_names = ["stuffset", "mixed"]
+    mv.dataset_name_to_idx = {"stuffset": 0, "mixed": 1}
+    mv.dataset_prompts = ["name", "name"]
+    mv.set_metadata(0, name="stuffset_stuffonly", stuff_classes=["things"] + [f"s{i}" for i in range(9)])
+    mv.set_metadata(1, name="mixed", thing_classes=[f"t{i}" for i in range(6)], stuff_classes=["things"] + [f"s{i}" for i in range(4)])
+    mv.class_names = {0: [f"c{i}" for i in range(10)], 1: [f"c{i}" for i in range(10)]}
+    mv.stuff_prob_thing = 0.25
+    # stuff-only dataset: no instances, K semantic channels, channel 0 overwritten with logit(stuff_prob_thing)
+    mv.set_eval_dataset("stuffset")
+    assert mv.eval_dataset_entity == "stuff"
+    res = model(inp)[0]
+    assert set(res) == {"sem_seg"} and tuple(res["sem_seg"].shape) == (10, h, w)
+    assert torch.allclose(res["sem_seg"][0], torch.full((h, w), float(torch.logit(torch.tensor(0.25)))))
+    # thing+stuff dataset: detector restricted to the 6 thing columns, semantic collapses them into one channel
+    mv.set_eval_dataset("mixed")
+    assert mv.eval_dataset_entity == "thing+stuff"
+    res = model(inp)[0]
+    assert set(res) == {"instances", "sem_seg"} and tuple(res["sem_seg"].shape) == (5, h, w)
+    assert int(res["instances"].pred_classes.max()) < 6
+    oo = orc.forward(image, text, semantic=dict(entity="thing+stuff", thing_classes=[f"t{i}" for i in range(6)],
+                                                stuff_classes=["things"] + [f"s{i}" for i in range(4)]))
+    agree = (res["sem_seg"].argmax(0) == oo["sem_seg"].argmax(0)).float().mean().item()
+    assert agree > 0.99, agree
+
+
 def test_bf16_host_pipeline_reported(fake_ops):
     """T3: bf16 storage at the kernels' rounding points vs the fp32 oracle -- reported, loose bound"""
     model, orc, image, text, gold = M.build_pair("tiny_padded", dtype=torch.bfloat16)
