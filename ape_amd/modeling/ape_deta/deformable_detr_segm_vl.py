@@ -9,7 +9,6 @@ the semantic / panoptic tails are outside this round's hot path and raise NotImp
 Per image (batch 1, like the reference's evaluation) the whole forward is a fixed sequence of HIP kernel launches
 on the current stream with no host synchronisation until the final device->host copy of the detections.
 """
-import copy
 import math
 import time
 from types import SimpleNamespace

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import thirdparty as tp
-from .configs import swiglu_hidden, window_block_indexes
+from .configs import window_block_indexes
 
 PIXEL_MEAN = (123.675, 116.280, 103.530)  # ape_deta_r50.py:118-119
 PIXEL_STD = (58.395, 57.120, 57.375)

@@ -7,7 +7,6 @@ TEST INFRASTRUCTURE ONLY.  Two uses:
 Math is done in float32 on whatever device the inputs live on; outputs are rounded to the requested dtype
 exactly once, like the kernels.
 """
-import math
 
 import torch
 import torch.nn.functional as F

@@ -3,7 +3,6 @@ all-gather of fixed-size detection records.  The model runs on the torch definit
 import os
 import sys
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

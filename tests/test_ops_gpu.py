@@ -1,5 +1,4 @@
 """-m gpu parity tests: every HIP kernel (through the C-ABI) vs its torch fp32 definition (tests/ref_ops.py)."""
-import math
 
 import pytest
 import torch
