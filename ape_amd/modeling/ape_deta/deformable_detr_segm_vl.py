@@ -88,6 +88,9 @@ class DeformableDETRSegmVL(nn.Module):
         self.metadata_list = [self._resolve_metadata(m) for m in self.dataset_metas]
         self.dataset_entities = [self._entity_of(m) for m in self.metadata_list]
         self.stuff_prob_thing, self.semantic_post_nms = stuff_prob_thing, semantic_post_nms
+        self.panoptic_post_nms = panoptic_post_nms
+        self.panoptic_configs = panoptic_configs or {"prob": 0.1, "pano_temp": 0.06, "transform_eval": True,
+                                                     "object_mask_threshold": 0.01, "overlap_threshold": 0.4}   # (:80-86)
         self.dataset_name_to_idx = {k: i for i, k in enumerate(self.dataset_names)}
         self.class_names = {}                       # dataset name -> list[str]; filled by set_class_names (MetadataCatalog stand-in)
         self.eval_dataset_id, self.eval_dataset_entity = -1, ""
@@ -217,7 +220,10 @@ class DeformableDETRSegmVL(nn.Module):
             return batched_input["text_features"].to(self.device).float(), None, prompt
         if self.eval_dataset_id >= 0:
             prompt = self.dataset_prompts[self.eval_dataset_id]
-            names, cache = self.class_names[self.eval_dataset_id], True
+            names = self.class_names.get(self.eval_dataset_id)
+            if names is None:
+                names = self.text_list_of(self.metadata_list[self.eval_dataset_id], self.dataset_entities[self.eval_dataset_id])
+            cache = True
         else:
             prompt = batched_input.get("prompt", "name")
             if prompt == "text":
@@ -239,6 +245,19 @@ class DeformableDETRSegmVL(nn.Module):
             if not self.text_feature_reduce_before_fusion or "last_hidden_state_eot" not in out:
                 raise NotImplementedError("ape_amd: un-reduced text tokens (text_feature_reduce_before_fusion=False) are not implemented")
         return out["last_hidden_state_eot"].to(self.device).float(), names, prompt
+
+    @staticmethod
+    def text_list_of(meta, entity):
+        """get_text_list (deformable_detr_segm_vl.py:1229-1248): the class-name vocabulary of a dataset's metadata"""
+        thing, stuff = list(meta.get("thing_classes") or []), list(meta.get("stuff_classes") or [])
+        overlap = len(thing) > 0 and len(stuff) > 0 and (set(thing) <= set(stuff) or set(stuff) <= set(thing))
+        if entity == "thing+stuff" and stuff[0] == "things":
+            return thing + stuff[1:]
+        if entity == "thing+stuff" and overlap:
+            return thing if len(thing) > len(stuff) else stuff
+        if entity == "thing+stuff":
+            return thing + stuff
+        return stuff if entity == "stuff" else thing
 
     def fusion_tokens(self, text_feats, prompt):
         """the language tokens the encoder fuses with: the zero / learnable token in name mode (:349-352); in phrase /
@@ -264,7 +283,7 @@ class DeformableDETRSegmVL(nn.Module):
 
     # ------------------------------------------------------------------ the hot path, one image
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
-                       semantic=None, detector_columns=None):
+                       semantic=None, detector_columns=None, panoptic=False):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
         instance: run the detection branch; semantic: metadata dict (entity, thing_classes, stuff_classes) to run the
         semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes."""
@@ -307,7 +326,7 @@ class DeformableDETRSegmVL(nn.Module):
             return ops.gemm(y, P["maskc"], None)                                                      # [H0*W0, 256]
 
         def after_encoder(memory):
-            if want_masks or semantic is not None:
+            if want_masks or semantic is not None or panoptic:
                 mask_job.append(ops.fork(lambda: mask_features(memory)))
 
         tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages, after_encoder=after_encoder)
@@ -336,13 +355,28 @@ class DeformableDETRSegmVL(nn.Module):
                     det_logits[:, arg] = logits[:, arg]
             det = self.inference_single(det_logits, boxes, (h, w), geo.box_scale)
             out.update(det)
-        if want_masks or semantic is not None:
+        if want_masks or semantic is not None or panoptic:
             mask_feat = mask_job[0].join()
             membed = self.mask_embed.forward_tokens(x, dt, out_dtype=dt)                              # [Q,256]
             if stages is not None:
                 stages.update(mask_features=mask_feat, mask_embed=membed)
         if semantic is not None:
             out["sem_seg"] = self.semantic_single(logits, boxes, membed, mask_feat, geo, (h, w), semantic, dt, stages)
+        if panoptic:
+            # panoptic_post_nms (:677-685): a third class-wise NMS on ALL class columns picks the queries; their mask logits
+            # are upsampled to the padded input size (:569-572) and cropped to the image (sem_seg_postprocess, :942)
+            if self.panoptic_post_nms:
+                pdet = self.inference_single(logits, boxes, (h, w), geo.box_scale)
+                pq, pvalid = pdet["det_query"], pdet["det_scores"] >= 0
+            else:
+                pq = torch.arange(logits.shape[0], device=logits.device)
+                pvalid = torch.ones_like(pq, dtype=torch.bool)
+            H0, W0 = geo.shapes[0]
+            S = self.backbone.padding_constraints.get("square_size", 0)
+            pkept = ops.gather_rows(membed, pq.to(torch.int32))
+            plog = ops.gemm(pkept, mask_feat, None, out_dtype=torch.float32)                          # [k, H0*W0]
+            up = ops.bilinear_resize(plog.view(-1, H0, W0), S, S)
+            out.update(pan_masks=up[:, :h, :w], pan_cls=logits[pq], pan_valid=pvalid, pan_query=pq)
         if want_masks:
             H0, W0 = geo.shapes[0]
             # only the kept queries are decoded / upsampled: the einsum (:510) and F.interpolate (:569-572) act per query
@@ -431,8 +465,9 @@ class DeformableDETRSegmVL(nn.Module):
         if self.training:
             raise NotImplementedError("ape_amd implements the inference forward only")
         entity, dataset_id = self.eval_dataset_entity, self.eval_dataset_id
-        if self.panoptic_on and not (entity and "thing+stuff" not in entity):
-            raise NotImplementedError("ape_amd: the panoptic tail is not implemented (instance and semantic branches are)")
+        do_pan = self.panoptic_on and not (entity and "thing+stuff" not in entity)          # (:671-673)
+        if do_pan and not (0 <= dataset_id < len(self.metadata_list)):
+            raise RuntimeError("ape_amd: the panoptic branch needs an evaluation dataset with metadata (set_eval_dataset)")
         do_inst = self.instance_on and not (entity and "thing" not in entity)              # (:575-577)
         do_sem = self.semantic_on and not (entity and "stuff" not in entity)               # (:628-630)
         meta = None
@@ -459,7 +494,8 @@ class DeformableDETRSegmVL(nn.Module):
             if self.select_box_nums_for_evaluation_list is not None:
                 self.test_topk_per_image = self.select_box_nums_for_evaluation_list[dataset_id]
             self.preprocess_time = time.perf_counter() - t0
-            out = self.forward_single(image, feats, prompt=prompt, instance=do_inst, semantic=meta, detector_columns=cols)
+            out = self.forward_single(image, feats, prompt=prompt, instance=do_inst, semantic=meta, detector_columns=cols,
+                                      panoptic=do_pan)
             h, w = image.shape[-2:]
             height, width = inp.get("height", h), inp.get("width", w)
             res = {}
@@ -471,8 +507,59 @@ class DeformableDETRSegmVL(nn.Module):
                         and self.stuff_prob_thing > 0):                                    # (:654-663)
                     r[0] = math.log(self.stuff_prob_thing / (1 - self.stuff_prob_thing))
                 res["sem_seg"] = r
+            if do_pan:
+                res["panoptic_seg"] = self.postprocess_panoptic(out, height, width, self.metadata_list[dataset_id])
             results.append(res)
         return results
+
+    def postprocess_panoptic(self, out, height, width, meta):
+        """_postprocess_panoptic (:921-998): Mask2Former-style merge of the kept queries' masks.  The per-segment decisions
+        are data dependent and read back by the host, exactly like the reference's `.item()` loop; the pixel work (resize,
+        sigmoid, per-pixel argmax over queries, mask writes) stays on the device.  -> (panoptic_seg int32 [H,W], segments_info)"""
+        cfg = self.panoptic_configs
+        valid = out["pan_valid"]
+        mask_cls = out["pan_cls"][valid]
+        mask_pred = ops.bilinear_resize(out["pan_masks"], height, width)[valid]              # (:942) on the logits
+        scores, labels = mask_cls.sigmoid().max(-1)
+        mask_pred = mask_pred.sigmoid()
+        keep = scores > cfg["object_mask_threshold"]
+        if cfg["transform_eval"]:
+            scores, labels = torch.softmax(mask_cls.sigmoid() / cfg["pano_temp"], dim=-1).max(-1)
+        cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], mask_pred[keep]
+        panoptic_seg = torch.zeros((height, width), dtype=torch.int32, device=mask_pred.device)
+        segments_info = []
+        if cur_masks.shape[0] == 0:
+            return panoptic_seg, segments_info
+        cur_mask_ids = (cur_scores.view(-1, 1, 1) * cur_masks).argmax(0)
+        n = cur_classes.shape[0]
+        ids = torch.arange(n, device=cur_masks.device).view(-1, 1, 1)
+        own = cur_mask_ids[None] == ids                                                     # [n, H, W]
+        conf = cur_masks >= cfg["prob"]
+        mask_area = own.flatten(1).sum(1).tolist()                                          # one read-back for all segments
+        original_area = conf.flatten(1).sum(1).tolist()
+        both = own & conf
+        both_area = both.flatten(1).sum(1).tolist()
+        classes = cur_classes.tolist()
+        thing_ids = set((meta.get("thing_dataset_id_to_contiguous_id") or {}).values())
+        things_first = (meta.get("stuff_classes") or [""])[0] == "things"
+        current_segment_id, stuff_memory = 0, {}
+        for k in range(n):
+            pred_class = int(classes[k])
+            isthing = pred_class in thing_ids
+            if mask_area[k] > 0 and original_area[k] > 0 and both_area[k] > 0:
+                if mask_area[k] / original_area[k] < cfg["overlap_threshold"]:
+                    continue
+                if not isthing:
+                    if pred_class in stuff_memory:
+                        panoptic_seg[both[k]] = stuff_memory[pred_class]
+                        continue
+                    stuff_memory[pred_class] = current_segment_id + 1
+                current_segment_id += 1
+                panoptic_seg[both[k]] = current_segment_id
+                if not isthing and things_first:
+                    pred_class = pred_class - len(meta["thing_classes"]) + 1
+                segments_info.append({"id": current_segment_id, "isthing": bool(isthing), "category_id": int(pred_class)})
+        return panoptic_seg, segments_info
 
     def postprocess_instance(self, out, image_size, height, width):
         """detector_postprocess (:857-872): rescale to (height, width), clip, drop empty boxes, paste masks; the

@@ -543,9 +543,53 @@ class ApeOracle:
             r[0, ...] = math.log(p / (1 - p))                                     # (:654-663)
         return r
 
+    def panoptic_branch(self, logits, coord, pred_masks, padded_size, image_size, height, width, meta, cfg):
+        """panoptic_post_nms + _postprocess_panoptic (deformable_detr_segm_vl.py:671-695, 921-998): the kept queries'
+        masks are merged Mask2Former style.  meta carries thing_classes / stuff_classes / thing_dataset_id_to_contiguous_id."""
+        S = self.stages
+        _, _, _, qidx = self.inference(logits[0], coord[0], image_size)                         # third NMS, all K columns
+        S["pan_query"] = qidx
+        mask_cls = logits[0][qidx]
+        mask_pred = F.interpolate(pred_masks[:, qidx], size=padded_size, mode="bilinear", align_corners=False)[0]   # (:569-572)
+        mask_pred = tp.sem_seg_postprocess(mask_pred, image_size, height, width)                  # (:942) logits, crop + resize
+        scores, labels = mask_cls.sigmoid().max(-1)
+        mask_pred = mask_pred.sigmoid()
+        keep = scores > cfg["object_mask_threshold"]
+        if cfg["transform_eval"]:
+            scores, labels = F.softmax(mask_cls.sigmoid() / cfg["pano_temp"], dim=-1).max(-1)
+        cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], mask_pred[keep]
+        cur_prob_masks = cur_scores.view(-1, 1, 1) * cur_masks
+        panoptic_seg = torch.zeros((height, width), dtype=torch.int32)
+        segments_info = []
+        current_segment_id = 0
+        thing_ids = set((meta.get("thing_dataset_id_to_contiguous_id") or {}).values())
+        if cur_masks.size(0) > 0:
+            cur_mask_ids = cur_prob_masks.argmax(0)
+            stuff_memory = {}
+            for k in range(cur_classes.shape[0]):
+                pred_class = int(cur_classes[k])
+                isthing = pred_class in thing_ids
+                mask_area = int((cur_mask_ids == k).sum())
+                original_area = int((cur_masks[k] >= cfg["prob"]).sum())
+                mask = (cur_mask_ids == k) & (cur_masks[k] >= cfg["prob"])
+                if mask_area > 0 and original_area > 0 and int(mask.sum()) > 0:
+                    if mask_area / original_area < cfg["overlap_threshold"]:
+                        continue
+                    if not isthing:
+                        if pred_class in stuff_memory:
+                            panoptic_seg[mask] = stuff_memory[pred_class]
+                            continue
+                        stuff_memory[pred_class] = current_segment_id + 1
+                    current_segment_id += 1
+                    panoptic_seg[mask] = current_segment_id
+                    if not isthing and (meta.get("stuff_classes") or [""])[0] == "things":
+                        pred_class = pred_class - len(meta["thing_classes"]) + 1
+                    segments_info.append({"id": current_segment_id, "isthing": bool(isthing), "category_id": int(pred_class)})
+        return panoptic_seg, segments_info
+
     @torch.no_grad()
     def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True, prompt="name",
-                phrase_bank=256, semantic=None):
+                phrase_bank=256, semantic=None, detector_columns=None, panoptic=None):
         """prompt="phrase" (also "expression" with text_feature_reduce_before_fusion): the text bank, zero-padded to
         the phrase-bank size (:304-327 with text_feature_bank + text_feature_bank_reset), is FUSED with the vision
         tokens in the encoder and the fused tokens are the classifier's vocabulary (:356-358, 448)."""
@@ -588,7 +632,8 @@ class ApeOracle:
         pred_masks = torch.einsum("bqc,bchw->bqhw", membed, mask_feat)
         S["pred_logits"], S["pred_boxes"], S["pred_masks"] = logits, coord, pred_masks
         out = {"pred_logits": logits, "pred_boxes": coord, "pred_masks": pred_masks}
-        boxes, scores, classes, qidx = self.inference(logits[0], coord[0], (h, w))
+        det_logits = logits[0] if detector_columns is None else logits[0][:, :detector_columns]   # thing columns (:578-590)
+        boxes, scores, classes, qidx = self.inference(det_logits, coord[0], (h, w))
         S["det_boxes"], S["det_scores"], S["det_classes"], S["det_query"] = boxes, scores, classes, qidx
         masks128 = None
         if with_masks:
@@ -602,4 +647,7 @@ class ApeOracle:
         if semantic is not None:
             out["sem_seg"] = S["sem_seg"] = self.semantic_branch(logits, coord, pred_masks, images.shape[-2:], (h, w), height, width,
                                                                  semantic)
+        if panoptic is not None:
+            out["panoptic_seg"] = self.panoptic_branch(logits, coord, pred_masks, images.shape[-2:], (h, w), height, width,
+                                                       panoptic["meta"], panoptic["cfg"])
         return out

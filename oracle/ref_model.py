@@ -28,7 +28,7 @@ class _TextStub(nn.Module):
         return {"last_hidden_state_eot": self.feats[: len(text_list)].clone()}
 
 
-def build_reference(cfg, text_feats, semantic_on=False):
+def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panoptic_configs=None):
     refshim.install()
     import ape.layers as L
     import ape.modeling.ape_deta as A
@@ -72,10 +72,11 @@ def build_reference(cfg, text_feats, semantic_on=False):
         with_box_refine=True, as_two_stage=True, criterion=criterion, pixel_mean=[123.675, 116.280, 103.530],
         pixel_std=[58.395, 57.120, 57.375], select_box_nums_for_evaluation=c.topk_eval, input_format="RGB",
         mask_encode_level=0, mask_in_features=["p2"], input_shapes={f: refshim.ShapeSpec(channels=256) for f in feats},
-        output_dir=None, vis_period=0, embed_dim_language=1024, instance_on=True, semantic_on=semantic_on, panoptic_on=False,
+        output_dir=None, vis_period=0, embed_dim_language=1024, instance_on=True, semantic_on=semantic_on, panoptic_on=panoptic_on,
         text_feature_bank=True, text_feature_reduce_before_fusion=True, text_feature_batch_repeat=True,
         expression_cumulative_gt_class=True, name_prompt_fusion_type="zero", dataset_prompts=["name"],
         dataset_names=["coco"], dataset_metas=["coco_2017_val"], text_feature_bank_reset=True,
+        **({"panoptic_configs": panoptic_configs} if panoptic_configs is not None else {}),
     )
     model = A.SomeThing(model_vision=model_vision, model_language=_TextStub(text_feats))
     model.eval()

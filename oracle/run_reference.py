@@ -39,14 +39,21 @@ def spec_of(model):
     return [(k, list(v.shape)) for k, v in model.state_dict().items()]
 
 
-def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name", semantic=None):
+def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name", semantic=None,
+                  eval_dataset=False, panoptic_configs=None):
     """returns (stages dict, instances dict, spec).  prompt="phrase": class names with a space, which the reference
     routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337)."""
     cfg = CONFIGS[cfg_name]
     refshim.METADATA.clear()
     if semantic is not None:        # semantic branch on: the (only) dataset's metadata carries the thing / stuff split
-        refshim.METADATA["coco_2017_val"] = {k: semantic[k] for k in ("thing_classes", "stuff_classes") if semantic.get(k)}
-    model = ref_model.build_reference(cfg, text_feats, semantic_on=semantic is not None)
+        refshim.METADATA["coco_2017_val"] = {k: semantic[k] for k in ("thing_classes", "stuff_classes",
+                                                                     "thing_dataset_id_to_contiguous_id") if semantic.get(k)}
+    # eval_dataset: the model is pointed at its (only) dataset like the evaluators do (set_eval_dataset): class names come
+    # from the metadata (get_text_list), the detector sees the thing columns only, and the panoptic merge runs
+    model = ref_model.build_reference(cfg, text_feats, semantic_on=semantic is not None, panoptic_on=bool(eval_dataset),
+                                      panoptic_configs=panoptic_configs)
+    if eval_dataset:
+        model.model_vision.set_eval_dataset("coco_2017_val")
     spec = spec_of(model)
     sd = weights.make_state_dict(spec, seed)
     weights.load_into(model, sd)
@@ -74,6 +81,7 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         lambda m, a, kw: S.update({"query_init": kw["query"], "query_pos": kw["query_pos"]}), with_kwargs=True))
     hook(mv.transformer.enc_output_norm, "output_memory")
     hook(mv.mask_embed, "mask_embed")
+    hook(mv.class_embed[len(mv.transformer.decoder.layers) - 1], "pred_logits_full")   # all K columns (the detector may see fewer)
 
     tmod = sys.modules["ape.modeling.ape_deta.deformable_transformer_vl"]
     smod = sys.modules["ape.modeling.ape_deta.deformable_detr_segm_vl"]
@@ -88,10 +96,16 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         S["mask_features"] = out
         return out
 
+    calls = []
+
     def inf(box_cls, box_pred, image_sizes, use_sigmoid=True):
-        if "pred_logits" in S:      # second call = semantic_post_nms (:638-647)
+        calls.append(1)
+        if "pred_logits" in S:      # later calls: semantic_post_nms (:638-647), then panoptic_post_nms (:677-685)
             res, filt = old_inf(box_cls, box_pred, image_sizes, use_sigmoid=use_sigmoid)
-            S["sem_box_cls"], S["sem_query"] = box_cls, filt[0]
+            if semantic is not None and "sem_query" not in S:
+                S["sem_box_cls"], S["sem_query"] = box_cls, filt[0]
+            else:
+                S["pan_query"] = filt[0]
             return res, filt
         S["pred_logits"], S["pred_boxes"] = box_cls, box_pred
         res, filt = old_inf(box_cls, box_pred, image_sizes, use_sigmoid=use_sigmoid)
@@ -108,8 +122,10 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
     mv.maskdino_mask_features, mv.inference, smod.retry_if_cuda_oom = mf, inf, retry
     try:
         h, w = image.shape[-2:]
-        inputs = {"image": image, "height": height or h, "width": width or w, "prompt": "text",
-                  "text_prompt": ",".join((f"c {i}" if prompt == "phrase" else f"c{i}") for i in range(text_feats.shape[0]))}
+        inputs = {"image": image, "height": height or h, "width": width or w}
+        if not eval_dataset:
+            inputs.update(prompt="text", text_prompt=",".join((f"c {i}" if prompt == "phrase" else f"c{i}")
+                                                                for i in range(text_feats.shape[0])))
         with torch.no_grad():
             out = model([inputs])[0]
     finally:
@@ -119,6 +135,8 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
             hk.remove()
     if "sem_seg" in out:
         S["sem_seg"] = out["sem_seg"]
+    if "panoptic_seg" in out:
+        S["panoptic_seg"], S["segments_info"] = out["panoptic_seg"]
     inst = out["instances"]
     instances = {"pred_boxes": inst.pred_boxes.tensor, "scores": inst.scores, "pred_classes": inst.pred_classes,
                  "pred_masks": inst.pred_masks if inst.has("pred_masks") else None}

@@ -27,7 +27,11 @@ CASES = {
     "tiny_phrase": ("tiny", 2, 7, (224, 256), 6, 8, "phrase"),
     # semantic branch on (a22): 10 classes = 6 things + ("things", 4 stuff) -> 5 semantic channels; output resized x1.5
     "tiny_semantic": ("tiny", 3, 9, (208, 240), 10, 4, "name", "semantic"),
+    # evaluation-dataset mode (set_eval_dataset): names from the metadata, detector on the 6 thing columns, semantic AND
+    # panoptic branches on (panoptic thresholds loosened so that seeded weights produce segments)
+    "tiny_panoptic": ("tiny", 3, 9, (208, 240), 10, 21, "name", "semantic", "panoptic"),
 }
+PANOPTIC_CFG = dict(prob=0.45, pano_temp=0.06, transform_eval=True, object_mask_threshold=0.0, overlap_threshold=0.0)
 SEMANTIC_META = {"entity": "thing+stuff", "thing_classes": [f"t{i}" for i in range(6)],
                  "stuff_classes": ["things"] + [f"s{i}" for i in range(4)]}
 FULL_SEM = ("sem_seg", "sem_query", "sem_box_cls")
@@ -64,7 +68,11 @@ def main():
         sem = SEMANTIC_META if len(CASES[case]) > 7 else None
         h, w = image.shape[-2:]
         out_hw = (int(1.5 * h), int(1.5 * w)) if sem else (None, None)
-        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt, semantic=sem, height=out_hw[0], width=out_hw[1])
+        pan = len(CASES[case]) > 8
+        if pan:
+            sem = dict(sem, thing_dataset_id_to_contiguous_id={i + 1: i for i in range(len(sem["thing_classes"]))})
+        S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt, semantic=sem, height=out_hw[0], width=out_hw[1],
+                                            eval_dataset=pan, panoptic_configs=PANOPTIC_CFG if pan else None)
         with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
             json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
@@ -76,6 +84,12 @@ def main():
         if sem:
             gold["semantic_meta"], gold["out_hw"] = sem, out_hw
             gold["full"]["sem_seg_argmax"] = S["sem_seg"].argmax(0).to(torch.uint8)      # [H, W] labels
+        if pan:
+            gold["panoptic_cfg"] = PANOPTIC_CFG
+            gold["full"]["panoptic_seg"] = S["panoptic_seg"].to(torch.int16)
+            gold["full"]["pan_query"] = S["pan_query"].clone()
+            gold["full"]["pred_logits_full"] = S["pred_logits_full"].clone()
+            gold["segments_info"] = S["segments_info"]
         gold["instances"] = {"pred_boxes": inst["pred_boxes"], "scores": inst["scores"], "pred_classes": inst["pred_classes"],
                              "mask_area": inst["pred_masks"].flatten(1).sum(1), "mask_shape": list(inst["pred_masks"].shape),
                              "mask_rowsum0": inst["pred_masks"][0].sum(1) if len(inst["pred_masks"]) else None}

@@ -67,3 +67,45 @@ def check_semantic(model, orc, image, text, gold, device, tol=1e-3):
     assert set(res) == {"instances", "sem_seg"} and tuple(res["sem_seg"].shape) == (5, H, W)
     agree = (res["sem_seg"].argmax(0).cpu().to(torch.uint8) == gold["full"]["sem_seg_argmax"]).float().mean().item()
     assert agree > 0.99, agree
+
+
+class TextStub:
+    """stands in for EVA02CLIP.forward_text: a fixed [K, 1024] bank, one row per class name"""
+
+    def __init__(self, feats):
+        self.feats = feats
+
+    def forward_text(self, text_list, cache=False):
+        return {"last_hidden_state_eot": self.feats[: len(text_list)].clone()}
+
+
+def check_panoptic(model, orc, image, text, gold, device):
+    """evaluation-dataset mode through model.forward(): names from the metadata, detector on the thing columns, semantic and
+    panoptic branches -- vs the oracle and the reference-generated fixture (tests/golden/ref_tiny_panoptic.pt)"""
+    mv = model.model_vision
+    meta = gold["semantic_meta"]
+    thing_ids = {i + 1: i for i in range(len(meta["thing_classes"]))}
+    mv.dataset_names, mv.dataset_name_to_idx, mv.dataset_prompts = ["coco"], {"coco": 0}, ["name"]
+    mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"],
+                    thing_dataset_id_to_contiguous_id=thing_ids)
+    mv.semantic_on = mv.panoptic_on = True
+    mv.panoptic_configs = dict(gold["panoptic_cfg"])
+    mv.set_model_language(TextStub(text.to(device)))
+    mv.set_eval_dataset("coco_2017_val")
+    assert mv.eval_dataset_id == 0 and mv.eval_dataset_entity == "thing+stuff"
+    H, W = gold["out_hw"]
+    res = model([{"image": image, "height": H, "width": W}])[0]
+    assert set(res) == {"instances", "sem_seg", "panoptic_seg"}
+    assert int(res["instances"].pred_classes.max()) < len(meta["thing_classes"])
+    frac = U.match_detections(res["instances"].pred_boxes, res["instances"].scores, res["instances"].pred_classes,
+                              gold["instances"]["pred_boxes"], gold["instances"]["scores"], gold["instances"]["pred_classes"])
+    assert frac >= 0.95, frac
+    seg, info = res["panoptic_seg"]
+    ref_seg = gold["full"]["panoptic_seg"].to(torch.int32)
+    assert tuple(seg.shape) == (H, W) and seg.dtype == torch.int32
+    same_info = [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in gold["segments_info"]]
+    agree = (seg.cpu() == ref_seg).float().mean().item()
+    print(f"[panoptic] {len(info)} segments (reference {len(gold['segments_info'])}), pixel agreement {agree:.4f}")
+    assert same_info and agree > 0.995
+    agree_sem = (res["sem_seg"].argmax(0).cpu().to(torch.uint8) == gold["full"]["sem_seg_argmax"]).float().mean().item()
+    assert agree_sem > 0.99

@@ -86,6 +86,12 @@ def test_expression_prompt_keeps_one_detection(fake_ops):
     assert model.model_vision.test_topk_per_image == model.model_vision.select_box_nums_for_evaluation
 
 
+def test_eval_dataset_panoptic_matches_reference(fake_ops):
+    """set_eval_dataset mode incl. the panoptic merge, through the reference entry point"""
+    model, orc, image, text, gold = M.build_pair("tiny_panoptic")
+    M.check_panoptic(model, orc, image, text, gold, "cpu")
+
+
 def test_dataset_metadata_routes_the_branches(fake_ops):
     """eval-dataset metadata decides which branches run and which class columns the detector sees (:575-590, 628-630,
     654-663): a "stuff" dataset runs only the semantic branch; a thing+stuff dataset restricts the detector to the things"""

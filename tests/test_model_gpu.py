@@ -149,3 +149,9 @@ def test_parallel_images_in_one_graph():
         assert frac >= 0.99, frac
         assert inst.pred_masks.shape == m.shape
         assert (inst.pred_masks != m).float().mean().item() < 1e-3
+
+
+def test_eval_dataset_panoptic_on_gpu():
+    """evaluation-dataset mode + panoptic merge with the fp32 HIP kernels"""
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_panoptic", torch.float32)
+    M.check_panoptic(model, orc, image_c, text_c, gold, "cuda")

@@ -65,6 +65,31 @@ def test_oracle_semantic_branch_matches_reference_golden():
     assert agree > 0.999, agree
 
 
+def test_oracle_eval_dataset_and_panoptic_match_reference_golden():
+    """evaluation-dataset mode: detector on the thing columns only (:578-590), semantic branch, and the panoptic merge
+    (:671-695, 921-998) -- against the reference run stored in ref_tiny_panoptic.pt"""
+    gold = U.load_golden("tiny_panoptic")
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+    orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
+    H, W = gold["out_hw"]
+    meta = gold["semantic_meta"]
+    out = orc.forward(image, text, forced_topk=gold["full"]["topk_proposals"], height=H, width=W, semantic=meta,
+                      detector_columns=len(meta["thing_classes"]), panoptic=dict(meta=meta, cfg=gold["panoptic_cfg"]))
+    S = orc.stages
+    assert U.relerr(S["pred_logits"], gold["full"]["pred_logits_full"]) < 1e-3
+    assert int(out["instances"]["pred_classes"].max()) < len(meta["thing_classes"])
+    frac = U.match_detections(S["det_boxes"], S["det_scores"], S["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+    assert set(S["pan_query"].tolist()) == set(gold["full"]["pan_query"].tolist())
+    seg, info = out["panoptic_seg"]
+    ref_seg = gold["full"]["panoptic_seg"].to(torch.int32)
+    assert tuple(seg.shape) == (H, W)
+    assert [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in gold["segments_info"]]
+    assert (seg == ref_seg).float().mean().item() > 0.999
+
+
 def test_state_spec_contract():
     """checkpoint-key contract of the full-size model, as enumerated by the reference itself"""
     spec = dict(U.load_spec("L_D"))
