@@ -99,6 +99,10 @@ class DeformableDETRSegmVL(nn.Module):
         # rows of features_phrase_bank (ape_deta/deformable_detr.py:281-291): max criterion.num_classes
         self.phrase_bank_size = max([int(getattr(c, "num_classes", 0)) for c in self.criterion] + [0]) or 256
         self.embed_dim_language = embed_dim_language
+        if text_feature_bank:
+            # (ape_deta/deformable_detr.py:281-291) one bank per criterion / dataset, not part of the state dict
+            self.register_buffer("features_phrase_bank",
+                                 torch.zeros((max(len(self.criterion), 1), self.phrase_bank_size, embed_dim_language)), False)
         self.instance_on, self.semantic_on, self.panoptic_on = instance_on, semantic_on, panoptic_on
         self.input_shapes, self.mask_in_features, self.mask_encode_level = input_shapes, mask_in_features, mask_encode_level
         assert len(mask_in_features) == 1 and mask_encode_level == 0
@@ -259,18 +263,33 @@ class DeformableDETRSegmVL(nn.Module):
             return thing + stuff
         return stuff if entity == "stuff" else thing
 
+    def _bank_classes(self, dataset_id):
+        """criterion[dataset_id].num_classes of the reference (:314-327); index -1 = the last criterion like Python indexing"""
+        if len(self.criterion) == 0:
+            return self.phrase_bank_size
+        return int(getattr(self.criterion[dataset_id], "num_classes", self.phrase_bank_size))
+
     def fusion_tokens(self, text_feats, prompt):
         """the language tokens the encoder fuses with: the zero / learnable token in name mode (:349-352); in phrase /
-        expression mode the text bank zero-padded to the phrase-bank size (:304-327, text_feature_bank with reset)"""
+        expression mode the reduced text bank, extended by the phrase bank (:304-327):
+          * text_feature_bank_reset: zero rows up to the bank size (negatives carry no text);
+          * persistent bank (the APE-*_D default) while evaluating a dataset: the rows kept from earlier images act as
+            negatives, then the bank is overwritten with the current tokens (stateful, in place);
+          * otherwise (free-text prompts, dataset_id = -1, no reset): just the current tokens."""
         if prompt == "name":
             return self.name_prompt_fusion_feature.detach().float().reshape(1, -1)
+        text_feats = text_feats.float()
         K, D = text_feats.shape
-        if self.text_feature_bank:
-            if not self.text_feature_bank_reset:
-                raise NotImplementedError("ape_amd: a persistent phrase bank (text_feature_bank_reset=False) is not implemented")
-            bank = max(K, self.phrase_bank_size)
-            text_feats = torch.cat([text_feats.float(), text_feats.new_zeros((bank - K, D), dtype=torch.float32)], 0)
-        return text_feats.float().contiguous()
+        ds = self.eval_dataset_id
+        if self.text_feature_bank and self.text_feature_bank_reset:
+            n = max(K, self._bank_classes(ds))
+            text_feats = torch.cat([text_feats, text_feats.new_zeros((n - K, D))], 0)
+        elif self.text_feature_bank and 0 <= ds < len(self.metadata_list):
+            ncls = self._bank_classes(ds)
+            row = ds if ds < self.features_phrase_bank.shape[0] else -1
+            text_feats = torch.cat([text_feats, self.features_phrase_bank[row].to(text_feats.device)], 0)[: max(K, ncls)]
+            self.features_phrase_bank[row, :ncls] = text_feats[:ncls].to(self.features_phrase_bank.device)
+        return text_feats.contiguous()
 
     def class_tokens(self, feats, lvl, dt):
         """per-vocabulary constants of the last-level classifier, cached by tensor identity"""

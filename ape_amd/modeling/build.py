@@ -63,7 +63,7 @@ def build_ape(size="L_D", model_language=None, **overrides):
         mask_in_features=["p2"], input_shapes=shapes, embed_dim_language=1024, instance_on=True, semantic_on=False,
         panoptic_on=False, text_feature_bank=True, text_feature_reduce_before_fusion=True, text_feature_batch_repeat=True,
         name_prompt_fusion_type="zero", dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"],
-        text_feature_bank_reset=True)
+        text_feature_bank_reset=False)      # the APE-*_D default (only the D3 configs reset the bank)
     model = SomeThing(model_vision=mv, model_language=model_language)
     model.eval()
     return model

@@ -602,7 +602,10 @@ class ApeOracle:
             fusion = self.p("name_prompt_fusion_feature").repeat(1, 1, 1)  # zeros [1,1,1024] (:349-352)
         else:
             K = text_feats.shape[0]
-            bank = torch.cat([text_feats.float(), torch.zeros(phrase_bank, text_feats.shape[1])], 0)[: max(K, phrase_bank)]
+            # phrase_bank: int = zero rows (text_feature_bank_reset, :321-327); tensor = the persistent bank's rows (:310-320);
+            # 0 = no bank (free-text prompts with the default config)
+            extra = torch.zeros(phrase_bank, text_feats.shape[1]) if isinstance(phrase_bank, int) else phrase_bank.float()
+            bank = torch.cat([text_feats.float(), extra], 0)[: max(K, extra.shape[0])]
             features_l = bank[None]                                  # (:321-335)
             fusion = features_l + 0.0 * self.p("name_prompt_fusion_feature")   # (:357-360)
         feat = self.vit(images)

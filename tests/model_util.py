@@ -17,6 +17,8 @@ def build_pair(case, device="cpu", dtype=torch.float32):
     assert not unexpected and all(m.endswith(("freqs_cos", "freqs_sin")) for m in missing), (missing, unexpected)
     model.to(device)
     model.model_vision.set_compute_dtype(dtype)
+    # the phrase fixture was produced with text_feature_bank_reset=True (zero-padded bank, oracle/ref_model.py)
+    model.model_vision.text_feature_bank_reset = U.case_prompt(gold) == "phrase"
     orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
     return model, orc, image, text, gold
 

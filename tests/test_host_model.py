@@ -86,6 +86,41 @@ def test_expression_prompt_keeps_one_detection(fake_ops):
     assert model.model_vision.test_topk_per_image == model.model_vision.select_box_nums_for_evaluation
 
 
+def test_phrase_bank_modes(fake_ops):
+    """the three phrase-bank behaviours of :304-327: no bank for free-text prompts with the default config, zero padding
+    with text_feature_bank_reset, and the persistent (stateful) bank while a dataset is evaluated"""
+    model, orc, image, text, gold = M.build_pair("tiny_phrase")
+    mv = model.model_vision
+    h, w = image.shape[-2:]
+    inp = {"image": image, "height": h, "width": w, "text_features": text, "prompt": "phrase"}
+
+    def logits_of(**kw):
+        st = {}
+        mv.forward_single(image, kw.pop("feats", text), stages=st, prompt="phrase", forced_topk=gold["full"]["topk_proposals"][0])
+        return st["pred_logits"]
+
+    # (a) default config, free-text prompt: only the K current tokens are fused
+    mv.text_feature_bank_reset = False
+    mv.eval_dataset_id = -1
+    la = logits_of()
+    oa = orc.forward(image, text, prompt="phrase", phrase_bank=0, forced_topk=gold["full"]["topk_proposals"])
+    assert la.shape[1] == text.shape[0] and U.relerr(la, oa["pred_logits"][0]) < 1e-3
+    # (b) persistent bank while evaluating dataset 0: the first image sees zeros, the second one the first image's tokens
+    mv.set_metadata(0, name="refcoco")
+    mv.eval_dataset_id = 0
+    nb = mv.phrase_bank_size
+    l1 = logits_of()
+    o1 = orc.forward(image, text, prompt="phrase", phrase_bank=torch.zeros(nb, 1024), forced_topk=gold["full"]["topk_proposals"])
+    assert l1.shape[1] == nb and U.relerr(l1, o1["pred_logits"][0]) < 1e-3
+    assert torch.equal(mv.features_phrase_bank[0, : text.shape[0]], text) and float(mv.features_phrase_bank[0, text.shape[0]:].abs().max()) == 0
+    text2 = torch.randn(4, 1024, generator=torch.Generator().manual_seed(99))
+    l2 = logits_of(feats=text2)
+    bank_rows = torch.cat([text, torch.zeros(nb - text.shape[0], 1024)], 0)
+    o2 = orc.forward(image, text2, prompt="phrase", phrase_bank=bank_rows, forced_topk=gold["full"]["topk_proposals"])
+    assert l2.shape[1] == nb and U.relerr(l2, o2["pred_logits"][0]) < 1e-3
+    assert torch.equal(mv.features_phrase_bank[0, :4], text2) and torch.equal(mv.features_phrase_bank[0, 4:6], text[:2])
+
+
 def test_eval_dataset_panoptic_matches_reference(fake_ops):
     """set_eval_dataset mode incl. the panoptic merge, through the reference entry point"""
     model, orc, image, text, gold = M.build_pair("tiny_panoptic")
