@@ -114,6 +114,7 @@ class DeformableDETRSegmVL(nn.Module):
         self.mask_embed = MLP(hidden, hidden, hidden, 3)
         self.test_mask_on = test_mask_on
         self.name_prompt_fusion_type = name_prompt_fusion_type
+        self.name_prompt_fusion_text = name_prompt_fusion_text      # per-dataset flags or None
         if name_prompt_fusion_type == "zero":
             self.name_prompt_fusion_feature = nn.Parameter(torch.zeros(1, 1, embed_dim_language), requires_grad=False)
         elif name_prompt_fusion_type == "learnable":
@@ -277,6 +278,9 @@ class DeformableDETRSegmVL(nn.Module):
             negatives, then the bank is overwritten with the current tokens (stateful, in place);
           * otherwise (free-text prompts, dataset_id = -1, no reset): just the current tokens."""
         if prompt == "name":
+            nft = self.name_prompt_fusion_text
+            if nft is not None and nft[self.eval_dataset_id]:          # (:343-347) ODinW-style: fuse the class names themselves
+                return text_feats.float().contiguous()
             return self.name_prompt_fusion_feature.detach().float().reshape(1, -1)
         text_feats = text_feats.float()
         K, D = text_feats.shape

@@ -589,7 +589,7 @@ class ApeOracle:
 
     @torch.no_grad()
     def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True, prompt="name",
-                phrase_bank=256, semantic=None, detector_columns=None, panoptic=None):
+                phrase_bank=256, semantic=None, detector_columns=None, panoptic=None, name_fusion_text=False):
         """prompt="phrase" (also "expression" with text_feature_reduce_before_fusion): the text bank, zero-padded to
         the phrase-bank size (:304-327 with text_feature_bank + text_feature_bank_reset), is FUSED with the vision
         tokens in the encoder and the fused tokens are the classifier's vocabulary (:356-358, 448)."""
@@ -598,7 +598,9 @@ class ApeOracle:
         height = height or h
         width = width or w
         features_l = text_feats.float()[None]                       # [1,K,1024]  (:279-280)
-        if prompt == "name":
+        if prompt == "name" and name_fusion_text:
+            fusion = features_l                                          # (:343-347) name_prompt_fusion_text[dataset_id]
+        elif prompt == "name":
             fusion = self.p("name_prompt_fusion_feature").repeat(1, 1, 1)  # zeros [1,1,1024] (:349-352)
         else:
             K = text_feats.shape[0]

@@ -86,6 +86,22 @@ def test_expression_prompt_keeps_one_detection(fake_ops):
     assert model.model_vision.test_topk_per_image == model.model_vision.select_box_nums_for_evaluation
 
 
+def test_name_prompt_fusion_text(fake_ops):
+    """name_prompt_fusion_text[dataset] (ODinW configs): the class-name features themselves are fused densely in the encoder,
+    the classifier still sees the RAW bank (:343-347, :446)"""
+    model, orc, image, text, gold = M.build_pair("tiny_padded")
+    mv = model.model_vision
+    mv.name_prompt_fusion_text = [True]
+    mv.eval_dataset_id = 0
+    st = {}
+    mv.forward_single(image, text, stages=st, forced_topk=gold["full"]["topk_proposals"][0])
+    oo = orc.forward(image, text, forced_topk=gold["full"]["topk_proposals"], name_fusion_text=True)
+    assert st["pred_logits"].shape[1] == text.shape[0]
+    assert U.relerr(st["pred_logits"], oo["pred_logits"][0]) < 1e-3 and U.relerr(st["pred_boxes"], oo["pred_boxes"][0]) < 1e-3
+    base = orc.forward(image, text, forced_topk=gold["full"]["topk_proposals"])
+    assert U.relerr(oo["pred_logits"], base["pred_logits"]) > 1e-4          # the fusion really changes the result
+
+
 def test_phrase_bank_modes(fake_ops):
     """the three phrase-bank behaviours of :304-327: no bank for free-text prompts with the default config, zero padding
     with text_feature_bank_reset, and the persistent (stateful) bank while a dataset is evaluated"""
