@@ -29,7 +29,7 @@ SIZES = {
 }
 
 
-def build_ape(size="L_D", model_language=None, **overrides):
+def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
     c = SimpleNamespace(**{**SIZES[size], **overrides}) if isinstance(size, str) else SimpleNamespace(**{**size, **overrides})
     feats = ["p2", "p3", "p4", "p5", "p6"]
     net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
@@ -63,7 +63,9 @@ def build_ape(size="L_D", model_language=None, **overrides):
         mask_in_features=["p2"], input_shapes=shapes, embed_dim_language=1024, instance_on=True, semantic_on=False,
         panoptic_on=False, text_feature_bank=True, text_feature_reduce_before_fusion=True, text_feature_batch_repeat=True,
         name_prompt_fusion_type="zero", dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"],
-        text_feature_bank_reset=False)      # the APE-*_D default (only the D3 configs reset the bank)
+        text_feature_bank_reset=False,      # the APE-*_D default (only the D3 configs reset the bank)
+        stuff_prob_thing=0.9,               # config :172; semantic_on is True there (:176) and decided per evaluation dataset --
+        **(vision_kwargs or {}))            # pass vision_kwargs=dict(semantic_on=True, dataset_metas=[{...}]) for stuff datasets
     model = SomeThing(model_vision=mv, model_language=model_language)
     model.eval()
     return model
