@@ -55,7 +55,7 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
     transformer = DeformableDetrTransformerVL(encoder=encoder, decoder=decoder, as_two_stage=True, num_feature_levels=5,
                                               two_stage_num_proposals=c.num_queries, assign_first_stage=True,
                                               proposal_ambiguous=1)
-    mv = DeformableDETRSegmVL(
+    vkw = dict(
         backbone=backbone, position_embedding=PositionEmbeddingSine(num_pos_feats=128, temperature=10000, normalize=True, offset=-0.5),
         neck=neck, transformer=transformer, embed_dim=256, num_classes=1256, num_queries=c.num_queries, criterion=[],
         pixel_mean=[123.675, 116.280, 103.530], pixel_std=[58.395, 57.120, 57.375], aux_loss=True, with_box_refine=True,
@@ -64,8 +64,9 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
         panoptic_on=False, text_feature_bank=True, text_feature_reduce_before_fusion=True, text_feature_batch_repeat=True,
         name_prompt_fusion_type="zero", dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"],
         text_feature_bank_reset=False,      # the APE-*_D default (only the D3 configs reset the bank)
-        stuff_prob_thing=0.9,               # config :172; semantic_on is True there (:176) and decided per evaluation dataset --
-        **(vision_kwargs or {}))            # pass vision_kwargs=dict(semantic_on=True, dataset_metas=[{...}]) for stuff datasets
+        stuff_prob_thing=0.9)               # config :172; semantic_on is True there (:176) and decided per evaluation dataset --
+    vkw.update(vision_kwargs or {})         # e.g. vision_kwargs=dict(semantic_on=True, dataset_metas=[{...}]) for stuff datasets
+    mv = DeformableDETRSegmVL(**vkw)
     model = SomeThing(model_vision=mv, model_language=model_language)
     model.eval()
     return model
