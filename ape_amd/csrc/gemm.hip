@@ -16,149 +16,9 @@
 #include "common.h"
 #include "../../include/ape_hip.h"
 
-typedef ApeGemmArgs GemmParams;
+#include "gemm_epi.h"
 
-__device__ __forceinline__ float act_fn(float x, int act) {
-  if (act == APE_ACT_RELU) return fmaxf(x, 0.f);
-  if (act == APE_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
-  if (act == APE_ACT_SILU) return x / (1.f + __expf(-x));
-  return x;
-}
-
-template <typename T>
-__device__ __forceinline__ void store_n(T* dst, const float* v, int cnt, bool vec) {
-  if (vec && cnt == 4) {
-    st4<T>(dst, v);
-  } else {
-    for (int r = 0; r < cnt; ++r) stf<T>(dst + r, v[r]);
-  }
-}
-
-// Epilogue arithmetic for 4 consecutive output columns n0..n0+3 (n0 % 4 == 0) of row m (m < M, n0 < N).
-// On return v[0..cnt) are the final values for output columns ocol..ocol+cnt (SwiGLU halves the column index).
-// p.vec_ok bits (launcher): 1 = C / residual rows allow 16-byte accesses, 2 = bias is 16-byte aligned,
-// 4 = RoPE tables 16-byte aligned, power-of-two head dim, rope_rows >= M or a power of two (masks replace the modulo).
-// For short-K GEMMs (the ViT at M = 4096) this code is as long as the main loop, so it is written for few VALU ops:
-// vector loads for bias / RoPE / residual, uniform conditions tested once per quad.
-__device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0, float v[4], int& ocol, int& cnt) {
-  const bool masked = p.rowmask != nullptr && p.rowmask[m] != 0;
-  const bool full = n0 + 3 < p.N;
-  if (p.alpha != 1.f) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] *= p.alpha;
-  }
-  if (p.rowscale != nullptr) {             // folded LayerNorm of the A operand: acc * rstd_m - rstd_m mean_m * rowsum(W')_n
-    const float rs = p.rowscale[m], sh = p.rowshift[m];
-    if ((p.vec_ok & 8) && full) {
-      const float4 c = *reinterpret_cast<const float4*>(p.colvec + n0);
-      v[0] = fmaf(v[0], rs, sh * c.x); v[1] = fmaf(v[1], rs, sh * c.y); v[2] = fmaf(v[2], rs, sh * c.z); v[3] = fmaf(v[3], rs, sh * c.w);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] = fmaf(v[r], rs, sh * p.colvec[n0 + r]);
-    }
-  }
-  if (masked && p.mask_mode == APE_MASK_ZERO_INPUT) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = 0.f;
-  }
-  if (p.bias != nullptr) {
-    if ((p.vec_ok & 2) && full) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) if (n0 + r < p.N) v[r] += p.bias[n0 + r];
-    }
-  }
-  if (p.rope_cos != nullptr && n0 < p.rope_cols) {
-    const int hd = p.rope_hd;
-    float c[4], sn[4];
-    if (p.vec_ok & 4) {
-      const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;   // rows >= M or a power of two
-      const size_t trow = (size_t)(m & rmask) * hd + (n0 & (hd - 1));
-      const float4 c4 = *reinterpret_cast<const float4*>(p.rope_cos + trow), s4 = *reinterpret_cast<const float4*>(p.rope_sin + trow);
-      c[0] = c4.x; c[1] = c4.y; c[2] = c4.z; c[3] = c4.w; sn[0] = s4.x; sn[1] = s4.y; sn[2] = s4.z; sn[3] = s4.w;
-    } else {
-      const size_t trow = (size_t)(m % p.rope_rows) * hd + n0 % hd;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { c[r] = p.rope_cos[trow + r]; sn[r] = p.rope_sin[trow + r]; }
-    }
-    const float x0 = v[0], x1 = v[1], x2 = v[2], x3 = v[3];
-    // t*cos + rotate_half(t)*sin with rotate_half pairs (2i,2i+1) -> (-x[2i+1], x[2i])
-    v[0] = x0 * c[0] - x1 * sn[0];
-    v[1] = x1 * c[1] + x0 * sn[1];
-    v[2] = x2 * c[2] - x3 * sn[2];
-    v[3] = x3 * c[3] + x2 * sn[3];
-  }
-  if (p.act == APE_ACT_SWIGLU) {
-    // interleaved (gate, up) pairs -> N/2 output columns
-    const float o0 = (v[0] / (1.f + __expf(-v[0]))) * v[1];
-    const float o1 = (v[2] / (1.f + __expf(-v[2]))) * v[3];
-    v[0] = o0; v[1] = o1;
-    ocol = n0 >> 1;
-    cnt = (ocol + 1 < (p.N >> 1)) ? 2 : 1;
-    return;
-  }
-  ocol = n0;
-  cnt = full ? 4 : (p.N - n0);
-  if (p.act == APE_ACT_RELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-  } else if (p.act != APE_ACT_NONE) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r], p.act);
-  }
-  if (p.clamp > 0.f) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = fminf(fmaxf(v[r], -p.clamp), p.clamp);
-  }
-  if (p.residual != nullptr) {
-    const size_t roff = (size_t)m * p.ldr + n0;
-    const bool vec = (p.vec_ok & 1) != 0;
-    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.res_dt == APE_DT_F32) {
-      const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
-      if (vec && cnt == 4) ld4<float>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = rp[r];
-    } else {
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + roff;
-      if (vec && cnt == 4) ld4<bf16_t>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = bf2f(rp[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] += rv[r];
-  }
-  if (masked && p.mask_mode == APE_MASK_ZERO_OUTPUT) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = 0.f;
-  }
-}
-
-// direct (register -> global) epilogue: 4 consecutive output columns of row m
-__device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float v[4]) {
-  if (m >= p.M || n0 >= p.N) return;
-  int ocol, cnt;
-  epi_n4_values(p, m, n0, v, ocol, cnt);
-  const bool vec = (p.vec_ok & 1) != 0 && cnt == 4;
-  const size_t off = (size_t)m * p.ldc + ocol;
-  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, vec);
-  else if (cnt == 2 && (p.vec_ok & 1)) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = pack2bf(v[0], v[1]);
-  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, vec);
-}
-
-__device__ __forceinline__ void epi_m4_values(const GemmParams& p, int n, float v[4]) {
-  const float b = p.bias != nullptr ? p.bias[n] : 0.f;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = act_fn(v[r] * p.alpha + b, p.act);
-}
-
-// transposed output C^T[n][m0..m0+3]  (bias by n, activation, no residual/rope/mask)
-__device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float v[4]) {
-  if (n >= p.N || m0 >= p.M) return;
-  epi_m4_values(p, n, v);
-  const int cnt = (p.M - m0) < 4 ? (p.M - m0) : 4;
-  const size_t off = (size_t)n * p.ldc + m0;
-  if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
-  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
-}
+const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s);   // gemm_p8.hip
 
 // ------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
@@ -1075,6 +935,18 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
     const char* ring_env = getenv("APE_GEMM_RING");     // read per call so a probe can flip it
     const int use_ring_always = ring_env ? atoi(ring_env) : 0;
     const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
+    if (p.tile64 == 3 || p.tile64 == 4) {
+      // 256 x 256 / 256 x 128 eight-wave tiles with the counted-wait pipeline (gemm_p8.hip); falls back when unsupported
+      const char* st_env = getenv("APE_GEMM_P8_STAGGER");
+      const int stagger = st_env ? atoi(st_env) : 1;
+      const char* name = ape_gemm_p8_launch(p, p.tile64 == 3 ? 256 : 128, stagger, s);
+      if (name != nullptr) {
+        g_last_gemm_kernel = name;
+        APE_CHECK_LAUNCH("ape_hip_gemm");
+        return 0;
+      }
+      p.tile64 = 0;
+    }
     if (v2_ok) {
       static bool attr_done = false;
       if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute

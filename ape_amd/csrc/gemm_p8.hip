@@ -1,0 +1,320 @@
+// bf16 MFMA GEMM "p8" for gfx950:  C[M,N] = epi(alpha * A[M,K] . W[N,K]^T), 256 x BN block tiles (BN = 256 | 128),
+// 8 waves (2 along M x 4 along N), each wave a 128 x (BN/4) sub-tile = 8 x (BN/64) MFMA 16x16x32 accumulators.
+//
+// Used for the large contractions of the APE forward (reference call sites: the EVA-02 block linears
+// ape/modeling/backbone/vit_eva_clip.py:225-232,264-268,125-132 at M = 4096 x images, the SimpleFPN / mask-head 3x3
+// convolutions :806-842 as im2col GEMMs at M = 65536, the encoder FFN of
+// ape/modeling/ape_deta/deformable_transformer_vl.py:45-54 at M = 87296).
+//
+// Schedule (CDNA4 guide, "256^2 8-phase template"): one K tile (64) is consumed in 4 phases, one quadrant of the wave's
+// accumulators (4 x BN/128 tiles, both 32-deep k steps = 16 / 8 MFMAs) per phase:
+//     phase 1: read B0, A0 fragments            -> MFMA(A0, B0)        stage  A1 of K tile t+1
+//     phase 2: read B1                          -> MFMA(A0, B1)        stage  B0 of K tile t+2
+//     phase 3: read A1                          -> MFMA(A1, B1)        stage  A0 of K tile t+2
+//     phase 4: (fragments all in registers)     -> MFMA(A1, B0)        stage  B1 of K tile t+2, counted vmcnt wait
+//   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip) into TWO stages of four 16 KiB (8 KiB
+//     for the B side of BN = 128) half-tiles; every phase stages one half-tile, three half-tiles stay in flight across
+//     the barriers: the only VMEM wait of the loop is one counted `s_waitcnt vmcnt(N)` per K tile (phase 4), N = the
+//     loads of the three youngest half-tiles.  Barriers are raw s_barrier (a __syncthreads() would drain the LDS-DMA
+//     queue with vmcnt(0)).
+//   * a half-tile is re-staged two phases after its last ds_read (one phase for B0, whose reads are issued first in
+//     phase 1 and retired by an lgkmcnt wait before the phase's first barrier), and is read one phase after the wait that
+//     retires it -- which also holds when the two wave rows run STAGGERed by one barrier (wave row 1 passes one extra
+//     barrier up front, so its ds_read / staging section overlaps wave row 0's MFMA section on the same SIMDs).
+//   * LDS rows are 128 B (64 k) with the 16-byte chunk index XOR-ed by (row >> 1) & 7: applied to the per-lane SOURCE
+//     address of the LDS-DMA (the LDS destination of global_load_lds is lane-linear) and to the ds_read_b128 address.
+//   * the MFMA operands are swapped (D = W . A^T) and the W rows of a wave's column slab are PERMUTED on their way into
+//     LDS (row 16 j + 4 g + r holds column 16 g + 4 j + r; 8 g + 4 j + r for the 32-wide slab of BN = 128), so a lane ends
+//     up with 16 (8) CONSECUTIVE output columns of each of its rows: the epilogue stores 16-byte pieces straight from
+//     registers, four lanes covering a 128-byte (64-byte) row segment -- no LDS round trip, no barrier.
+//   * tiles are walked in an XCD-aware, grouped order (blockIdx % 8 = XCD; each XCD owns a contiguous range, inside it
+//     8 row-tiles x all column-tiles at a time) so that both operands of concurrently running tiles hit in the XCD's L2.
+// trans_out is the same kernel with the operands exchanged by the launcher (C^T = W . A^T) and the bias indexed by row.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm_epi.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+#define P8_BM 256
+#define P8_BK 64
+#define P8_BIAS_BY_ROW 16 /* vec_ok bit: bias[m] instead of bias[n] (transposed problems) */
+
+template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
+  static_assert(N >= 0 && N <= 63, "vmcnt immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
+  constexpr int WN = BN / 4;              // columns per wave: 64 | 32
+  constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
+  constexpr int TNH = TN / 2;             // n tiles per half: 2 | 1
+  constexpr int NIB = BN / 128;           // LDS-DMA instructions per lane per B half-tile: 2 | 1
+  constexpr int A_HALF = 128 * 128;       // bytes: 128 rows x 128 B
+  constexpr int B_HALF = (BN / 2) * 128;  // bytes
+  constexpr int STG = 2 * A_HALF + 2 * B_HALF;
+  constexpr int OFF_A0 = 0, OFF_A1 = A_HALF, OFF_B0 = 2 * A_HALF, OFF_B1 = 2 * A_HALF + B_HALF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 * STG bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int frow = lane & 15, fq = lane >> 4;
+
+  // ---- tile of this workgroup
+  const int tiles_m = (p.M + P8_BM - 1) / P8_BM, tiles_n = (p.N + BN - 1) / BN;
+  int id;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, j = b >> 3;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective: XCD x owns a contiguous id range
+  }
+  int tm, tn;
+  {
+    const int per_group = 8 * tiles_n;           // 8 row-tiles x all column-tiles, column-major inside the group
+    const int g = id / per_group, rem = id - g * per_group;
+    const int rows = min(8, tiles_m - g * 8);
+    tm = g * 8 + rem % rows;
+    tn = rem / rows;
+  }
+  const int m0 = tm * P8_BM, n0 = tn * BN;
+
+  // ---- LDS-DMA source offsets (bytes from A / W), one per (half, instruction); LDS row lr = e * 8 + lane / 8
+  const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(p.A);
+  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.W);
+  uint32_t offA[2][2], offB[2][NIB];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int lr = (wave * 2 + q) * 8 + (lane >> 3);                   // 0..127: wave row lr / 64, row lr % 64 of its half
+      const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
+      int gm = m0 + trow; gm = gm < p.M ? gm : p.M - 1;
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      offA[h][q] = (uint32_t)gm * (uint32_t)p.lda * 2u + (uint32_t)c * 16u;
+    }
+#pragma unroll
+    for (int q = 0; q < NIB; ++q) {
+      const int lr = (wave * NIB + q) * 8 + (lane >> 3);                 // 0..BN/2-1: wave column lr / (WN/2)
+      const int wcs = lr / (WN / 2), within = lr % (WN / 2);
+      const int rho = h * (WN / 2) + within;                             // row of the wave's WN-row slab
+      const int col = WN == 64 ? (((rho >> 2) & 3) * 16 + (rho >> 4) * 4 + (rho & 3))
+                               : (((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3));
+      int gn = n0 + wcs * WN + col; gn = gn < p.N ? gn : p.N - 1;
+      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      offB[h][q] = (uint32_t)gn * (uint32_t)p.ldw * 2u + (uint32_t)c * 16u;
+    }
+  }
+  // half-tile j of K tile kt: 0 = B0, 1 = A0, 2 = B1, 3 = A1
+  auto issue_A = [&](int kt, int h) __attribute__((always_inline)) {
+    unsigned char* dst = smem + (kt & 1) * STG + (h ? OFF_A1 : OFF_A0) + wave * 2048;
+    const unsigned char* src = Ab + (size_t)kt * (P8_BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + offA[h][q]), (lds_void_t*)(dst + q * 1024), 16, 0, 0);
+  };
+  auto issue_B = [&](int kt, int h) __attribute__((always_inline)) {
+    unsigned char* dst = smem + (kt & 1) * STG + (h ? OFF_B1 : OFF_B0) + wave * (NIB * 1024);
+    const unsigned char* src = Wb + (size_t)kt * (P8_BK * 2);
+#pragma unroll
+    for (int q = 0; q < NIB; ++q)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + offB[h][q]), (lds_void_t*)(dst + q * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment reads: lane (frow, fq) reads row (16-row tile base + frow), 16-byte chunk (ks * 4 + fq) ^ ((frow >> 1) & 7)
+  const int sw = (frow >> 1) & 7;
+  const int rd0 = frow * 128 + (((0 + fq) ^ sw) << 4);     // k step 0
+  const int rd1 = frow * 128 + (((4 + fq) ^ sw) << 4);     // k step 1
+  bf16x8_t af[2][4][2], wf[2][TNH][2];
+  auto read_A = [&](int stage, int h) __attribute__((always_inline)) {
+    const unsigned char* base = smem + stage * STG + (h ? OFF_A1 : OFF_A0) + wr * (64 * 128);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      af[h][i][0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + i * 2048 + rd0));
+      af[h][i][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + i * 2048 + rd1));
+    }
+  };
+  auto read_B = [&](int stage, int h) __attribute__((always_inline)) {
+    const unsigned char* base = smem + stage * STG + (h ? OFF_B1 : OFF_B0) + wc * ((WN / 2) * 128);
+#pragma unroll
+    for (int j = 0; j < TNH; ++j) {
+      wf[h][j][0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + j * 2048 + rd0));
+      wf[h][j][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + j * 2048 + rd1));
+    }
+  };
+  f32x4_t acc[8][TN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto mma = [&](int ha, int hb) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TNH; ++j)
+          acc[ha * 4 + i][hb * TNH + j] =
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hb][j][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH + j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto barrier = [&]() __attribute__((always_inline)) {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto lgkm0 = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int nk = p.K / P8_BK;
+  constexpr int INFLIGHT = 2 * NIB + 2;          // loads of the three youngest half-tiles at a phase-4 wait: B0, A0, B1
+  // ---- prologue: K tile 0 complete, the first three half-tiles of K tile 1 in flight
+  issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
+  if (nk > 1) {
+    issue_B(1, 0); issue_A(1, 0); issue_B(1, 1);
+    p8_wait_vmcnt<INFLIGHT>();
+  } else {
+    p8_wait_vmcnt<0>();
+  }
+  barrier();
+  if (STAGGER && wr == 1) barrier();
+
+  for (int t = 0; t < nk; ++t) {
+    const int s = t & 1;
+    // ---- phase 1
+    read_B(s, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_A(s, 0);
+    if (t + 1 < nk) issue_A(t + 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads (issued first) are complete: B0 may be re-staged next phase
+    barrier();
+    lgkm0();
+    mma(0, 0);
+    barrier();
+    // ---- phase 2
+    read_B(s, 1);
+    if (t + 2 < nk) issue_B(t + 2, 0);
+    barrier();
+    lgkm0();
+    mma(0, 1);
+    barrier();
+    // ---- phase 3
+    read_A(s, 1);
+    if (t + 2 < nk) issue_A(t + 2, 0);
+    barrier();
+    lgkm0();
+    mma(1, 1);
+    barrier();
+    // ---- phase 4: every load of K tile t+1 must have landed before the next phase reads it
+    if (t + 2 < nk) {
+      issue_B(t + 2, 1);
+      p8_wait_vmcnt<INFLIGHT>();
+    } else if (t + 1 < nk) {
+      p8_wait_vmcnt<0>();
+    }
+    barrier();
+    mma(1, 0);
+    barrier();
+  }
+  if (STAGGER && wr == 0) barrier();
+
+  // ---- epilogue from registers: lane (frow, fq) owns rows tile_i * 16 + frow, TN * 4 consecutive columns
+  constexpr int W = TN * 4;
+  const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
+  // wave-uniform: the wave's whole column slab is inside N (a partial slab takes the generic, bounds-checked path)
+  const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
+  // one specialisation per launch (wave-uniform): the unrolled body stays short
+  auto run = [&](auto rope_t, auto norm_t, auto act_t) __attribute__((always_inline)) {
+    constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value;
+    constexpr int ACT = decltype(act_t)::value;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + frow;
+      if (m < p.M) {
+        float o[W];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[4 * j + r] = acc[i][j][r];
+        epi_row_fast<W, ROPE, NORM, ACT>(p, m, nb, o);
+        if (ACT == EPI_ACT_SWIGLU) store_row<W / 2>(p, m, nb >> 1, o);
+        else store_row<W>(p, m, nb, o);
+      }
+    }
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (!fast) {
+    // generic path: any epilogue combination, one quad at a time (not unrolled over the row tiles: code size)
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + frow;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          epi_n4(p, m, nb + 4 * j, v);
+        }
+      }
+    }
+  } else if (p.rope_cos != nullptr) {
+    run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
+  } else if (p.rowscale != nullptr) {
+    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{});
+  } else if (p.act == APE_ACT_SWIGLU) {
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{});
+  } else if (p.act == APE_ACT_RELU) {
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{});
+  } else {
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launcher (called from ape_hip_gemm in gemm.hip).  Returns the kernel symbol, or nullptr when the problem does not fit.
+// ------------------------------------------------------------------------------------------
+static bool p8_supported(const ApeGemmArgs& p) {
+  if (p.in_dt != APE_DT_BF16 || p.K % P8_BK != 0 || p.K < P8_BK) return false;
+  if (p.splitk > 1 || p.rowscale != nullptr && p.trans_out) return false;
+  const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+  if (((uintptr_t)p.C) % 16 != 0 || ((size_t)p.ldc * esz) % 16 != 0) return false;
+  if ((size_t)p.M * p.lda * 2 >= (1ull << 32) || (size_t)p.N * p.ldw * 2 >= (1ull << 32)) return false;   // 32-bit source offsets
+  if (p.act == APE_ACT_SWIGLU && (p.N % 4 != 0 || p.trans_out)) return false;
+  return true;
+}
+
+const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s) {
+  if (!p8_supported(p)) return nullptr;
+  if (p.trans_out) {
+    // C^T[N, M] = W . A^T: the same kernel on the exchanged problem, bias indexed by (new) row
+    const void* a = p.A; p.A = p.W; p.W = a;
+    const int m = p.M; p.M = p.N; p.N = m;
+    const int l = p.lda; p.lda = p.ldw; p.ldw = l;
+    p.trans_out = 0;
+    p.vec_ok = (p.vec_ok & ~2) | P8_BIAS_BY_ROW;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    attr_done = true;
+  }
+  const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
+  if (bn == 256) {
+    if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true>), dim3(tiles), dim3(512), 131072, s, p); return "gemm_bf16_p8_kernel<256, true>"; }
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, false>), dim3(tiles), dim3(512), 131072, s, p);
+    return "gemm_bf16_p8_kernel<256, false>";
+  }
+  if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, true>), dim3(tiles), dim3(512), 98304, s, p); return "gemm_bf16_p8_kernel<128, true>"; }
+  hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, false>), dim3(tiles), dim3(512), 98304, s, p);
+  return "gemm_bf16_p8_kernel<128, false>";
+}

@@ -53,9 +53,9 @@ class DataParallelRunner:
 
     # pipelined form (forward_fn must offer submit/result, e.g. runtime.GraphedForward): the device->host transfer of
     # image i and the record all-gather overlap the compute of image i+1
-    def submit(self, image, text):
-        """enqueue one image; returns a ticket for `result`"""
-        ticket = self.forward_fn.submit(image, text)
+    def submit(self, image, text, height=None, width=None, prompt="name"):
+        """enqueue one image (output frame height x width, prompt mode as in GraphedForward.submit); returns a ticket"""
+        ticket = self.forward_fn.submit(image, text, height, width, prompt)
         ticket.records = self._all_gather(ticket.rec6)     # stream-ordered behind the forward, no host wait
         return ticket
 

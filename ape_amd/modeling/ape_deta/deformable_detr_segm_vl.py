@@ -3,8 +3,8 @@
 Mirror of ape/modeling/ape_deta/deformable_detr_segm_vl.py (DeformableDETRSegmVL.forward :166-726,
 maskdino_mask_features :728-750, inference :759-810, preprocess_image :846-855, _postprocess_instance :857-872) and
 of the constructor in ape/modeling/ape_deta/deformable_detr.py:52-296 (heads :100-215): same class name, constructor
-kwargs and state-dict keys.  Training branches, the phrase/expression prompt modes (dense multi-token fusion) and
-the semantic / panoptic tails are outside this round's hot path and raise NotImplementedError.
+kwargs and state-dict keys.  Name / phrase / expression prompts (single-token and dense multi-token fusion) and the
+instance / semantic / panoptic tails are implemented; training branches raise NotImplementedError.
 
 Per image (batch 1, like the reference's evaluation) the whole forward is a fixed sequence of HIP kernel launches
 on the current stream with no host synchronisation until the final device->host copy of the detections.
@@ -296,13 +296,18 @@ class DeformableDETRSegmVL(nn.Module):
         return text_feats.contiguous()
 
     def class_tokens(self, feats, lvl, dt):
-        """per-vocabulary constants of the last-level classifier, cached by tensor identity"""
-        key = (feats.data_ptr(), feats._version, tuple(feats.shape), lvl, dt)
-        if key not in self._text:
-            if len(self._text) > 16:
-                self._text.clear()
-            self._text[key] = self.class_embed[lvl].text_side(feats, dt)
-        return self._text[key]
+        """per-vocabulary constants of the last-level classifier, cached by tensor IDENTITY: an entry keeps a reference to
+        its bank (which also pins the address) and hits only for that very tensor object at the same version -- a freed
+        bank whose address the allocator hands to another vocabulary can never match."""
+        key = (id(feats), lvl, dt)
+        ent = self._text.get(key)
+        if ent is not None and ent[0] is feats and ent[1] == feats._version:
+            return ent[2]
+        if len(self._text) > 16:
+            self._text.clear()
+        val = self.class_embed[lvl].text_side(feats, dt)
+        self._text[key] = (feats, feats._version, val)
+        return val
 
     # ------------------------------------------------------------------ the hot path, one image
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,

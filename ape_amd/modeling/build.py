@@ -22,8 +22,12 @@ SIZES = {
                  dec_layers=2, num_queries=300, topk_eval=50),
     "small": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=3,
                   dec_layers=3, num_queries=900, topk_eval=100),
+    # select_box_nums_for_evaluation: 300 in the APE-L_D joint config (..._lsj1024_cp_16x4_1080k.py:108), 100 in the COCO
+    # instance-segmentation config that scripts/eval_APE-L_D.sh evaluates next (ape_deta_r50.py:121)
     "L_D": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336, enc_layers=6,
-                dec_layers=6, num_queries=900, topk_eval=100),
+                dec_layers=6, num_queries=900, topk_eval=300),
+    "L_D_coco": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336, enc_layers=6,
+                     dec_layers=6, num_queries=900, topk_eval=100),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
 }

@@ -44,7 +44,10 @@ class GraphedForward:
         boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
         boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
         keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-        rec = torch.cat([boxes, out["det_scores"][:, None], out["det_classes"][:, None].float(),
+        # dropped rows (empty slots, empty boxes after the rescale) carry score -1 in the record, so the 6-column view that
+        # is all-gathered across ranks tells kept from dropped without the keep column
+        score = torch.where(keep, out["det_scores"], torch.full_like(out["det_scores"], -1.0))
+        rec = torch.cat([boxes, score[:, None], out["det_classes"][:, None].float(),
                          out["det_query"][:, None].float(), keep[:, None].float()], 1)                 # [k, 8]
         # kept detections first (stable): the host then takes PREFIX views of the pinned buffers instead of gathering
         # ~1 MB per mask with a boolean index (a 105 MB host copy per image whenever one detection is dropped)
@@ -55,6 +58,14 @@ class GraphedForward:
     def _device_all(self, images, text, height, width, prompt):
         """the B forwards: image 0 on the current stream, the others as forked branches"""
         from . import ops
+        mv = self.mv
+        if prompt == "expression" and mv.test_topk_per_image != 1:      # (:183-194) forward() applies the same rule
+            saved = mv.test_topk_per_image
+            mv.test_topk_per_image = 1
+            try:
+                return self._device_all(images, text, height, width, prompt)
+            finally:
+                mv.test_topk_per_image = saved
         if len(images) == 1:
             return [self._device_part(images[0], text, height, width, prompt)]
         # whole images are the parallel branches; the finer-grained forks inside a forward run inline (nested fork/join
@@ -71,7 +82,10 @@ class GraphedForward:
         B = len(images)
         entry = SimpleNamespace()
         entry.images = [im.clone() for im in images]
-        entry.text = text
+        entry.text = text             # keeps the bank alive: the graph key holds its address
+        # warm-up and capture run fusion_tokens, which (phrase / expression prompts, persistent bank) shifts the phrase bank
+        # in place: snapshot it and restore it afterwards so that building a graph does not count as three extra images
+        bank = mv.features_phrase_bank.clone() if getattr(mv, "text_feature_bank", False) else None
         for _ in range(2):            # warm every cache (weight packing, geometry, text side) outside the capture
             self._device_all(entry.images, text, height, width, prompt)
         torch.cuda.synchronize()
@@ -81,7 +95,9 @@ class GraphedForward:
                 entry.outs = self._device_all(entry.images, text, height, width, prompt)
         else:
             entry.graph = None
-        k = mv.test_topk_per_image
+        if bank is not None:
+            mv.features_phrase_bank.copy_(bank)
+        k = 1 if prompt == "expression" else mv.test_topk_per_image       # (:183-194) one box per referring expression
         has_masks = self.with_masks and mv.test_mask_on
         entry.slots = []
         for _ in range(self.SLOTS):
@@ -110,7 +126,9 @@ class GraphedForward:
         if any(tuple(im.shape[-2:]) != (h, w) for im in images):
             raise ValueError("GraphedForward.submit: the images of one step must share a size")
         height, width = height or h, width or w
-        key = (h, w, height, width, text.data_ptr(), tuple(text.shape), prompt)
+        # the classifier's text side is a per-vocabulary constant baked into the capture: an in-place update of the bank
+        # (text._version) must rebuild the graph, exactly like a new bank
+        key = (h, w, height, width, text.data_ptr(), text._version, tuple(text.shape), prompt)
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.max_graphs:

@@ -13,11 +13,20 @@ CONFIGS = {
     # 32x32 tokens, windows of 16x16, 21824 encoder tokens
     "small": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224,
                   enc_layers=3, dec_layers=3, num_queries=900, topk_eval=100),
+    # select_box_nums_for_evaluation: 300 in the APE-L_D joint config (ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py:108,
+    # LVIS-1203 evaluation), 100 in the COCO config scripts/eval_APE-L_D.sh also runs (ape_deta_r50.py:121) -> "L_D_coco"
     "L_D": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
-                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=100),
+                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300),
+    "L_D_coco": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
+                     enc_layers=6, dec_layers=6, num_queries=900, topk_eval=100, spec="L_D"),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
-                     enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
+                     enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500, spec="L_D"),
 }
+
+
+def spec_name(cfg_name):
+    """state_spec_<name>.json that holds the state-dict contract of this configuration (top-k variants share one)"""
+    return CONFIGS[cfg_name].get("spec", cfg_name)
 
 
 def window_block_indexes(depth):

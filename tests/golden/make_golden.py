@@ -16,7 +16,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import ref_model, run_reference as rr  # noqa: E402
-from oracle.configs import CONFIGS  # noqa: E402
+from oracle.configs import CONFIGS, spec_name  # noqa: E402
 
 CASES = {
     # name: (cfg, weight seed, image seed, (h, w), K classes, text seed)
@@ -30,7 +30,18 @@ CASES = {
     # evaluation-dataset mode (set_eval_dataset): names from the metadata, detector on the 6 thing columns, semantic AND
     # panoptic branches on (panoptic thresholds loosened so that seeded weights produce segments)
     "tiny_panoptic": ("tiny", 3, 9, (208, 240), 10, 21, "name", "semantic", "panoptic"),
+    # ---- the BASELINE.json configurations at full size: minutes of CPU each, generated once
+    # config 2: APE-L_D, 1024x1024 uint8-uniform image seed 2, 80 classes seed 3, name prompt, top-100 (COCO config)
+    "L_D_coco80": ("L_D_coco", 0, 2, (1024, 1024), 80, 3),
+    # config 3: 1203-class vocabulary seed 4, top-300 (the L_D config's own select_box_nums_for_evaluation)
+    "L_D_lvis1203": ("L_D", 0, 2, (1024, 1024), 1203, 4),
+    # config 4 flavour: a COCO-shaped (padded) image in the 1024 square
+    "L_D_padded": ("L_D_coco", 0, 5, (683, 1024), 80, 3),
+    # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
+    "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }
+BIG_SEMANTIC_META = {"entity": "thing+stuff", "thing_classes": [f"t{i}" for i in range(80)],
+                     "stuff_classes": ["things"] + [f"s{i}" for i in range(53)]}
 PANOPTIC_CFG = dict(prob=0.45, pano_temp=0.06, transform_eval=True, object_mask_threshold=0.0, overlap_threshold=0.0)
 SEMANTIC_META = {"entity": "thing+stuff", "thing_classes": [f"t{i}" for i in range(6)],
                  "stuff_classes": ["things"] + [f"s{i}" for i in range(4)]}
@@ -65,25 +76,43 @@ def main():
             continue
         cfg, wseed, image, text = make_inputs(case)
         prompt = CASES[case][6] if len(CASES[case]) > 6 else "name"
-        sem = SEMANTIC_META if len(CASES[case]) > 7 else None
+        sem = (BIG_SEMANTIC_META if cfg.startswith("L_D") else SEMANTIC_META) if len(CASES[case]) > 7 else None
         h, w = image.shape[-2:]
-        out_hw = (int(1.5 * h), int(1.5 * w)) if sem else (None, None)
+        out_hw = ((h, w) if cfg.startswith("L_D") else (int(1.5 * h), int(1.5 * w))) if sem else (None, None)
         pan = len(CASES[case]) > 8
         if pan:
             sem = dict(sem, thing_dataset_id_to_contiguous_id={i + 1: i for i in range(len(sem["thing_classes"]))})
         S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt, semantic=sem, height=out_hw[0], width=out_hw[1],
                                             eval_dataset=pan, panoptic_configs=PANOPTIC_CFG if pan else None)
-        with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
-            json.dump(spec, fh)
+        if spec_name(cfg) == cfg:
+            with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
+                json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
+        big = cfg.startswith("L_D")
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)
                 if k in FULL or (k in FULL_SEM and k != "sem_seg"):
                     gold["full"][k] = v.clone()
+        if big:
+            # full-size cases: keep the fixture small.  Logits of wide vocabularies: a seeded 128-column subset (the
+            # fingerprint and the detections still cover every column)
+            if gold["full"]["pred_logits"].shape[-1] > 256:
+                cols = torch.randperm(gold["full"]["pred_logits"].shape[-1], generator=torch.Generator().manual_seed(11))[:128].sort()[0]
+                gold["logit_cols"] = cols
+                gold["full"]["pred_logits"] = gold["full"]["pred_logits"][..., cols].clone()
+            # argmax masks: sign bits of the low-resolution mask logits of the first 100 kept detections (+ a tie mask:
+            # |logit| < 1e-3 * absmax is excluded from the comparison), and the final pasted masks of the first 4 instances
+            import numpy as np
+            pm = S["pred_masks"][0][S["det_query"][:100]]
+            gold["full"]["mask_sign_kept"] = torch.from_numpy(np.packbits((pm > 0).numpy(), axis=-1))
+            gold["full"]["mask_tie_kept"] = torch.from_numpy(np.packbits((pm.abs() < 1e-3 * pm.abs().max()).numpy(), axis=-1))
+            gold["full"]["final_masks4"] = torch.from_numpy(np.packbits(inst["pred_masks"][:4].bool().numpy(), axis=-1))
         if sem:
             gold["semantic_meta"], gold["out_hw"] = sem, out_hw
-            gold["full"]["sem_seg_argmax"] = S["sem_seg"].argmax(0).to(torch.uint8)      # [H, W] labels
+            lab = S["sem_seg"].argmax(0).to(torch.uint8)                                   # [H, W] labels
+            gold["sem_stride"] = 4 if lab.numel() > (1 << 20) else 1                       # big maps: every 4th row / column
+            gold["full"]["sem_seg_argmax"] = lab[:: gold["sem_stride"], :: gold["sem_stride"]].clone()
         if pan:
             gold["panoptic_cfg"] = PANOPTIC_CFG
             gold["full"]["panoptic_seg"] = S["panoptic_seg"].to(torch.int16)

@@ -23,6 +23,35 @@ def build_pair(case, device="cpu", dtype=torch.float32):
     return model, orc, image, text, gold
 
 
+def build_model(case, device="cpu", dtype=torch.float32):
+    """(our model with the fixture's seeded weights, image, text, golden) -- no oracle (full-size cases)"""
+    gold = U.load_golden(case)
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+    model = build_ape(cfg_name)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.endswith(("freqs_cos", "freqs_sin")) for m in missing), (missing, unexpected)
+    del sd
+    model.to(device)
+    model.model_vision.set_compute_dtype(dtype)
+    model.model_vision.text_feature_bank_reset = U.case_prompt(gold) == "phrase"
+    return model, image, text, gold
+
+
+def ref_layout(k, t, shape):
+    """our token-major stage tensor -> the reference's layout (the fingerprints index the reference's flat tensors)"""
+    t = t.detach()
+    if k in ("p2", "p3", "p4", "p5", "p6", "mask_features"):
+        return t.t().reshape(shape)
+    return t.reshape(shape)
+
+
+def unpack_bits(packed, width):
+    """inverse of np.packbits(..., axis=-1) for a bool tensor whose last dim was `width`"""
+    import numpy as np
+    return torch.from_numpy(np.unpackbits(packed.numpy(), axis=-1)[..., :width]).bool()
+
+
 def token_major(k, t):
     """oracle stage tensor (NCHW / batch-first) -> our token-major layout"""
     if k in ("p2", "p3", "p4", "p5", "p6", "mask_features"):

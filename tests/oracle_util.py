@@ -8,7 +8,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def load_spec(cfg_name):
-    with open(os.path.join(GOLDEN, f"state_spec_{cfg_name}.json")) as fh:
+    from oracle.configs import spec_name
+
+    with open(os.path.join(GOLDEN, f"state_spec_{spec_name(cfg_name)}.json")) as fh:
         return [(n, tuple(s)) for n, s in json.load(fh)]
 
 

@@ -45,7 +45,7 @@ def _worker(rank, world, port, ret):
 
     # the pipelined form (submit image i, collect image i-1) must deliver the same records in the same order
     class Pipelined:
-        def submit(self, image, text):
+        def submit(self, image, text, height=None, width=None, prompt="name"):
             from types import SimpleNamespace
             return SimpleNamespace(rec6=fwd(image, text)[1])
 

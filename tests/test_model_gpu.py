@@ -7,6 +7,19 @@ import oracle_util as U
 
 pytestmark = pytest.mark.gpu
 
+import os
+
+# APE_TEST_SELFCHECK=1: run the full-size parity tests on the CPU with ops := their torch definitions (validates the
+# harness and the host-side composition at APE-L_D size; minutes per case)
+SELF = os.environ.get("APE_TEST_SELFCHECK") == "1"
+DEV = "cpu" if SELF else "cuda"
+if SELF:
+    import ape_amd.ops as _ops
+    import ref_ops as _ref
+    for _n in dir(_ref):
+        if not _n.startswith("_") and callable(getattr(_ref, _n)) and hasattr(_ops, _n):
+            setattr(_ops, _n, getattr(_ref, _n))
+
 
 def _run(case, dtype):
     model, orc, image, text, gold = M.build_pair(case, device="cuda", dtype=dtype)
@@ -155,3 +168,146 @@ def test_eval_dataset_panoptic_on_gpu():
     """evaluation-dataset mode + panoptic merge with the fp32 HIP kernels"""
     model, orc, image, text, gold, image_c, text_c = _run("tiny_panoptic", torch.float32)
     M.check_panoptic(model, orc, image_c, text_c, gold, "cuda")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The BASELINE.json configurations at full size (APE-L_D, 1024^2 / 1536^2), against fixtures produced by executing the
+# reference on the same seeded inputs (tests/golden/make_golden.py: L_D_coco80 = config 2, L_D_lvis1203 = config 3,
+# L_D_padded = a COCO-shaped image of config 4, L_D_1536_sseg = config 5).  No oracle run here: fixtures only.
+# ------------------------------------------------------------------------------------------------------------------
+LD_STAGES = ("p2", "p4", "p6", "enc0_fused_v", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact",
+             "mask_features", "mask_embed")
+
+
+def _ld_heads(stages, gold):
+    logits = stages["pred_logits"].float().cpu()
+    if "logit_cols" in gold:
+        logits = logits[:, gold["logit_cols"]]
+    return U.relerr(logits, gold["full"]["pred_logits"][0]), U.relerr(stages["pred_boxes"].float().cpu(), gold["full"]["pred_boxes"][0])
+
+
+def _ld_mask_sign_mismatch(stages, out, gold):
+    """argmax masks: sign of the low-resolution mask logits of the kept detections vs the reference's, per query; pixels the
+    reference marks as ties (|logit| < 1e-3 absmax) are excluded"""
+    q_ref = gold["full"]["det_query"][:100].tolist()
+    npix = stages["det_mask_logits"].shape[1]
+    sign_ref = M.unpack_bits(gold["full"]["mask_sign_kept"].flatten(1), npix)
+    tie_ref = M.unpack_bits(gold["full"]["mask_tie_kept"].flatten(1), npix)
+    ours = {int(q): i for i, q in enumerate(out["det_query"].cpu().tolist())}
+    rows = [(ours[q], j) for j, q in enumerate(q_ref) if q in ours]
+    mine = (stages["det_mask_logits"].float().cpu() > 0)[[i for i, _ in rows]]
+    ref, tie = sign_ref[[j for _, j in rows]], tie_ref[[j for _, j in rows]]
+    bad = ((mine != ref) & ~tie).float().sum().item()
+    return bad / max((~tie).float().sum().item(), 1.0), len(rows)
+
+
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg"])
+def test_L_D_fp32_matches_reference(case):
+    """T1 at the benchmarked sizes: fp32 HIP kernels vs the reference run; north_star tolerance 1e-3 on logits / boxes,
+    identical argmax masks"""
+    model, image, text, gold = M.build_model(case, DEV, torch.float32)
+    mv = model.model_vision
+    image, text = image.to(DEV), text.to(DEV)
+    sem = None
+    if "semantic_meta" in gold:
+        meta = gold["semantic_meta"]
+        mv.semantic_on = True
+        mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
+        sem = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    stages = {}
+    mv.forward_single(image, text, stages=stages)                       # own proposal selection
+    for k in LD_STAGES:
+        fp = gold["stages"][k]
+        e = U.check_fingerprint(M.ref_layout(k, stages[k].float(), fp["shape"]), fp, 1e-3, k)
+        print(f"[L_D fp32 {case}] {k}: {e:.2e}")
+    ov = M.set_overlap(stages["topk_proposals"].cpu(), gold["full"]["topk_proposals"][0])
+    print(f"[L_D fp32 {case}] proposal overlap with the reference run: {ov:.4f}")
+    assert ov >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    cols = ("first", len(meta["thing_classes"])) if sem else None       # (:578-590) the detector sees the thing columns
+    out = mv.forward_single(image, text, forced_topk=ref_topk.to(DEV), stages=stages, semantic=sem, detector_columns=cols)
+    el, eb = _ld_heads(stages, gold)
+    print(f"[L_D fp32 {case}] pred_logits {el:.2e} pred_boxes {eb:.2e} (vs reference fixture, tolerance 1e-3)")
+    assert el < 1e-3 and eb < 1e-3
+    frac = U.match_detections(out["det_boxes"].cpu(), out["det_scores"].cpu(), out["det_classes"].cpu(),
+                              gold["full"]["det_boxes"], gold["full"]["det_scores"], gold["full"]["det_classes"])
+    print(f"[L_D fp32 {case}] detections reproduced: {frac:.3f} of {len(gold['full']['det_scores'])}")
+    assert frac >= 0.97
+    mm, n = _ld_mask_sign_mismatch(stages, out, gold)
+    print(f"[L_D fp32 {case}] mask-logit sign mismatch {mm:.2e} over {n} kept detections")
+    assert n >= 95 and mm < 1e-4
+    # final pasted masks of the first detections (detector_postprocess), when the ordering agrees
+    inst = mv.postprocess_instance(out, tuple(image.shape[-2:]), image.shape[-2], image.shape[-1])
+    want = M.unpack_bits(gold["full"]["final_masks4"], image.shape[-1])
+    same_order = torch.equal(inst.query_index[:4], gold["full"]["det_query"][:4]) and torch.equal(inst.pred_classes[:4], gold["full"]["det_classes"][:4])
+    if same_order:
+        mm = (inst.pred_masks[:4] != want).float().mean().item()
+        print(f"[L_D fp32 {case}] final mask mismatch (first 4 instances): {mm:.2e}")
+        assert mm < 1e-3
+    areas = inst.pred_masks.flatten(1).sum(1).float()
+    if len(areas) == len(gold["instances"]["mask_area"]) and torch.equal(inst.query_index, gold["full"]["det_query"]):
+        rel = ((areas - gold["instances"]["mask_area"].float()).abs() / gold["instances"]["mask_area"].float().clamp_min(64)).max().item()
+        print(f"[L_D fp32 {case}] max relative mask-area difference: {rel:.2e}")
+        assert rel < 2e-2
+    if sem:
+        st = gold.get("sem_stride", 1)
+        lab = out["sem_seg"].argmax(0).to(torch.uint8).cpu()[::st, ::st]
+        agree = (lab == gold["full"]["sem_seg_argmax"]).float().mean().item()
+        print(f"[L_D fp32 {case}] semantic label agreement with the reference run: {agree:.5f}")
+        assert agree > 0.999
+
+
+# measured on MI355X (profiles/r02_parity_L_D.log); asserted at 2x the measured value
+LD_BF16_T2 = {"p2": 1.0, "memory": 1.0, "enc_class": 1.0, "pred_logits": 1.0, "pred_boxes": 1.0}
+LD_BF16_T3 = {"p2": 1.0, "memory": 1.0, "pred_logits": 1.0, "pred_boxes": 1.0}
+
+
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203"])
+def test_L_D_bf16_pipeline(case):
+    """The benchmarked arithmetic at the benchmarked size.  T2: the bf16 HIP pipeline vs the SAME pipeline evaluated with the
+    torch definitions of the ops (tests/ref_ops.py, on the device) at exactly the product's rounding points.  T3: vs the fp32
+    reference fixture (reported + detection-level agreement)."""
+    import ape_amd.ops as ops
+    import ref_ops
+
+    model, image, text, gold = M.build_model(case, DEV, torch.bfloat16)
+    mv = model.model_vision
+    image, text = image.to(DEV), text.to(DEV)
+    ref_topk = gold["full"]["topk_proposals"][0].to(DEV)
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    keep = {k: stages[k].float().cpu() for k in ("p2", "memory", "enc_class", "pred_logits", "pred_boxes")}
+    # ---- T3
+    t3 = {}
+    for k in ("p2", "memory"):
+        fp = gold["stages"][k]
+        got = M.ref_layout(k, stages[k].float(), fp["shape"]).reshape(-1)[fp["idx"]].cpu()
+        t3[k] = ((got - fp["samples"].float()).abs().max() / fp["absmax"]).item()
+    t3["pred_logits"], t3["pred_boxes"] = _ld_heads(stages, gold)
+    frac = U.match_detections(out["det_boxes"].cpu(), out["det_scores"].cpu(), out["det_classes"].cpu(),
+                              gold["full"]["det_boxes"], gold["full"]["det_scores"], gold["full"]["det_classes"],
+                              box_tol=5e-2, score_tol=5e-2)
+    mm, n = _ld_mask_sign_mismatch(stages, out, gold)
+    print(f"[L_D bf16 {case}] T3 vs fp32 reference:", {k: f"{v:.2e}" for k, v in t3.items()},
+          f"detections matched (box 5%, score 0.05): {frac:.3f}; mask sign mismatch {mm:.2e} over {n} shared detections")
+    # ---- T2: same composition, torch definitions, same rounding points, on the device
+    saved = {n_: getattr(ops, n_) for n_ in dir(ref_ops) if not n_.startswith("_") and callable(getattr(ref_ops, n_)) and hasattr(ops, n_)}
+    del stages, out
+    if not SELF:
+        torch.cuda.empty_cache()
+    try:
+        for n_ in saved:
+            setattr(ops, n_, getattr(ref_ops, n_))
+        st_r = {}
+        mv.forward_single(image, text, forced_topk=ref_topk, stages=st_r)
+    finally:
+        for n_, f in saved.items():
+            setattr(ops, n_, f)
+    t2 = {k: U.relerr(keep[k], st_r[k].float().cpu()) for k in keep}
+    print(f"[L_D bf16 {case}] T2 vs same-rounding torch evaluation:", {k: f"{v:.2e}" for k, v in t2.items()})
+    for k, v in t2.items():
+        assert v < LD_BF16_T2[k], (k, v)
+    for k, v in t3.items():
+        assert v < LD_BF16_T3[k], (k, v)
+    assert frac >= 0.5

@@ -502,3 +502,59 @@ def test_gemm_folded_layernorm(ops, dtype):
     if dtype == torch.bfloat16:
         got2 = ops.gemm(h, wf, c2, residual=res, rownorm=(rs, sh, c1), out_dtype=torch.float32, splitk=2, tile64=0)
         assert relerr(got2, got) < 1e-5
+
+
+@pytest.mark.parametrize("stagger", [0, 1])
+@pytest.mark.parametrize("tile", [3, 4])
+def test_gemm_p8(ops, tile, stagger, monkeypatch):
+    """256x256 / 256x128 eight-wave counted-wait kernel (gemm_p8.hip): every specialised epilogue, the generic one, ragged
+    M / N edges, 1..many K tiles, transposed output (operand exchange), both barrier schedules"""
+    monkeypatch.setenv("APE_GEMM_P8_STAGGER", str(stagger))
+    bf = torch.bfloat16
+
+    def check(name, a, w, bias, tol=None, **kw):
+        got = ops.gemm(a, w, bias, tile64=tile, **kw)
+        if not SELF:
+            from ape_amd import _lib
+            assert b"p8" in _lib.load().ape_hip_gemm_last_kernel(), name      # the case really took the new kernel
+        ref = ref_ops.gemm(a, w, bias, **kw)
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        e = relerr(got, ref)
+        odt = kw.get("out_dtype", bf)
+        print(f"gemm p8 tile={tile} stagger={stagger} [{name}] M{a.shape[0]} N{w.shape[0]} K{a.shape[1]}: {e:.3e}")
+        assert e < (tol or (6e-3 if odt == bf else 3e-4)), name
+
+    for (M, N, K) in [(256, 256, 64), (512, 512, 128), (1000, 700, 320), (4096, 2048, 1024), (300, 136, 192), (87296, 256, 2048)]:
+        a, w = rnd(M, K, dtype=bf, seed=1), rnd(N, K, dtype=bf, scale=K ** -0.5, seed=2)
+        bias = rnd(N, seed=3)
+        check("plain", a, w, bias)
+        check("f32out_nobias", a, w, None, out_dtype=torch.float32)
+        if M > 50000:
+            check("res16", a, w, bias, residual=rnd(M, N, dtype=bf, seed=5))
+            continue
+        res32, res16 = rnd(M, N, seed=4), rnd(M, N, dtype=bf, seed=5)
+        mask = (torch.arange(M) % 7 == 3).to(DEV)
+        check("res32", a, w, bias, residual=res32, out_dtype=torch.float32)
+        check("res16_relu", a, w, bias, residual=res16, act=ref_ops.ACT_RELU)
+        check("gelu_generic", a, w, bias, act=ref_ops.ACT_GELU, out_dtype=torch.float32)
+        check("alpha_clamp_mask", a, w, bias, alpha=0.37, clamp=0.8, rowmask=mask, mask_mode=ref_ops.MASK_ZERO_OUTPUT, out_dtype=torch.float32)
+        check("trans", a, w, bias, trans_out=True, m_pad=(M + 63) // 64 * 64 + 64)
+        check("trans_relu_f32", a, w, None, trans_out=True, act=ref_ops.ACT_RELU, out_dtype=torch.float32)
+        if N % 4 == 0:
+            check("swiglu", a, w, bias, act=ref_ops.ACT_SWIGLU)
+            check("swiglu_f32", a, w, bias, act=ref_ops.ACT_SWIGLU, out_dtype=torch.float32)
+        if N % 64 == 0:
+            # RoPE, fast path (power-of-two table rows) and generic path (rows cycle every 100)
+            cos, sin = rnd(128, 64, seed=7), rnd(128, 64, seed=8)
+            check("rope_pow2", a, w, bias, rope=(cos, sin, 128, 64, N // 2 // 64 * 64), out_dtype=torch.float32)
+            check("rope_bf16", a, w, bias, rope=(cos, sin, 128, 64, N // 2 // 64 * 64))
+            check("rope_mod100", a, w, bias, rope=(cos[:100].contiguous(), sin[:100].contiguous(), 100, 64, N // 2 // 64 * 64), out_dtype=torch.float32)
+        rs, sh, cv = rnd(M, seed=10).abs() + 0.5, rnd(M, seed=11), rnd(N, seed=12)
+        check("rownorm_res32", a, w, bias, rownorm=(rs, sh, cv), residual=res32, out_dtype=torch.float32)
+    # strided operands and output views
+    big = rnd(1024, 3 * 256, dtype=bf, seed=7)
+    w = rnd(512, 256, dtype=bf, scale=1 / 16, seed=8)
+    out = torch.zeros(1024, 1024, dtype=bf, device=DEV)
+    ops.gemm(big[:, 256:512], w, None, out=out[:, 256:768], tile64=tile)
+    assert relerr(out[:, 256:768], ref_ops.gemm(big[:, 256:512], w, None)) < 6e-3
+    assert out[:, :256].abs().max().item() == 0 and out[:, 768:].abs().max().item() == 0
