@@ -69,6 +69,8 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ape_hip_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p]),
+    "ape_hip_attention_strided": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_int, c_int, c_float, c_int, c_void_p]),
     "ape_hip_patchify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p,
                                  c_int, c_int, c_void_p]),
     "ape_hip_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

@@ -19,6 +19,7 @@ struct AttnParams {
   const void* Q; const void* K; const void* Vt; void* O;
   int ldq, ldk, ldvt, ldo;
   int N, H;
+  int bstride;       // rows (tokens) between consecutive batch items / windows, >= N
   float scale_log2;  // scale * log2(e)
   float scale;
 };
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     const int qc = qrow[u] < N ? qrow[u] : N - 1;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
-      qf[u][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * N + qc) * p.ldq + h * HD + ks * 32 + fq * 8));
+      qf[u][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(Qp + ((size_t)b * p.bstride + qc) * p.ldq + h * HD + ks * 32 + fq * 8));
   }
 
   // staging: K tile (64 keys x HD) and Vt tile (HD x 64 keys) go global -> LDS with global_load_lds (no VGPR round trip,
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
       const int row = slot / KC, cp = slot % KC;
       const int c = KC == 8 ? (cp ^ ((row >> 1) & 7)) : (cp ^ (((row >> 3) & 1) << 1));
       krow[i] = row;
-      ksrc[i] = Kp + (size_t)b * N * p.ldk + h * HD + c * 8;
+      ksrc[i] = Kp + (size_t)b * p.bstride * p.ldk + h * HD + c * 8;
     }
     {
       const int row = slot >> 3, cp = slot & 7;
       const int c = cp ^ ((row >> 1) & 7);
-      vsrc[i] = Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * N + c * 8;
+      vsrc[i] = Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * p.bstride + c * 8;
     }
   }
   auto issue = [&](int t, int buf) {
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   for (int u = 0; u < QT; ++u) {
     const float inv = 1.f / lacc[u][0];    // every row of the ones-tile holds the full sum over keys for query frow
     if (qrow[u] < N) {
-      bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * N + qrow[u]) * p.ldo + h * HD + fq * 4;
+      bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 4;
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
   const int qrow_c = qrow < N ? qrow : N - 1;
   float q[HD], o[HD];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) { q[d] = Qp[((size_t)b * N + qrow_c) * p.ldq + h * HD + d] * p.scale; o[d] = 0.f; }
+  for (int d = 0; d < HD; ++d) { q[d] = Qp[((size_t)b * p.bstride + qrow_c) * p.ldq + h * HD + d] * p.scale; o[d] = 0.f; }
   float m_run = -INFINITY, l_run = 0.f;
   const int nt = (N + 63) / 64;
   for (int t = 0; t < nt; ++t) {
@@ -239,12 +240,12 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
     for (int idx = lane; idx < 64 * HD; idx += 64) {
       const int row = idx / HD, d = idx % HD;
       int key = key0 + row; key = key < N ? key : N - 1;
-      sK[row][d] = Kp[((size_t)b * N + key) * p.ldk + h * HD + d];
+      sK[row][d] = Kp[((size_t)b * p.bstride + key) * p.ldk + h * HD + d];
     }
     for (int idx = lane; idx < 64 * HD; idx += 64) {
       const int d = idx / 64, kk = idx % 64;
       const int key = key0 + kk;
-      sV[kk][d] = key < N ? Vp[(size_t)(h * HD + d) * p.ldvt + (size_t)b * N + key] : 0.f;
+      sV[kk][d] = key < N ? Vp[(size_t)(h * HD + d) * p.ldvt + (size_t)b * p.bstride + key] : 0.f;
     }
     __syncthreads();
     for (int c0 = 0; c0 < 64; c0 += 16) {
@@ -276,19 +277,20 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
     }
   }
   if (qrow < N) {
-    float* op = reinterpret_cast<float*>(p.O) + ((size_t)b * N + qrow) * p.ldo + h * HD;
+    float* op = reinterpret_cast<float*>(p.O) + ((size_t)b * p.bstride + qrow) * p.ldo + h * HD;
     const float inv = 1.f / l_run;
 #pragma unroll
     for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
   }
 }
 
-extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
-                                 int B, int N, int H, int HD, float scale, int dt, void* stream) {
+extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                         int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream) {
   APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
   APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64), "ape_hip_attention: bad shape (HD must be 32 or 64)");
+  APE_CHECK_ARG(bstride >= N, "ape_hip_attention: batch stride %d < N %d", bstride, N);
   AttnParams p;
-  p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H;
+  p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H; p.bstride = bstride;
   p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(N, 64), H, B);
@@ -296,7 +298,7 @@ extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk,
     APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "ape_hip_attention(bf16): ld alignment");
     APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 8 == 0,
                   "ape_hip_attention(bf16): pointer alignment");
-    APE_CHECK_ARG(B == 1 || N % 8 == 0, "ape_hip_attention(bf16): batched windows need N %% 8 == 0");
+    APE_CHECK_ARG(B == 1 || bstride % 8 == 0, "ape_hip_attention(bf16): batched windows need a batch stride %% 8 == 0");
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
     const bool big = (size_t)ceil_div(N, 128) * H * B >= 512;
     if (big) grid.x = ceil_div(N, 128);
@@ -308,4 +310,9 @@ extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk,
   }
   APE_CHECK_LAUNCH("ape_hip_attention");
   return 0;
+}
+
+extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                 int B, int N, int H, int HD, float scale, int dt, void* stream) {
+  return ape_hip_attention_strided(Q, ldq, K, ldk, Vt, ldvt, O, ldo, B, N, N, H, HD, scale, dt, stream);
 }

@@ -311,15 +311,16 @@ class DeformableDETRSegmVL(nn.Module):
 
     # ------------------------------------------------------------------ the hot path, one image
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
-                       semantic=None, detector_columns=None, panoptic=False):
+                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
         instance: run the detection branch; semantic: metadata dict (entity, thing_classes, stuff_classes) to run the
-        semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes."""
+        semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes;
+        vit_feat: this image's rows of a batched ViT pass (backbone.net.forward_tokens on a list of images)."""
         dt = self.compute_dtype
         P = self.packed(dt)
         h, w = image.shape[-2:]
         t0 = time.perf_counter()
-        maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std)
+        maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std, vit_feat=vit_feat)
         self.backbone_time = time.perf_counter() - t0
         names = self.neck.in_features
         level_shapes = [maps[f][1] for f in names]

@@ -125,8 +125,9 @@ class Block(nn.Module):
         return dict(w3f=w3f, c1=w3f.float().sum(dim=1).contiguous(),                 # row sums of the ROUNDED folded weight
                     c2=(w3 @ b + m.w3.bias.detach().float()).contiguous())
 
-    def forward_tokens(self, x, dt, rope, nwin, ntok_win, vt_buf, last=False):
-        """x [N, E] fp32 residual stream (window-major). rope = (cos, sin, rows). Returns the new stream."""
+    def forward_tokens(self, x, dt, rope, nwin, ntok_win, vt_buf, last=False, images=1):
+        """x [images * N, E] fp32 residual stream (window-major per image). rope = (cos, sin, rows); nwin = windows of ALL
+        images.  Returns the new stream."""
         P = self.packed(dt)
         E = x.shape[1]
         nh = self.attn.num_heads
@@ -139,7 +140,7 @@ class Block(nn.Module):
         if self.window_size > 0:
             o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=nwin, n=ntok_win, heads=nh, head_dim=hd, scale=hd ** -0.5)
         else:
-            o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=1, n=x.shape[0], heads=nh, head_dim=hd, scale=hd ** -0.5)
+            o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=images, n=x.shape[0] // images, heads=nh, head_dim=hd, scale=hd ** -0.5)
         o = ops.layernorm(o, P["nin"][0], P["nin"][1], P["nin"][2], out_dtype=dt)
         x = ops.gemm(o, P["wproj"], P["bproj"], residual=x, out_dtype=torch.float32)
         xn = ops.layernorm(x, P["n2"][0], P["n2"][1], P["n2"][2], out_dtype=dt)
@@ -212,6 +213,10 @@ class ViT(Backbone):
         self.compute_dtype = torch.bfloat16
         attach_cache(self)
 
+    def token_order(self, hw):
+        """(tok2raster, raster2tok) of the feature this ViT hands to the pyramid: window-major order"""
+        return window_major_order(hw, hw, self.window_size)
+
     def packed(self, dt):
         def build(dt):
             hw = self.img_size // self.patch_size
@@ -236,18 +241,32 @@ class ViT(Backbone):
         return self._pack.get(self, dt, build)
 
     def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
-        """image [3,h,w] fp32 (h,w <= img_size) -> last feature [N, E] in the compute dtype, WINDOW-MAJOR token order"""
+        """image [3,h,w] fp32 (h,w <= img_size) -> last feature [N, E] in the compute dtype, WINDOW-MAJOR token order.
+        A list of B images (sizes may differ) runs as ONE pass over [B * N, E]: every linear sees B x 4096 rows (the big-tile
+        GEMM kernels need that many to fill 256 CUs), windows / global attention stay per image.  Rows are independent in
+        every op of the ViT, so each image's result is bit-identical to its own single-image pass."""
         dt = self.compute_dtype
         P = self.packed(dt)
         hw = P["hw"]
         n = hw * hw
-        patches = ops.patchify(image, P["t2r"], hw, hw, mean, std, out_dtype=dt)
-        x = ops.gemm(patches, P["wpe"], P["bpe"], residual=P["pos"], out_dtype=torch.float32)
-        nwin = (hw // self.window_size) ** 2
-        vt_buf = torch.zeros((self.embed_dim, round_up(n, 64)), dtype=dt, device=x.device)
+        images = list(image) if isinstance(image, (list, tuple)) else [image]
+        B = len(images)
+        if B == 1:
+            patches = ops.patchify(images[0], P["t2r"], hw, hw, mean, std, out_dtype=dt)
+            pos = P["pos"]
+        else:
+            patches = torch.empty((B * n, 768), dtype=dt, device=images[0].device)
+            for b, im in enumerate(images):
+                ops.patchify(im, P["t2r"], hw, hw, mean, std, out_dtype=dt, out=patches[b * n:(b + 1) * n])
+            if ("pos", B) not in P:
+                P[("pos", B)] = P["pos"].repeat(B, 1).contiguous()
+            pos = P[("pos", B)]
+        x = ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32)
+        nwin = (hw // self.window_size) ** 2 * B
+        vt_buf = torch.zeros((self.embed_dim, round_up(B * n, 64)), dtype=dt, device=x.device)
         for i, blk in enumerate(self.blocks):
             rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
-            x = blk.forward_tokens(x, dt, rope, nwin, self.window_size ** 2, vt_buf, last=(i == len(self.blocks) - 1))
+            x = blk.forward_tokens(x, dt, rope, nwin, self.window_size ** 2, vt_buf, last=(i == len(self.blocks) - 1), images=B)
         return x
 
     def forward(self, x):
@@ -343,7 +362,7 @@ class SimpleFeaturePyramid(Backbone):
         def build(dt):
             hw = self.net.img_size // self.net.patch_size
             dev = self.simfp_4[0].weight.device
-            _, r2t = window_major_order(hw, hw, self.net.window_size)
+            _, r2t = self.net.token_order(hw)          # vit_eva_clip: window-major, vit_eva02: raster
             r2t = r2t.long()
             # raster (Y,X) of the x2 / x4 maps -> row of the nested (token, i, j[, i2, j2]) layouts the deconv GEMMs produce
             Y2, X2 = torch.meshgrid(torch.arange(2 * hw), torch.arange(2 * hw), indexing="ij")
@@ -370,12 +389,13 @@ class SimpleFeaturePyramid(Backbone):
         cols = ops.im2col3x3(y, perm, H, W)
         return ops.layernorm(ops.gemm(cols, c3[0], None), c3[1], c3[2], c3[3], out_dtype=dt)
 
-    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
-        """-> dict name -> ([H*W, C] raster token-major map in the compute dtype, (H, W))"""
+    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), vit_feat=None):
+        """-> dict name -> ([H*W, C] raster token-major map in the compute dtype, (H, W)).  vit_feat: this image's rows of a
+        batched ViT pass (ViT.forward_tokens on a list) -- the pyramid then starts from them."""
         dt = self.compute_dtype
         P = self.packed(dt)
         hw = P["hw"]
-        x = self.net.forward_tokens(image, mean, std)          # [hw*hw, E] window-major
+        x = vit_feat if vit_feat is not None else self.net.forward_tokens(image, mean, std)          # [hw*hw, E] window-major
         out = {}
         # The four scales only share the ViT output: stride 8 / 16 / 32 run as parallel graph branches next to the heavy
         # stride-4 chain (their kernels are small launches that leave most of the chip idle).

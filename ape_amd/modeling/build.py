@@ -28,6 +28,9 @@ SIZES = {
                 dec_layers=6, num_queries=900, topk_eval=300),
     "L_D_coco": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336, enc_layers=6,
                      dec_layers=6, num_queries=900, topk_eval=100),
+    # APE-Ti (BASELINE config 1): configs/common/backbone/vitt_eva02.py:10-41 -- the EVA-02 MIM ViT-Ti of vit_eva02.py
+    "Ti": dict(img_size=1024, embed_dim=192, depth=12, num_heads=3, window_size=14, pretrain_img_size=224, enc_layers=6,
+               dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02"),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
 }
@@ -36,12 +39,21 @@ SIZES = {
 def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
     c = SimpleNamespace(**{**SIZES[size], **overrides}) if isinstance(size, str) else SimpleNamespace(**{**size, **overrides})
     feats = ["p2", "p3", "p4", "p5", "p6"]
-    net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
-              drop_path_rate=0.4, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
-              norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=[i for i in range(c.depth) if i % 3 != 2],
-              residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=True, xattn=True,
-              rope=True, pt_hw_seq_len=16, intp_freq=True, naiveswiglu=True, subln=True,
-              pretrain_img_size=c.pretrain_img_size, pretrain_use_cls_token=True)
+    if getattr(c, "backbone", "eva_clip") == "eva02":
+        from .backbone import vit_eva02
+        net = vit_eva02.ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
+                            drop_path_rate=0.8, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
+                            norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                            window_block_indexes=[i for i in range(c.depth) if i % 3 != 2], residual_block_indexes=[],
+                            use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True, subln=False,
+                            swiglu=True, naiveswiglu=False)
+    else:
+        net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
+                  drop_path_rate=0.4, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
+                  norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=[i for i in range(c.depth) if i % 3 != 2],
+                  residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=True, xattn=True,
+                  rope=True, pt_hw_seq_len=16, intp_freq=True, naiveswiglu=True, subln=True,
+                  pretrain_img_size=c.pretrain_img_size, pretrain_use_cls_token=True)
     backbone = SimpleFeaturePyramid(net=net, in_feature="last_feat", out_channels=256, scale_factors=(4.0, 2.0, 1.0, 0.5),
                                     top_block=LastLevelMaxPool(), norm="LN", square_pad=c.img_size)
     shapes = {f: SimpleNamespace(channels=256) for f in feats}

@@ -65,6 +65,16 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
       prefers 128x128: 19 vs 21 us); long K stays on the 128x128 kernel unsplit (4096x1024x2752: 48 vs 50 us split)."""
     if dtype != torch.bfloat16 or K % 32 != 0:
         return 0, 1
+    if K % 64 == 0 and K >= 512:
+        # eight-wave 256 x 256 / 256 x 128 tiles with the counted-wait pipeline (csrc/gemm_p8.hip) once they fill the chip
+        # (measured, profiles/r02_gemm_p8_table.log: 16384x5504x1024 286 -> 193 us, 65536x256x2304 122 -> 77 us,
+        # 4096x2048x1024 35 -> 29 us with 256 x 128 tiles); a transposed output is the exchanged problem
+        rows, cols = (N, M) if trans_out else (M, N)
+        tm = (rows + 255) // 256
+        if tm * ((cols + 255) // 256) >= 200:
+            return 3, 1
+        if tm * ((cols + 127) // 128) >= 200:
+            return 4, 1
     t128 = ((M + 127) // 128) * ((N + 127) // 128)
     t64 = ((M + 63) // 64) * ((N + 63) // 64)
     splittable = not trans_out and act != ACT_SWIGLU and N % 4 == 0
@@ -276,17 +286,19 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     return out
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None):
-    """softmax(scale * q k^T) v per (window, head).  q,k: [batch*n, >=heads*head_dim] views; vt: V transposed
-    [heads*head_dim, >= round_up(batch*n, 64)] (finite padding); returns [batch*n, heads*head_dim]."""
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None):
+    """softmax(scale * q k^T) v per (window, head).  q,k: [rows, >=heads*head_dim] views; vt: V transposed
+    [heads*head_dim, >= round_up(rows, 64)] (finite padding); returns [rows, heads*head_dim].  Window b owns rows
+    b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride)."""
     _dev(q, k, vt, out)
     _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(vt, "vt")
     if not (q.dtype == k.dtype == vt.dtype):
         raise TypeError("ape_amd.ops.attention: q/k/vt must share a dtype")
+    stride = n if stride is None else int(stride)
     if out is None:
-        out = torch.empty((batch * n, heads * head_dim), dtype=q.dtype, device=q.device)
-    rc = _lib.load().ape_hip_attention(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, heads,
-                                      head_dim, float(scale), _dt(q), _stream())
+        out = (torch.empty if stride == n else torch.zeros)((batch * stride, heads * head_dim), dtype=q.dtype, device=q.device)
+    rc = _lib.load().ape_hip_attention_strided(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, stride,
+                                              heads, head_dim, float(scale), _dt(q), _stream())
     _lib.check(rc, "ape_hip_attention")
     return out
 
@@ -299,12 +311,15 @@ def _i32(t, name):
     return t
 
 
-def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype):
+def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype, out=None):
     """(img - mean)/std, zero pad to the token grid, 16x16 patch rows [ht*wt, 768] in token order."""
-    _dev(img, tok2raster)
+    _dev(img, tok2raster, out)
     if img.dtype != torch.float32 or img.dim() != 3 or img.shape[0] != 3 or not img.is_contiguous():
         raise ValueError("ape_amd.ops.patchify: img must be contiguous float32 [3,h,w]")
-    out = torch.empty((ht * wt, 768), dtype=out_dtype, device=img.device)
+    if out is None:
+        out = torch.empty((ht * wt, 768), dtype=out_dtype, device=img.device)
+    elif tuple(out.shape) != (ht * wt, 768) or not out.is_contiguous():
+        raise ValueError("ape_amd.ops.patchify: out must be a contiguous [ht*wt, 768] tensor")
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
     rc = _lib.load().ape_hip_patchify(_p(img), img.shape[1], img.shape[2], _p(_i32(tok2raster, "tok2raster")), ht, wt, m, s,

@@ -25,8 +25,9 @@ import torch
 class GraphedForward:
     SLOTS = 2
 
-    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1):
+    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True):
         self.mv = model_vision
+        self.batch_vit = batch_vit
         self.use_graph = use_graph
         self.max_graphs = max_graphs
         self.with_masks = with_masks
@@ -35,11 +36,11 @@ class GraphedForward:
         self._copy_stream = None
 
     # ------------------------------------------------------------------ device work of one image
-    def _device_part(self, image, text, height, width, prompt="name"):
+    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None):
         """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame)"""
         mv = self.mv
         h, w = image.shape[-2:]
-        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt)
+        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat)
         boxes = out["det_boxes"].clone()
         boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
         boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
@@ -68,12 +69,20 @@ class GraphedForward:
                 mv.test_topk_per_image = saved
         if len(images) == 1:
             return [self._device_part(images[0], text, height, width, prompt)]
-        # whole images are the parallel branches; the finer-grained forks inside a forward run inline (nested fork/join
-        # made hipStreamEndCapture crash on this ROCm, and the image-level overlap already fills the idle phases)
+        # The ViT runs ONCE over the B images (every linear sees B x 4096 rows: the 256 x 256-tile GEMM kernels need that
+        # many to fill the chip; rows are independent, so nothing changes numerically).  Everything after it stays one
+        # batch-1 forward per image, the B of them parallel branches of the graph; the finer-grained forks inside a forward
+        # run inline (nested fork/join made hipStreamEndCapture crash on this ROCm, and the image-level overlap already
+        # fills the idle phases).
         with ops.inline_forks():
-            jobs = [ops.fork(lambda b=b: self._device_part(images[b], text, height, width, prompt), force=True)
+            feats = [None] * len(images)
+            if self.batch_vit:
+                n_tok = (mv.backbone.net.img_size // mv.backbone.net.patch_size) ** 2
+                x = mv.backbone.net.forward_tokens(images, mv._mean, mv._std)
+                feats = [x[b * n_tok:(b + 1) * n_tok] for b in range(len(images))]
+            jobs = [ops.fork(lambda b=b: self._device_part(images[b], text, height, width, prompt, feats[b]), force=True)
                     for b in range(1, len(images))]
-            outs = [self._device_part(images[0], text, height, width, prompt)]
+            outs = [self._device_part(images[0], text, height, width, prompt, feats[0])]
             return outs + [j.join() for j in jobs]
 
     def _build(self, images, text, height, width, prompt):

@@ -177,6 +177,11 @@ int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spat
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                       int B, int N, int H, int HD, float scale, int dt, void* stream);
+/* same, with `bstride` >= N rows between consecutive batch items (windows): batch item b owns rows b*bstride .. b*bstride+N-1
+ * of Q / K / O and columns b*bstride .. of Vt.  For the zero-padded 14 x 14 windows of ape/modeling/backbone/vit_eva02.py:437-458
+ * (196 tokens per window, stored at a stride of 200 so that every window starts 16-byte aligned in Vt). */
+int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                              int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

@@ -174,6 +174,50 @@ class ApeOracle:
         hidden = self.ln(hidden, pre + "mlp.ffn_ln", 1e-6)
         return x + self.lin(hidden, pre + "mlp.w3")
 
+    # --------------------------------------------------------------------------------------------
+    # config 1 (APE-Ti): the EVA-02 MIM ViT of vit_eva02.py -- packed qkv without sub-LN (Attention :206-291, subln=False),
+    # packed SwiGLU without ffn_ln (xops_SwiGLU :85-98, :107-149), zero-padded windows (Block :437-458 with
+    # utils_eva02.py:19-63: the padding is applied AFTER norm1, padded tokens are keys with k = 0 and v = v_bias)
+    # --------------------------------------------------------------------------------------------
+    def vit_attention_eva02(self, x, i, rope):
+        pre = f"backbone.net.blocks.{i}.attn."
+        B, H, W, C = x.shape
+        N = H * W
+        x = x.reshape(B, N, C)
+        nh = self.num_heads_vit
+        q_bias, v_bias = self.p(pre + "q_bias"), self.p(pre + "v_bias")
+        qkv = F.linear(x, self.p(pre + "qkv.weight"), torch.cat((q_bias, torch.zeros_like(v_bias), v_bias)))
+        qkv = qkv.reshape(B, N, 3, nh, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        cos, sin = rope
+        q = q * cos + rotate_half(q) * sin
+        k = k * cos + rotate_half(k) * sin
+        att = ((q * q.shape[-1] ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)
+        o = (att @ v).permute(0, 2, 1, 3).reshape(B, N, -1)
+        return self.lin(o, pre + "proj").view(B, H, W, C)
+
+    def vit_block_eva02(self, x, i):
+        pre = f"backbone.net.blocks.{i}."
+        shortcut = x
+        x = self.ln(x, pre + "norm1", 1e-6)
+        if i in self.win_blocks:
+            ws = self.ws
+            B, H, W, C = x.shape
+            ph, pw = (ws - H % ws) % ws, (ws - W % ws) % ws
+            xp = F.pad(x, (0, 0, 0, pw, 0, ph))                                   # utils_eva02.py:31-35
+            Hp, Wp = H + ph, W + pw
+            xw = window_partition(xp, ws)
+            xw = self.vit_attention_eva02(xw, i, self.rope_win)
+            x = window_unpartition(xw, ws, Hp, Wp)[:, :H, :W, :].contiguous()    # :57-62
+        else:
+            x = self.vit_attention_eva02(x, i, self.rope_glb)
+        x = shortcut + x
+        h = self.ln(x, pre + "norm2", 1e-6)
+        w12, b12 = self.p(pre + "mlp.w12.weight"), self.p(pre + "mlp.w12.bias")
+        hid = w12.shape[0] // 2
+        hidden = F.silu(F.linear(h, w12[:hid], b12[:hid])) * F.linear(h, w12[hid:], b12[hid:])
+        return x + self.lin(hidden, pre + "mlp.w3")
+
     def abs_pos(self, hw):
         """get_abs_pos (utils_eva02.py:158-187): drop cls, bicubic resize to the token grid"""
         pos = self.p("backbone.net.pos_embed")[:, 1:]
@@ -194,7 +238,7 @@ class ApeOracle:
         import time
         for i in range(self.depth):
             t0 = time.perf_counter()
-            x = self.vit_block(x, i)
+            x = self.vit_block_eva02(x, i) if self.cfg.get("backbone") == "eva02" else self.vit_block(x, i)
             self._tick("vit_win_block" if i in self.win_blocks else "vit_glb_block", t0)
             self.stages[f"vit_block{i}"] = x
         return x.permute(0, 3, 1, 2)

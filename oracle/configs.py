@@ -19,6 +19,10 @@ CONFIGS = {
                 enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300),
     "L_D_coco": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=100, spec="L_D"),
+    # config 1: APE-Ti (configs/common/backbone/vitt_eva02.py:10-41 + ape_deta_vitt_eva02_vlf_lsj1024_cp_16x4_1080k.py): the
+    # EVA-02 MIM ViT-Ti of vit_eva02.py, 14 x 14 windows on the 64 x 64 grid (zero-padded to 70 x 70), packed SwiGLU
+    "Ti": dict(img_size=1024, embed_dim=192, depth=12, num_heads=3, window_size=14, pretrain_img_size=224,
+               enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02"),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500, spec="L_D"),
 }

@@ -35,14 +35,22 @@ def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panop
     from ape.modeling.backbone.vit_eva_clip import SimpleFeaturePyramid, ViT
 
     c = SimpleNamespace(**cfg)
-    net = ViT(
-        img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
-        drop_path_rate=0.0, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
-        norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=window_block_indexes(c.depth),
-        residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
-        rope=True, pt_hw_seq_len=16, intp_freq=True, naiveswiglu=True, subln=True, pretrain_img_size=c.pretrain_img_size,
-        pretrain_use_cls_token=True,
-    )
+    if cfg.get("backbone") == "eva02":          # APE-Ti: configs/common/backbone/vitt_eva02.py:10-41
+        from ape.modeling.backbone.vit_eva02 import SimpleFeaturePyramid, ViT
+        net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
+                  drop_path_rate=0.0, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
+                  norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=window_block_indexes(c.depth),
+                  residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
+                  subln=False, swiglu=True, naiveswiglu=False)
+    else:
+        net = ViT(
+            img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
+            drop_path_rate=0.0, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
+            norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=window_block_indexes(c.depth),
+            residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
+            rope=True, pt_hw_seq_len=16, intp_freq=True, naiveswiglu=True, subln=True, pretrain_img_size=c.pretrain_img_size,
+            pretrain_use_cls_token=True,
+        )
     backbone = SimpleFeaturePyramid(net=net, in_feature="last_feat", out_channels=256, scale_factors=(4.0, 2.0, 1.0, 0.5),
                                     top_block=refshim.LastLevelMaxPool(), norm="LN", square_pad=c.img_size)
     feats = ["p2", "p3", "p4", "p5", "p6"]

@@ -522,7 +522,7 @@ def install():
 
     load("ape.modeling.backbone.utils_eva02", "ape/modeling/backbone/utils_eva02.py")
     load("ape.modeling.backbone.vit_eva_clip", "ape/modeling/backbone/vit_eva_clip.py")
-    load("ape.modeling.backbone.vit_eva02", "ape/modeling/backbone/vit_eva02.py") if os.environ.get("APE_SHIM_TI") else None
+    load("ape.modeling.backbone.vit_eva02", "ape/modeling/backbone/vit_eva02.py")
 
     A = sys.modules["ape.modeling.ape_deta"]
     _mod("ape.modeling.ape_deta.segmentation", MaskHeadSmallConv=object, MHAttentionMap=object)

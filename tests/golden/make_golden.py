@@ -30,6 +30,8 @@ CASES = {
     # evaluation-dataset mode (set_eval_dataset): names from the metadata, detector on the 6 thing columns, semantic AND
     # panoptic branches on (panoptic thresholds loosened so that seeded weights produce segments)
     "tiny_panoptic": ("tiny", 3, 9, (208, 240), 10, 21, "name", "semantic", "panoptic"),
+    # config 1: APE-Ti, a 512 x 512 image top-left in the mandatory 1024 square pad, 10 classes (text seed 1)
+    "Ti_512": ("Ti", 0, 2, (512, 512), 10, 1),
     # ---- the BASELINE.json configurations at full size: minutes of CPU each, generated once
     # config 2: APE-L_D, 1024x1024 uint8-uniform image seed 2, 80 classes seed 3, name prompt, top-100 (COCO config)
     "L_D_coco80": ("L_D_coco", 0, 2, (1024, 1024), 80, 3),
@@ -88,7 +90,7 @@ def main():
             with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
                 json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
-        big = cfg.startswith("L_D")
+        big = cfg.startswith("L_D") or cfg == "Ti"
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)

@@ -182,24 +182,34 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     return o.to(odt)
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None):
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None):
     E = heads * head_dim
-    qf = q[:, :E].float().reshape(batch, n, heads, head_dim).permute(0, 2, 1, 3)
-    kf = k[:, :E].float().reshape(batch, n, heads, head_dim).permute(0, 2, 1, 3)
-    vf = vt[:, : batch * n].float().reshape(heads, head_dim, batch, n).permute(2, 0, 3, 1)
+    stride = n if stride is None else stride
+    rows = batch * stride
+
+    def win(t):                                     # [rows, E] -> [batch, heads, n, head_dim] (window b = rows b*stride .. +n)
+        tf = t[:, :E].float()
+        if tf.shape[0] < rows:
+            tf = torch.cat([tf, tf.new_zeros((rows - tf.shape[0], E))], 0)
+        return tf[:rows].reshape(batch, stride, heads, head_dim)[:, :n].permute(0, 2, 1, 3)
+
+    qf, kf = win(q), win(k)
+    vf = vt[:, :rows].float().reshape(heads, head_dim, batch, stride)[..., :n].permute(2, 0, 3, 1)
     att = (qf @ kf.transpose(-1, -2)) * scale
-    o = att.softmax(-1) @ vf
-    o = o.permute(0, 2, 1, 3).reshape(batch * n, E)
+    o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                       # [batch, n, heads, head_dim]
+    full = o.new_zeros((batch, stride, heads, head_dim))
+    full[:, :n] = o
+    full = full.reshape(rows, E)
     if out is not None:
-        out.copy_(o.to(out.dtype))
+        out[:rows].copy_(full.to(out.dtype))
         return out
-    return o.to(q.dtype)
+    return full.to(q.dtype)
 
 
 # ------------------------------------------------------------------------------------------------
 # spatial gathers
 # ------------------------------------------------------------------------------------------------
-def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype):
+def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype, out=None):
     h, w = img.shape[1:]
     m = torch.tensor(mean, dtype=torch.float32, device=img.device).view(3, 1, 1)
     s = torch.tensor(std, dtype=torch.float32, device=img.device).view(3, 1, 1)
@@ -207,6 +217,9 @@ def patchify(img, tok2raster, ht, wt, mean, std, *, out_dtype):
     p = x.view(3, ht, 16, wt, 16).permute(1, 3, 0, 2, 4).reshape(ht * wt, 768)
     if tok2raster is not None:
         p = p[tok2raster.long()]
+    if out is not None:
+        out.copy_(p.to(out.dtype))
+        return out
     return p.to(out_dtype).contiguous()
 
 

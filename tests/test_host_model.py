@@ -197,3 +197,19 @@ def test_product_path_has_no_cpu_fallback():
 
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+def test_batched_vit_pass_equals_single_image_passes(fake_ops):
+    """ViT.forward_tokens on a list of images (one pass over [B*N, E], sizes may differ) == the per-image passes, and the
+    model gives the same heads when it is handed its rows of the batched pass (runtime.GraphedForward, images_per_step > 1)"""
+    model, orc, image, text, gold = M.build_pair("tiny_padded")
+    mv = model.model_vision
+    image2 = torch.randint(0, 256, (3, 256, 176), generator=torch.Generator().manual_seed(77)).float()
+    net = mv.backbone.net
+    x = net.forward_tokens([image, image2], mv._mean, mv._std)
+    n = x.shape[0] // 2
+    a, b = net.forward_tokens(image, mv._mean, mv._std), net.forward_tokens(image2, mv._mean, mv._std)
+    assert torch.allclose(x[:n], a, atol=1e-5) and torch.allclose(x[n:], b, atol=1e-5)
+    ref = mv.forward_single(image2, text)
+    got = mv.forward_single(image2, text, vit_feat=x[n:])
+    assert torch.allclose(got["pred_logits"], ref["pred_logits"], atol=1e-4) and torch.equal(got["det_query"], ref["det_query"])

@@ -176,7 +176,7 @@ def test_eval_dataset_panoptic_on_gpu():
 # L_D_padded = a COCO-shaped image of config 4, L_D_1536_sseg = config 5).  No oracle run here: fixtures only.
 # ------------------------------------------------------------------------------------------------------------------
 LD_STAGES = ("p2", "p4", "p6", "enc0_fused_v", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact",
-             "mask_features", "mask_embed")
+             "mask_features")
 
 
 def _ld_heads(stages, gold):
@@ -225,10 +225,11 @@ def test_L_D_fp32_matches_reference(case):
     assert ov >= 0.99
     ref_topk = gold["full"]["topk_proposals"][0]
     stages = {}
-    cols = ("first", len(meta["thing_classes"])) if sem else None       # (:578-590) the detector sees the thing columns
-    out = mv.forward_single(image, text, forced_topk=ref_topk.to(DEV), stages=stages, semantic=sem, detector_columns=cols)
+    # free-text prompt (dataset_id = -1): the detector sees every class column (:578-592)
+    out = mv.forward_single(image, text, forced_topk=ref_topk.to(DEV), stages=stages, semantic=sem)
     el, eb = _ld_heads(stages, gold)
-    print(f"[L_D fp32 {case}] pred_logits {el:.2e} pred_boxes {eb:.2e} (vs reference fixture, tolerance 1e-3)")
+    em = U.check_fingerprint(stages["mask_embed"].float().reshape(gold["stages"]["mask_embed"]["shape"]), gold["stages"]["mask_embed"], 1e-3, "mask_embed")
+    print(f"[L_D fp32 {case}] pred_logits {el:.2e} pred_boxes {eb:.2e} mask_embed {em:.2e} (vs reference fixture, tolerance 1e-3)")
     assert el < 1e-3 and eb < 1e-3
     frac = U.match_detections(out["det_boxes"].cpu(), out["det_scores"].cpu(), out["det_classes"].cpu(),
                               gold["full"]["det_boxes"], gold["full"]["det_scores"], gold["full"]["det_classes"])
@@ -247,9 +248,10 @@ def test_L_D_fp32_matches_reference(case):
         assert mm < 1e-3
     areas = inst.pred_masks.flatten(1).sum(1).float()
     if len(areas) == len(gold["instances"]["mask_area"]) and torch.equal(inst.query_index, gold["full"]["det_query"]):
-        rel = ((areas - gold["instances"]["mask_area"].float()).abs() / gold["instances"]["mask_area"].float().clamp_min(64)).max().item()
-        print(f"[L_D fp32 {case}] max relative mask-area difference: {rel:.2e}")
-        assert rel < 2e-2
+        want_a = gold["instances"]["mask_area"].float()
+        rel = ((areas - want_a).abs().sum() / want_a.sum().clamp_min(1.0)).item()
+        print(f"[L_D fp32 {case}] mask-area difference summed over {len(areas)} instances / total area: {rel:.2e}")
+        assert rel < 1e-3
     if sem:
         st = gold.get("sem_stride", 1)
         lab = out["sem_seg"].argmax(0).to(torch.uint8).cpu()[::st, ::st]
@@ -259,8 +261,10 @@ def test_L_D_fp32_matches_reference(case):
 
 
 # measured on MI355X (profiles/r02_parity_L_D.log); asserted at 2x the measured value
-LD_BF16_T2 = {"p2": 1.0, "memory": 1.0, "enc_class": 1.0, "pred_logits": 1.0, "pred_boxes": 1.0}
-LD_BF16_T3 = {"p2": 1.0, "memory": 1.0, "pred_logits": 1.0, "pred_boxes": 1.0}
+# T2 measured: p2 1.0e-2, memory 1.7e-2, enc_class 8.2e-3, pred_logits 5.8e-2 / 6.6e-2, pred_boxes 8.4e-2
+# T3 measured: p2 4.7e-3, memory 6.6e-3, pred_logits 2.7e-2 / 1.9e-2, pred_boxes 4.1e-2; 83 % of the reference's detections matched
+LD_BF16_T2 = {"p2": 2e-2, "memory": 3.5e-2, "enc_class": 1.7e-2, "pred_logits": 1.3e-1, "pred_boxes": 1.7e-1}
+LD_BF16_T3 = {"p2": 1e-2, "memory": 1.4e-2, "pred_logits": 5.5e-2, "pred_boxes": 8.5e-2}
 
 
 @pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203"])
@@ -310,4 +314,4 @@ def test_L_D_bf16_pipeline(case):
         assert v < LD_BF16_T2[k], (k, v)
     for k, v in t3.items():
         assert v < LD_BF16_T3[k], (k, v)
-    assert frac >= 0.5
+    assert frac >= 0.7 and mm < 2.5e-2
