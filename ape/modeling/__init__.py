@@ -1,0 +1,2 @@
+"""ape/modeling/__init__.py (hot-path part)"""
+from . import ape_deta, backbone  # noqa: F401

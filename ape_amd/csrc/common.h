@@ -13,6 +13,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define APE_DT_F32 0
 #define APE_DT_BF16 1
+#define APE_DT_F16 2
+typedef _Float16 f16_t;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even via gfx950's v_cvt_pk_bf16_f32 (same rule as torch's float->bfloat16 cast; NaN stays NaN)
@@ -30,6 +32,9 @@ template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { retu
 template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t* p) { return (float)*p; }
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
 
 // 4 consecutive elements (p must be aligned to 4 elements)
 template <typename T> __device__ __forceinline__ void ld4(const T* p, float v[4]);
@@ -60,6 +65,12 @@ template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float v
   v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
   v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+template <> __device__ __forceinline__ void ld8<f16_t>(const f16_t* p, float v[8]) {
+  const f16x8_t t = *reinterpret_cast<const f16x8_t*>(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+}
 template <typename T> __device__ __forceinline__ void st8(T* p, const float v[8]);
 template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8]) {
   st4<float>(p, v); st4<float>(p + 4, v + 4);
@@ -67,6 +78,13 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float v[8
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v[8]) {
   *reinterpret_cast<uint4*>(p) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]),
                                             pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+
+template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float v[8]) {
+  f16x8_t t;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t[i] = (f16_t)v[i];
+  *reinterpret_cast<f16x8_t*>(p) = t;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

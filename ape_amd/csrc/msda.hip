@@ -158,19 +158,54 @@ template <int P> __device__ __forceinline__ int quad_bcast_i(int v) { return __b
 __device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)); }
 __device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)); }
 
-template <typename TV, int P, int L>
-__device__ __forceinline__ void quad_gather(const TV* __restrict__ vb, int ldv, const float (&cw)[L][4], const int (&ci)[L][4], int l,
-                                            float acc[8]) {
+// (weight, row index) of corner c of the sample owned by quad lane P, broadcast across the quad
+__device__ __forceinline__ float quad_pick_f(int P, float v) {
+  return P == 0 ? quad_bcast_f<0>(v) : (P == 1 ? quad_bcast_f<1>(v) : (P == 2 ? quad_bcast_f<2>(v) : quad_bcast_f<3>(v)));
+}
+__device__ __forceinline__ int quad_pick_i(int P, int v) {
+  return P == 0 ? quad_bcast_i<0>(v) : (P == 1 ? quad_bcast_i<1>(v) : (P == 2 ? quad_bcast_i<2>(v) : quad_bcast_i<3>(v)));
+}
+
+// The four corner rows of one sample: 4 independent 16-byte loads.  No branch on the weight: a corner outside the level
+// carries weight 0 and row index 0 (a valid row) -- a per-corner `if (w != 0)` serialised every load behind a branch.
+template <typename TV>
+struct CornerGroup {
+  uint4 raw[4];      // bf16: 8 channels per corner
+  float w[4];
+};
+
+template <typename TV, int L>
+__device__ __forceinline__ void group_load(const TV* __restrict__ vb, int ldv, const float (&cw)[L][4], const int (&ci)[L][4], int s,
+                                           CornerGroup<TV>& g) {
+  const int l = s >> 2, P = s & 3;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float w = quad_bcast_f<P>(cw[l][c]);
-    const int idx = quad_bcast_i<P>(ci[l][c]);
-    if (w != 0.f) corner_acc<TV>(vb, ldv, idx, w, acc);
+    g.w[c] = quad_pick_f(P, cw[l][c]);
+    int idx = quad_pick_i(P, ci[l][c]);
+    asm volatile("" : "+v"(idx));            // the load may not be hoisted above this point (IR passes ignore sched_barrier)
+    g.raw[c] = *reinterpret_cast<const uint4*>(vb + (size_t)idx * ldv);
   }
 }
 
+// acc += sum_c w[c] * row[c]: the kernel is VALU bound (each lane: 80 corners x 8 channels), so one v_pk_fma_f32 per bf16 pair
+template <typename TV>
+__device__ __forceinline__ void group_fma(const CornerGroup<TV>& g, f32x2_t (&a2)[4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x2_t ww = {g.w[c], g.w[c]};
+    const uint32_t d[4] = {g.raw[c].x, g.raw[c].y, g.raw[c].z, g.raw[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const f32x2_t v2 = {__uint_as_float(d[e] << 16), __uint_as_float(d[e] & 0xffff0000u)};
+      a2[e] = __builtin_elementwise_fma(ww, v2, a2[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(a2[e]));   // ... and the FMAs may not sink below it
+}
+
 template <typename TV, typename TO, int L>
-__global__ __launch_bounds__(256) void msda_fused_quad_kernel(const MsdaParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void msda_fused_quad_kernel(const MsdaParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   int chunk;
@@ -236,16 +271,42 @@ __global__ __launch_bounds__(256) void msda_fused_quad_kernel(const MsdaParams p
     cw[l][2] = (b_ok && l_ok) ? aw * lh * hw : 0.f; ci[l][2] = (b_ok && l_ok) ? base + h_high * W + w_low : 0;
     cw[l][3] = (b_ok && r_ok) ? aw * lh * lw : 0.f; ci[l][3] = (b_ok && r_ok) ? base + h_high * W + w_high : 0;
   }
-  // ---- phase 2: gather; (index, weight) of each corner broadcast from the lane that owns the sample's point
+  // ---- phase 2: gather; (index, weight) of each corner broadcast from the lane that owns the sample's point.
+  // Software pipeline over the L*4 samples: the 4 loads of sample s+1 are issued before the FMAs of sample s; the
+  // sched_barriers pin that order (left alone the compiler hoists all 80 loads and spills).
   float acc[8];
+  if (sizeof(TV) == 2) {
+    f32x2_t a2[4];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int e = 0; e < 4; ++e) a2[e] = (f32x2_t){0.f, 0.f};
+    CornerGroup<TV> g0, g1;
+    group_load<TV, L>(vb, p.ldv, cw, ci, 0, g0);
 #pragma unroll
-  for (int l = 0; l < L; ++l) {
-    quad_gather<TV, 0, L>(vb, p.ldv, cw, ci, l, acc);
-    quad_gather<TV, 1, L>(vb, p.ldv, cw, ci, l, acc);
-    quad_gather<TV, 2, L>(vb, p.ldv, cw, ci, l, acc);
-    quad_gather<TV, 3, L>(vb, p.ldv, cw, ci, l, acc);
+    for (int s = 0; s < L * 4; s += 2) {
+      group_load<TV, L>(vb, p.ldv, cw, ci, s + 1, g1);
+      __builtin_amdgcn_sched_barrier(0);
+      group_fma<TV>(g0, a2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < L * 4) group_load<TV, L>(vb, p.ldv, cw, ci, s + 2, g0);
+      __builtin_amdgcn_sched_barrier(0);
+      group_fma<TV>(g1, a2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[2 * e] = a2[e][0]; acc[2 * e + 1] = a2[e][1]; }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int s = 0; s < L * 4; ++s) {
+      const int l = s >> 2, P = s & 3;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float w = quad_pick_f(P, cw[l][c]);
+        const int idx = quad_pick_i(P, ci[l][c]);
+        if (w != 0.f) corner_acc<TV>(vb, p.ldv, idx, w, acc);    // fp32 validation path: one corner at a time (no spills)
+      }
+    }
   }
   if (live) {
     TO* o = reinterpret_cast<TO*>(p.out) + qg * p.ldout + h * MS_D + sub * 8;
@@ -256,7 +317,7 @@ __global__ __launch_bounds__(256) void msda_fused_quad_kernel(const MsdaParams p
 template <typename TV, typename TO, bool FUSED>
 static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
   const dim3 grid(ceil_div(p.Q, 8), B), block(256);
-  if (FUSED) {
+  if constexpr (FUSED) {
     switch (L) {
       case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1>), grid, block, 0, s, p); return 0;
       case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2>), grid, block, 0, s, p); return 0;
@@ -265,7 +326,7 @@ static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
       case 5: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 5>), grid, block, 0, s, p); return 0;
       default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
     }
-  }
+  } else {
   switch (L) {
     case 1: hipLaunchKernelGGL((msda_kernel<TV, TO, 1, FUSED>), grid, block, 0, s, p); break;
     case 2: hipLaunchKernelGGL((msda_kernel<TV, TO, 2, FUSED>), grid, block, 0, s, p); break;
@@ -273,6 +334,7 @@ static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
     case 4: hipLaunchKernelGGL((msda_kernel<TV, TO, 4, FUSED>), grid, block, 0, s, p); break;
     case 5: hipLaunchKernelGGL((msda_kernel<TV, TO, 5, FUSED>), grid, block, 0, s, p); break;
     default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
+  }
   }
   return 0;
 }
@@ -305,7 +367,9 @@ extern "C" int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const 
   p.value = value; p.ldv = ldv; p.loc = sampling_loc; p.attn = attn_weight; p.out = out; p.ldout = ldout; p.S = S; p.Q = Q;
   if (fill_levels(p, spatial_shapes, level_start_index, L, S)) return -1;
   int rc;
+  APE_CHECK_ARG(dt == APE_DT_F32 || dt == APE_DT_BF16 || dt == APE_DT_F16, "ms_deform_attn_forward: dtype code %d (0 = f32, 1 = bf16, 2 = f16)", dt);
   if (dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, false>(p, B, L, (hipStream_t)stream);
+  else if (dt == APE_DT_F16) rc = launch_msda<f16_t, f16_t, false>(p, B, L, (hipStream_t)stream);   // the CUDA op's half dispatch (ms_deform_attn_cuda.cu:65)
   else rc = launch_msda<float, float, false>(p, B, L, (hipStream_t)stream);
   if (rc) return rc;
   APE_CHECK_LAUNCH("ape_hip_ms_deform_attn_forward");

@@ -143,3 +143,40 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
   APE_CHECK_LAUNCH("ape_hip_vl_pool");
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Per-head matrix-vector products of the single-token language side (ape/layers/fuse_helper.py:70-73,140,160-161 after the
+// reassociation of layers/fuse_helper.py): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n], all fp32.
+// One wave per (h, n); replaces torch.einsum / matmul (rocBLAS launches inside the captured forward).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int ldo, int H,
+                                                        int N, int D, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // over H * N
+  if (row >= H * N) return;
+  const int h = row / N, n = row % N;
+  const float* w = W + (size_t)row * D;
+  const float* xr = x + (size_t)h * ldx;
+  float s = 0.f;
+  if ((D & 3) == 0 && (ldx & 3) == 0) {
+    for (int d = lane * 4; d < D; d += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(w + d), b = *reinterpret_cast<const float4*>(xr + d);
+      s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+    }
+  } else {
+    for (int d = lane; d < D; d += 64) s = fmaf(w[d], xr[d], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[(size_t)h * ldo + n] = s * alpha + (bias != nullptr ? bias[row] : 0.f);
+}
+
+extern "C" int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N,
+                                 int D, float alpha, void* stream) {
+  APE_CHECK_ARG(x && W && out && H > 0 && N > 0 && D > 0, "ape_hip_head_gemv: bad args");
+  APE_CHECK_ARG(((uintptr_t)x) % 16 == 0 && ((uintptr_t)W) % 16 == 0, "ape_hip_head_gemv: x / W must be 16-byte aligned");
+  hipLaunchKernelGGL(head_gemv_kernel, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha);
+  APE_CHECK_LAUNCH("ape_hip_head_gemv");
+  return 0;
+}

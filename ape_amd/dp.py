@@ -56,10 +56,15 @@ class DataParallelRunner:
     def submit(self, image, text, height=None, width=None, prompt="name"):
         """enqueue one image (output frame height x width, prompt mode as in GraphedForward.submit); returns a ticket"""
         ticket = self.forward_fn.submit(image, text, height, width, prompt)
-        ticket.records = self._all_gather(ticket.rec6)     # stream-ordered behind the forward, no host wait
+        if getattr(ticket, "rec6", None) is not None:      # detections already enqueued (non-pipelined runtime): gather now,
+            ticket.records = self._all_gather(ticket.rec6)  # stream-ordered behind the forward, no host wait
         return ticket
 
     def result(self, ticket):
-        """(instances on the host, all ranks' records [world, k, 6]) of a submitted image"""
-        inst, _ = self.forward_fn.result(ticket)
+        """(instances on the host, all ranks' records [world, k, 6]) of a submitted image.  With the software-pipelined runtime
+        a ticket's detections are produced by the NEXT step's replay, so the record all-gather is enqueued here (every rank
+        collects its tickets in the same order, which keeps the collective matched)."""
+        inst, rec = self.forward_fn.result(ticket)
+        if getattr(ticket, "records", None) is None:
+            ticket.records = self._all_gather(rec)
         return inst, ticket.records

@@ -1,0 +1,84 @@
+"""DefaultPredictor -- mirror of ape/engine/defaults.py:157-230 (the class demo/demo_lazy.py and demo/predictor_lazy.py drive):
+BGR uint8 image in, `{"instances": Instances, ...}` out.
+
+Construction.  In a full environment (detectron2 importable) pass the LazyConfig: the model is `instantiate(cfg.model)`
+(the config's `ape.*` import paths resolve to the HIP-backed classes through the `ape` alias package), the checkpoint is
+loaded with `DetectionCheckpointer` and the test-time resize comes from `cfg.dataloader.test.mapper.augmentations[0]`
+(`ResizeShortestEdge(short_edge_length=1024, max_size=1024)` in the APE-*_D configs).  Without detectron2 pass a built
+model (`ape_amd.modeling.build.build_ape`) and the resize parameters.
+
+Input pipeline.  The reference resizes on the host with PIL (`ResizeTransform.apply_image`, bilinear with
+PIL's antialiasing filter support) and the model normalises + pads on the device.  Here the host does the same PIL
+resize (same library, so the same pixels) when PIL is importable, the upload goes through a pinned staging buffer, and
+normalise + pad are fused into the patch-embedding gather (csrc/spatial.hip `patchify`)."""
+import numpy as np
+import torch
+
+
+def shortest_edge_size(h, w, short_edge_length, max_size):
+    """detectron2 ResizeShortestEdge.get_output_shape: scale the short side to `short_edge_length`, cap the long side"""
+    scale = short_edge_length * 1.0 / min(h, w)
+    newh, neww = (short_edge_length, scale * w) if h < w else (scale * h, short_edge_length)
+    if max(newh, neww) > max_size:
+        s = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * s, neww * s
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def resize_image(img, newh, neww):
+    """HWC uint8 -> HWC uint8, PIL bilinear (what detectron2's ResizeTransform.apply_image does for uint8 images)"""
+    if img.shape[0] == newh and img.shape[1] == neww:
+        return img
+    from PIL import Image
+    return np.asarray(Image.fromarray(img).resize((neww, newh), Image.BILINEAR))
+
+
+class DefaultPredictor:
+    def __init__(self, cfg=None, model=None, short_edge_length=1024, max_size=1024, input_format="RGB"):
+        self.cfg = cfg
+        self.aug = None
+        if model is None:
+            from detectron2.checkpoint import DetectionCheckpointer      # full environment only
+            from detectron2.config import instantiate
+            model = instantiate(cfg.model)
+            model.to(cfg.train.device)
+            DetectionCheckpointer(model).load(cfg.train.init_checkpoint)
+            self.aug = instantiate(cfg.dataloader.test.mapper.augmentations[0])
+            mv = cfg.model.model_vision if "model_vision" in cfg.model else cfg.model
+            input_format = mv.input_format
+        self.model = model.eval()
+        self.short_edge_length, self.max_size = short_edge_length, max_size
+        self.input_format = input_format
+        assert self.input_format in ("RGB", "BGR"), self.input_format
+        self._pinned = None
+
+    def _upload(self, image_hwc):
+        """HWC uint8 (host) -> CHW float32 on the model's device through a pinned staging buffer"""
+        dev = next(self.model.parameters()).device
+        t = torch.from_numpy(np.ascontiguousarray(image_hwc))
+        if dev.type == "cuda":
+            if self._pinned is None or self._pinned.numel() < t.numel():
+                self._pinned = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
+            buf = self._pinned[: t.numel()].view(t.shape)
+            buf.copy_(t)
+            t = buf.to(dev, non_blocking=True)
+        return t.permute(2, 0, 1).float().contiguous()
+
+    @torch.no_grad()
+    def __call__(self, original_image, text_prompt=None, mask_prompt=None):
+        """original_image: np.ndarray [H, W, 3] uint8 in BGR order (cv2.imread) -> predictions dict of the model"""
+        if self.input_format == "RGB":
+            original_image = original_image[:, :, ::-1]
+        height, width = original_image.shape[:2]
+        if self.aug is not None:
+            image = self.aug.get_transform(original_image).apply_image(original_image)
+        else:
+            newh, neww = shortest_edge_size(height, width, self.short_edge_length, self.max_size)
+            image = resize_image(np.ascontiguousarray(original_image), newh, neww)
+        inputs = {"image": self._upload(image), "height": height, "width": width}
+        if text_prompt is not None:
+            inputs["prompt"] = "text"
+            inputs["text_prompt"] = text_prompt
+        if mask_prompt is not None:
+            raise NotImplementedError("ape_amd DefaultPredictor: mask prompts are outside the inference hot path")
+        return self.model([inputs])[0]

@@ -75,7 +75,9 @@ class BiAttentionBlock(nn.Module):
                 wl=f32(a.l_proj.weight), bl=f32(a.l_proj.bias), wvl=f32(a.values_l_proj.weight), bvl=f32(a.values_l_proj.bias),
                 wov=f32(a.out_v_proj.weight), bov=f32(a.out_v_proj.bias), wol=f32(a.out_l_proj.weight), bol=f32(a.out_l_proj.bias),
                 wv=f32(a.v_proj.weight).view(nh, hd, vd), bv=f32(a.v_proj.bias).view(nh, hd),
-                wvv=f32(a.values_v_proj.weight).view(nh, hd, vd), bvv=f32(a.values_v_proj.bias).view(nh, hd),
+                wvT=f32(a.v_proj.weight).view(nh, hd, vd).transpose(1, 2).contiguous(),            # [h, v_dim, hd]
+                bv1=f32(a.v_proj.bias).view(nh, 1, hd).contiguous(),
+                wvv=f32(a.values_v_proj.weight).view(nh, hd, vd).contiguous(), bvv=f32(a.values_v_proj.bias).view(nh, hd).contiguous(),
                 gv=f32(self.gamma_v), gl=f32(self.gamma_l))
         return self._pack.get(self, dt, build)
 
@@ -156,12 +158,13 @@ class BiAttentionBlock(nn.Module):
 
         def language_side():
             kh = k.view(a.num_heads, a.head_dim)
-            u = torch.einsum("hd,hdi->hi", kh, P["wv"])              # W_v,h^T k_h       [8, v_dim]
-            c = (P["bv"] * kh).sum(-1)                               # b_v,h . k_h       [8]
-            sbias = (a.scale * (c - u @ gdv)).contiguous()           # scores are taken on LN_v(v) = v_new - gdv
+            u = ops.head_gemv(kh, P["wvT"])                          # W_v,h^T k_h       [8, v_dim]
+            c = ops.head_gemv(kh, P["bv1"])                          # b_v,h . k_h       [8, 1]
+            ug = ops.gemv(gdv[None, :].contiguous(), u)              # u . gamma_v delta_v   [1, 8]
+            sbias = (a.scale * (c[:, 0] - ug[0])).contiguous()       # scores are taken on LN_v(v) = v_new - gdv
             S = ops.gemm(v_new, u.to(dt).contiguous(), sbias, alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
-            pooled = ops.vl_pool(S, v_new) - gdv[None, :]            # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
-            ol = torch.einsum("hi,hdi->hd", pooled, P["wvv"]) + P["bvv"]   # values_v_proj per head   [8, hd]
+            pooled = (ops.vl_pool(S, v_new) - gdv[None, :]).contiguous()   # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
+            ol = ops.head_gemv(pooled, P["wvv"], P["bvv"])           # values_v_proj per head   [8, hd]
             dl = ops.gemv(ol.reshape(1, -1).contiguous(), P["wol"], P["bol"])
             return l_n + P["gl"] * dl
 

@@ -34,8 +34,11 @@ def _register_torch_op():
 
         lib.impl("ms_deform_attn_forward", impl, "CUDA")
         return lib
-    except Exception:  # already defined (e.g. the reference extension is loaded)
-        return None
+    except RuntimeError as exc:
+        # the only tolerated failure: the operator is already defined (the reference's compiled extension was imported first)
+        if "ms_deform_attn_forward" in str(exc) and hasattr(torch.ops.ape, "ms_deform_attn_forward"):
+            return None
+        raise
 
 
 _TORCH_LIB = _register_torch_op()

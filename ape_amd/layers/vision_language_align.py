@@ -30,7 +30,7 @@ class VisionLanguageAlign(nn.Module):
         P = self._pack.get(self, torch.float32, build)
         e = torch.nn.functional.normalize(embedding.float(), p=2, dim=-1)
         tok = ops.gemm((e / 2.0).contiguous(), P["w"], P["b"], out_dtype=torch.float32)
-        bias = (torch.matmul(e, self.bias_lang.detach().float()) + self.bias0.detach().float()).contiguous()
+        bias = (ops.gemv(f32(self.bias_lang).reshape(1, -1), e.contiguous())[0] + self.bias0.detach().float()).contiguous()
         # host scalar, read once per module (not per image / per vocabulary: phrase mode rebuilds the vocabulary per image)
         inv_scale = self._pack.get(self, "inv_scale", lambda _k: 1.0 / float(self.log_scale.detach().exp()))
         return tok.to(dt).contiguous(), bias, inv_scale

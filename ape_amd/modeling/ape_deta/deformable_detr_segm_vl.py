@@ -20,6 +20,7 @@ import torch.nn as nn
 from ... import ops
 from ...layers import VisionLanguageAlign
 from ...packing import attach_cache, f32, pack_matrix
+from ...structures import make_instances
 from . import geometry as G
 from ._containers import MLP
 
@@ -592,22 +593,16 @@ class DeformableDETRSegmVL(nn.Module):
 
     def postprocess_instance(self, out, image_size, height, width):
         """detector_postprocess (:857-872): rescale to (height, width), clip, drop empty boxes, paste masks; the
-        result is moved to the CPU like the reference (`r.to("cpu")`)."""
+        result is a detectron2-style `Instances` (ape_amd/structures.py) moved to the CPU like the reference (`r.to("cpu")`)."""
         h, w = image_size
         boxes = out["det_boxes"].clone()
         sx, sy = width / w, height / h
         boxes[:, 0::2] = (boxes[:, 0::2] * sx).clamp(0, width)
         boxes[:, 1::2] = (boxes[:, 1::2] * sy).clamp(0, height)
         keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-        res = SimpleNamespace(image_size=(height, width))
         masks = None
         if "det_masks128" in out:
             masks = ops.paste_bits(out["det_masks128"], boxes.contiguous(), height, width)
         keep_c = keep.cpu()                                   # the one host sync of the forward
-        res.pred_boxes = boxes.cpu()[keep_c]
-        res.scores = out["det_scores"].cpu()[keep_c]
-        res.pred_classes = out["det_classes"].cpu()[keep_c]
-        res.query_index = out["det_query"].cpu()[keep_c]
-        if masks is not None:
-            res.pred_masks = masks.cpu()[keep_c].bool()
-        return res
+        return make_instances((height, width), boxes.cpu()[keep_c], out["det_scores"].cpu()[keep_c], out["det_classes"].cpu()[keep_c],
+                              masks.cpu()[keep_c].bool() if masks is not None else None, query_index=out["det_query"].cpu()[keep_c])

@@ -182,6 +182,23 @@ def gemv(x, w, bias=None, alpha=1.0):
     return out
 
 
+def head_gemv(x, w, bias=None, alpha=1.0):
+    """out[h, n] = alpha * x[h, :] . w[h, n, :] + bias[h, n]; x [H, D], w [H, N, D], bias [H, N] (all fp32) -> [H, N] fp32."""
+    _dev(x, w, bias)
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or not w.is_contiguous():
+        raise TypeError("ape_amd.ops.head_gemv: fp32 x and contiguous fp32 w")
+    _rowmajor(x, "x")
+    H, N, D = w.shape
+    if x.shape != (H, D):
+        raise ValueError(f"ape_amd.ops.head_gemv: x {tuple(x.shape)} vs w {tuple(w.shape)}")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != H * N):
+        raise ValueError("ape_amd.ops.head_gemv: bias must be a contiguous fp32 [H, N] tensor")
+    out = torch.empty((H, N), dtype=torch.float32, device=x.device)
+    rc = _lib.load().ape_hip_head_gemv(_p(x), _ld(x), _p(w), _p(bias), _p(out), N, H, N, D, float(alpha), _stream())
+    _lib.check(rc, "ape_hip_head_gemv")
+    return out
+
+
 def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None, add=None, out2=None):
     """Row LayerNorm; returns y, or (y, y + add) when `add` is given.  Columns C..cpad-1 of y are zeroed."""
     _dev(x, w, b, out, add, out2)
@@ -257,8 +274,9 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if sampling_loc.shape[3] != L:
         raise ValueError("ms_deform_attn_forward: num_levels mismatch")
     out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
+    dt = 2 if value.dtype == torch.float16 else _dt(value)          # APE_DT_F16: half storage, fp32 arithmetic
     rc = _lib.load().ape_hip_ms_deform_attn_forward(_p(value), M * D, shp, st, _p(sampling_loc), _p(attn_weight), _p(out),
-                                                   M * D, B, S, Q, L, _dt(value), _stream())
+                                                   M * D, B, S, Q, L, dt, _stream())
     _lib.check(rc, "ape_hip_ms_deform_attn_forward")
     return out
 
@@ -582,6 +600,7 @@ class _Joined:
 
 
 _FORK_INLINE = [False]
+_FORK_NEST = [0]
 
 
 class inline_forks:
@@ -599,6 +618,11 @@ def fork(fn, force=False):
     """run fn() on a side stream, concurrent with whatever the caller enqueues next; returns a handle with .join()"""
     if not torch.cuda.is_available() or os.environ.get("APE_NO_FORK") == "1" or (_FORK_INLINE[0] and not force):
         return _Joined(fn())
+    if _FORK_NEST[0] > 0 and os.environ.get("APE_FORK_NESTED") != "1":
+        # branches do not fork again: one level of side streams per parent.  (Graphs whose capture nested side streams two
+        # levels deep crashed hipGraphLaunch once a process had built three of them -- ROCm 7.2 -- and the second level
+        # bought nothing measurable.)
+        return _Joined(fn())
     dev = torch.cuda.current_device()
     cur = torch.cuda.current_stream()
     # one pool of side streams PER PARENT stream: a branch's outputs are consumed by its parent, and the next branch on the
@@ -611,7 +635,11 @@ def fork(fn, force=False):
     start.record(cur)
     side.wait_event(start)
     with torch.cuda.stream(side):
-        result = fn()
+        _FORK_NEST[0] += 1
+        try:
+            result = fn()
+        finally:
+            _FORK_NEST[0] -= 1
         done = torch.cuda.Event()
         done.record(side)
     return _Joined(result, done, keep=fn)

@@ -13,21 +13,41 @@ writes straight into the slot's staging buffer; a copy stream then moves the slo
 `submit()` enqueues an image and returns a ticket, `result(ticket)` waits for that slot's copy only -- so the ~2 ms
 PCIe transfer of one image overlaps the compute of the next.  `__call__` = result(submit(...)) is the synchronous form.
 
+`pipeline=True` (software pipeline over steps): the graph of a step holds the ViT of the NEW images (one batched pass, every
+linear at B x 4096 rows) as one branch and the rest of the forward ("tails": FPN, encoder, proposal selection, decoder,
+heads, NMS, masks) of the PREVIOUS step's images as B more branches, reading the ViT features the previous replay left in
+a persistent buffer.  The GEMM-bound ViT of one batch then overlaps the latency-bound tails of another instead of all
+images sitting in the same phase at the same time; a ticket's results exist after the NEXT submit (or a flush).
+
 `images_per_step = B > 1`: the forwards of B images are captured as PARALLEL BRANCHES of one graph (ops.fork), so the
 latency-bound phases of one image (proposal selection, decoder, NMS: mostly idle CUs) run next to the GEMM-heavy phases
 of another.  Every image still goes through the batch-1 pipeline; nothing is batched numerically.
 """
+import weakref
 from types import SimpleNamespace
 
 import torch
+
+from .structures import make_instances
+
+
+class _Ticket:
+    """handle of a submitted step (weak-referenceable, unlike SimpleNamespace)"""
+    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "__weakref__")
+
+    def __init__(self, entry, single):
+        self.entry, self.single = entry, single
+        self.slot, self.ready, self.rec6, self.records = None, False, None, None
 
 
 class GraphedForward:
     SLOTS = 2
 
-    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True):
+    def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
+                 pipeline=False):
         self.mv = model_vision
         self.batch_vit = batch_vit
+        self.pipeline = bool(pipeline)
         self.use_graph = use_graph
         self.max_graphs = max_graphs
         self.with_masks = with_masks
@@ -85,6 +105,36 @@ class GraphedForward:
             outs = [self._device_part(images[0], text, height, width, prompt, feats[0])]
             return outs + [j.join() for j in jobs]
 
+    def _device_pipelined(self, entry, text, height, width, prompt):
+        """one pipelined step: ViT of entry.images (new) || tails of the features in entry.feat (previous step's images)"""
+        from . import ops
+        mv = self.mv
+        net = mv.backbone.net
+        B = len(entry.images)
+        n_tok = entry.feat.shape[0] // B
+        if prompt == "expression" and mv.test_topk_per_image != 1:
+            saved = mv.test_topk_per_image
+            mv.test_topk_per_image = 1
+            try:
+                return self._device_pipelined(entry, text, height, width, prompt)
+            finally:
+                mv.test_topk_per_image = saved
+        with ops.inline_forks():
+            vjob = ops.fork(lambda: net.forward_tokens(entry.images if B > 1 else entry.images[0], mv._mean, mv._std), force=True)
+            feats = [entry.feat[b * n_tok:(b + 1) * n_tok] for b in range(B)]
+            jobs = [ops.fork(lambda b=b: self._device_part(entry.images[b], text, height, width, prompt, feats[b]), force=True)
+                    for b in range(1, B)]
+            outs = [self._device_part(entry.images[0], text, height, width, prompt, feats[0])] + [j.join() for j in jobs]
+            entry.feat.copy_(vjob.join())             # behind every tail: the next replay reads the new features
+        return outs
+
+    def _run_entry(self, e):
+        """the device work of one step of entry `e` on its static image buffers"""
+        height, width = e.size
+        if self.pipeline:
+            return self._device_pipelined(e, e.text, height, width, e.prompt)
+        return self._device_all(e.images, e.text, height, width, e.prompt)
+
     def _build(self, images, text, height, width, prompt):
         mv = self.mv
         dev = images[0].device
@@ -95,13 +145,22 @@ class GraphedForward:
         # warm-up and capture run fusion_tokens, which (phrase / expression prompts, persistent bank) shifts the phrase bank
         # in place: snapshot it and restore it afterwards so that building a graph does not count as three extra images
         bank = mv.features_phrase_bank.clone() if getattr(mv, "text_feature_bank", False) else None
+        if self.pipeline:
+            net = mv.backbone.net
+            n_tok = (net.img_size // net.patch_size) ** 2
+            entry.feat = torch.zeros((B * n_tok, net.embed_dim), dtype=mv.compute_dtype, device=dev)
+            entry.pending = None          # ticket whose ViT features sit in entry.feat, tails not run yet
+        entry.size, entry.prompt = (height, width), prompt
+        # (no closure over `entry` is stored on it: a reference cycle would leave the captured graph to the garbage collector,
+        # which may then destroy it -- and free its memory pool -- in the middle of a later capture)
+        run = lambda: self._run_entry(entry)  # noqa: E731
         for _ in range(2):            # warm every cache (weight packing, geometry, text side) outside the capture
-            self._device_all(entry.images, text, height, width, prompt)
+            run()
         torch.cuda.synchronize()
         if self.use_graph:
             entry.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(entry.graph):
-                entry.outs = self._device_all(entry.images, text, height, width, prompt)
+                entry.outs = run()
         else:
             entry.graph = None
         if bank is not None:
@@ -119,7 +178,6 @@ class GraphedForward:
             s.busy = False
             entry.slots.append(s)
         entry.next_slot = 0
-        entry.size = (height, width)
         return entry
 
     # ------------------------------------------------------------------ pipelined interface
@@ -141,22 +199,44 @@ class GraphedForward:
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.max_graphs:
-                self._graphs.pop(next(iter(self._graphs)))
+                oldest = next(iter(self._graphs))
+                self.flush(self._graphs[oldest])       # a ticket waiting for its tails keeps its entry alive through ticket.entry
+                self._graphs.pop(oldest)
             e = self._graphs[key] = self._build(images, text, height, width, prompt)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=images[0].device)
-        s = e.slots[e.next_slot]
-        if s.busy:
-            raise RuntimeError("GraphedForward.submit: every result slot is outstanding -- call result() on an earlier ticket first")
-        e.next_slot = (e.next_slot + 1) % self.SLOTS
+        single = not isinstance(image, (list, tuple))
+        if not self.pipeline:
+            t = _Ticket(e, single)
+            self._replay(e, images, text, height, width, prompt, completes=t)
+            return t
+        # pipelined: this replay runs the tails of the PREVIOUS ticket and the ViT of these images
+        t = _Ticket(e, single)
+        self._replay(e, images, text, height, width, prompt, completes=e.pending() if e.pending is not None else None)
+        e.pending = weakref.ref(t)        # weak: ticket -> entry -> ticket would be a cycle (see _build); a dropped ticket's
+        return t                          # detections are simply not delivered
+
+    def _replay(self, e, images, text, height, width, prompt, completes):
+        """enqueue one step (graph replay or eager run) and, for the ticket whose detections it produces, the mask paste into a
+        result slot and the slot's transfer to pinned memory on the copy stream"""
+        from . import ops
+        s = None
+        if completes is not None:
+            s = e.slots[e.next_slot]
+            if s.busy:
+                raise RuntimeError("GraphedForward.submit: every result slot is outstanding -- call result() on an earlier ticket first")
+            e.next_slot = (e.next_slot + 1) % self.SLOTS
         cur = torch.cuda.current_stream()
-        if e.graph is not None:
+        if images is not None:
             for buf, im in zip(e.images, images):
                 buf.copy_(im, non_blocking=True)
+        if e.graph is not None:
             e.graph.replay()
             outs = e.outs
         else:
-            outs = self._device_all(images, text, height, width, prompt)
+            outs = self._run_entry(e)
+        if completes is None:
+            return
         cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
         has_masks = s.d_masks is not None and outs[0][1] is not None
         for b, (rec, masks128, boxes) in enumerate(outs):
@@ -172,14 +252,26 @@ class GraphedForward:
             s.copied.record(self._copy_stream)
         s.busy = True
         s.has_masks = has_masks
-        rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
-        return SimpleNamespace(entry=e, slot=s, rec6=rec6, single=not isinstance(image, (list, tuple)))
+        completes.slot, completes.ready = s, True
+        completes.rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
+
+    def flush(self, entry=None):
+        """pipelined mode: run the tails of the ticket whose ViT features are waiting (one more replay; its ViT branch recomputes
+        the features of the images already in the static buffers, which nobody consumes)"""
+        for e in ([entry] if entry is not None else list(self._graphs.values())):
+            if self.pipeline and e.pending is not None:
+                height, width = e.size
+                t, e.pending = e.pending(), None
+                self._replay(e, None, e.text, height, width, e.prompt, completes=t)
 
     def result(self, ticket):
         """wait for the ticket's transfer; returns (instances on the host, device record view [k,6]) -- lists / [B,k,6] when the
         step was submitted as a list.  pred_masks is a zero-copy view of the slot's pinned buffer: valid until SLOTS further
-        submits."""
-        e, s = ticket.entry, ticket.slot
+        completed steps.  Pipelined mode: a ticket completes with the NEXT submit; asking earlier flushes the pipeline."""
+        e = ticket.entry
+        if not ticket.ready:
+            self.flush(e)
+        s = ticket.slot
         s.copied.synchronize()
         s.busy = False
         height, width = e.size
@@ -187,10 +279,9 @@ class GraphedForward:
         for b in range(self.B):
             hr = s.h_rec[b]
             n = int((hr[:, 7] > 0.5).sum())                 # kept detections are a prefix (sorted on the device)
-            inst = SimpleNamespace(image_size=(height, width), pred_boxes=hr[:n, :4].clone(), scores=hr[:n, 4].clone(),
-                                   pred_classes=hr[:n, 5].long(), query_index=hr[:n, 6].long())
-            if s.has_masks:
-                inst.pred_masks = s.h_masks[b, :n].view(torch.bool)      # zero-copy view of the pinned buffer
+            inst = make_instances((height, width), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(),
+                                  s.h_masks[b, :n].view(torch.bool) if s.has_masks else None,    # zero-copy view of the pinned buffer
+                                  query_index=hr[:n, 6].long())
             insts.append(inst)
         if ticket.single:
             return insts[0], ticket.rec6

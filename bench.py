@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--stream-images", type=int, default=8, help="distinct synthetic images cycled per rank")
     ap.add_argument("--images-per-step", type=int, default=3,
                     help="images per rank per step, captured as parallel branches of one hipGraph (each one a batch-1 forward)")
+    ap.add_argument("--no-batch-vit", action="store_true", help="one ViT pass per image instead of one per step")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="no software pipeline over steps (ViT of step i+1 || tails of step i inside one graph)")
     return ap.parse_args()
 
 
@@ -166,7 +169,8 @@ def main():
     from ape_amd.dp import DataParallelRunner
 
     B = args.images_per_step
-    graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B)
+    graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
+                             pipeline=not args.no_pipeline)
     dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev)
     # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
@@ -178,18 +182,20 @@ def main():
     # replay + mask paste + record all-gather), then the host collects image i-1, whose device->host transfer ran on the
     # copy stream meanwhile.  K timed steps = K submits + K collected results (the last one is flushed inside the timed
     # region), so `value` counts K complete images per rank, masks on the host included.
-    pending = [None]
+    # the host collects a ticket `depth` steps after submitting it: 1 = while the next image computes (its transfer ran on the
+    # copy stream meanwhile); 2 with the software pipeline, where a ticket's detections are produced by the next step's replay
+    depth = 1 if args.no_pipeline else 2
+    queue = []
 
     def step(i):
         batch = [images[(i * B + b) % len(images)] for b in range(B)]
-        ticket = dp.submit(batch if B > 1 else batch[0], text)
-        done = dp.result(pending[0]) if pending[0] is not None else None
-        pending[0] = ticket
-        return done
+        queue.append(dp.submit(batch if B > 1 else batch[0], text))
+        return dp.result(queue.pop(0)) if len(queue) > depth else None
 
     def flush():
-        done = dp.result(pending[0]) if pending[0] is not None else None
-        pending[0] = None
+        done = None
+        while queue:
+            done = dp.result(queue.pop(0))
         return done
 
     for i in range(args.warmup):

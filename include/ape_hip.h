@@ -22,6 +22,9 @@ extern "C" {
 
 #define APE_DT_F32 0
 #define APE_DT_BF16 1
+#define APE_DT_F16 2 /* IEEE half storage, fp32 arithmetic: accepted by ape_hip_ms_deform_attn_forward (the reference evaluates in
+                      * fp16, tools/train_net.py:642, and its CUDA op dispatches half, ms_deform_attn_cuda.cu:65); the model-level
+                      * kernels store bf16 -- an fp16 module casts at its edge (ape_amd/layers/multi_scale_deform_attn.py) */
 
 #define APE_ACT_NONE 0
 #define APE_ACT_RELU 1
@@ -226,6 +229,11 @@ int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int32_t* order, 
 int ape_hip_vl_pool_workspace_floats(int T, int C);
 int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace, float* out,
                     void* stream);
+/* per-head matrix-vector products of the same language side (fuse_helper.py:70-73 v_proj / values_v_proj applied to one
+ * pooled vector per head): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n]; x [H, ldx], W [H, N, D], bias [H, N] or
+ * NULL, out [H, ldo], fp32.  -- csrc/vlpool.hip */
+int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N, int D,
+                      float alpha, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Softmaxes of the DENSE bi-directional attention (L > 1 text tokens: phrase / expression prompts;

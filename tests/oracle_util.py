@@ -53,6 +53,7 @@ def check_fingerprint(t, fp, tol, name):
 
 def match_detections(boxes_a, scores_a, classes_a, boxes_b, scores_b, classes_b, box_tol=1e-2, score_tol=1e-3):
     """fraction of detections in b that have a counterpart in a (same class, close score, close box)"""
+    boxes_a, boxes_b = getattr(boxes_a, "tensor", boxes_a), getattr(boxes_b, "tensor", boxes_b)      # Boxes or plain tensors
     matched = 0
     used = set()
     for j in range(len(scores_b)):

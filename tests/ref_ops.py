@@ -76,6 +76,11 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     return x.to(odt)
 
 
+def head_gemv(x, w, bias=None, alpha=1.0):
+    out = torch.einsum("hd,hnd->hn", x.float(), w.float()) * alpha
+    return out + bias.float().reshape(out.shape) if bias is not None else out
+
+
 def row_stats(x, eps):
     xf = x.float()
     mean = xf.mean(dim=1)

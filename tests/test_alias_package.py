@@ -1,0 +1,56 @@
+"""The `ape` alias package: every class path the APE-L_D / APE-Ti LazyConfigs import resolves to the HIP-backed classes.
+
+Runs in a subprocess: the oracle's refshim registers its own `ape.*` modules (the reference's files) in sys.modules, which
+must not mix with the alias package inside one interpreter."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (import path, names) -- configs/LVISCOCOCOCOSTUFF_.../ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py:10-16,
+# configs/COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py:9-19, configs/common/backbone/vitl_eva02_clip.py:7,
+# configs/common/backbone/vitt_eva02.py:7, ape/layers/__init__.py:1-8, demo/predictor_lazy.py (DefaultPredictor)
+TARGETS = [
+    ("ape.layers", ["VisionLanguageFusion", "VisionLanguageAlign", "MultiScaleDeformableAttention",
+                    "multi_scale_deformable_attn_pytorch", "BiAttentionBlock", "BiMultiHeadAttention"]),
+    ("ape.layers.multi_scale_deform_attn", ["MultiScaleDeformableAttention"]),
+    ("ape.modeling.ape_deta", ["DeformableDETRSegmVL", "DeformableDetrTransformerDecoderVL", "DeformableDetrTransformerEncoderVL",
+                               "DeformableDetrTransformerVL", "SomeThing"]),
+    ("ape.modeling.backbone.vit_eva_clip", ["SimpleFeaturePyramid", "ViT"]),
+    ("ape.modeling.backbone.vit_eva02", ["SimpleFeaturePyramid", "ViT"]),
+    ("ape.engine.defaults", ["DefaultPredictor"]),
+]
+
+SCRIPT = r"""
+import importlib, sys
+sys.path.insert(0, %r)
+targets = %r
+import ape_amd
+for mod, names in targets:
+    m = importlib.import_module(mod)
+    for n in names:
+        obj = getattr(m, n)
+        assert obj.__module__.startswith("ape_amd."), (mod, n, obj.__module__)
+# the model tree of the L_D config, built from the alias paths with the config's kwargs (what instantiate() does)
+from ape_amd.modeling import build
+import ape.modeling.ape_deta as A, ape.modeling.backbone.vit_eva_clip as B
+assert build.DeformableDETRSegmVL is A.DeformableDETRSegmVL and build.ViT is B.ViT
+model = build.build_ape("tiny")
+assert type(model).__module__ == "ape_amd.modeling.ape_deta.ape_deta"
+print("alias ok")
+"""
+
+
+def test_alias_paths_resolve_to_the_hip_classes():
+    out = subprocess.run([sys.executable, "-c", SCRIPT % (ROOT, TARGETS)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "alias ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_default_predictor_resize_rule():
+    from ape_amd.engine import shortest_edge_size
+    # ResizeShortestEdge(1024, max_size=1024): the long side lands on 1024
+    assert shortest_edge_size(480, 640, 1024, 1024) == (768, 1024)
+    assert shortest_edge_size(640, 480, 1024, 1024) == (1024, 768)
+    assert shortest_edge_size(1000, 1000, 1024, 1024) == (1024, 1024)
+    assert shortest_edge_size(427, 640, 1024, 1024) == (683, 1024)

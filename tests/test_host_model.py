@@ -213,3 +213,53 @@ def test_batched_vit_pass_equals_single_image_passes(fake_ops):
     ref = mv.forward_single(image2, text)
     got = mv.forward_single(image2, text, vit_feat=x[n:])
     assert torch.allclose(got["pred_logits"], ref["pred_logits"], atol=1e-4) and torch.equal(got["det_query"], ref["det_query"])
+
+
+def test_ape_ti_backbone_matches_reference_golden(fake_ops):
+    """BASELINE config 1 plumbing: ape_amd.modeling.backbone.vit_eva02 (APE-Ti) with the torch definitions of the ops, fp32,
+    against the reference run (512 x 512 image in the 1024 square pad): last ViT feature and the five pyramid levels <= 1e-5
+    (SURVEY 8d), and the state-dict contract of the whole APE-Ti model"""
+    gold = U.load_golden("Ti_512")
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    spec = U.load_spec(cfg_name)
+    from ape_amd.modeling.build import build_ape
+    from oracle import weights
+    model = build_ape(cfg_name)
+    own = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    want = dict(spec)
+    assert set(own) == set(want) and all(own[k] == want[k] for k in want), sorted(set(own) ^ set(want))[:6]
+    model.load_state_dict(weights.make_state_dict(spec, wseed), strict=False)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.float32)
+    feat = mv.backbone.net.forward_tokens(image, mv._mean, mv._std)                    # [4096, 192] raster order
+    fp = gold["stages"]["last_feat"]
+    e = U.check_fingerprint(feat.t().reshape(fp["shape"]), fp, 1e-5, "last_feat")
+    maps = mv.backbone.forward_tokens(image, mv._mean, mv._std, vit_feat=feat)
+    for k, (t, (H, W)) in maps.items():
+        fp = gold["stages"][k]
+        e = max(e, U.check_fingerprint(M.ref_layout(k, t, fp["shape"]), fp, 1e-5, k))
+    print(f"APE-Ti backbone vs reference run: max relerr {e:.2e}")
+
+
+def test_fp16_model_runs_through_the_module_edge(fake_ops):
+    """the reference evaluates with model.to(torch.float16) (tools/train_net.py:642): parameters and inputs arrive as fp16,
+    the HIP path stores bf16 / computes fp32 behind an explicit cast at the module edge, results come back like the
+    reference's (Instances on the CPU).  Here: model.half() must run and reproduce the fp32 model's detections up to the
+    fp16 rounding of the weights."""
+    model, orc, image, text, gold = M.build_pair("tiny_padded")
+    h, w = image.shape[-2:]
+    ref = model([{"image": image, "height": h, "width": w, "text_features": text}])[0]["instances"]
+    model.half()
+    assert model.model_vision.backbone.net.blocks[0].attn.q_proj.weight.dtype == torch.float16
+    model.model_vision.set_compute_dtype(torch.float32)
+    got = model([{"image": image.half(), "height": h, "width": w, "text_features": text.half()}])[0]["instances"]
+    frac = U.match_detections(got.pred_boxes, got.scores, got.pred_classes, ref.pred_boxes, ref.scores, ref.pred_classes,
+                              box_tol=3e-2, score_tol=3e-2)
+    assert frac >= 0.9, frac
+    # the layer-level reference signature keeps the caller's dtype (multi_scale_deform_attn.py:350-351)
+    msda = model.model_vision.transformer.encoder.layers[0].attentions[0]
+    shapes = torch.tensor([[8, 8], [4, 4], [2, 2], [1, 1], [1, 1]])
+    q = torch.randn(1, 86, 256).half()
+    out = msda(q, value=q, identity=q, query_pos=torch.zeros_like(q), reference_points=torch.rand(1, 86, 5, 2),
+               spatial_shapes=shapes, level_start_index=torch.tensor([0, 64, 80, 84, 85]))
+    assert out.dtype == torch.float16 and out.shape == q.shape and torch.isfinite(out).all()

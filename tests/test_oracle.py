@@ -125,3 +125,20 @@ def test_oracle_matches_live_reference():
     # RoPE tables are persistent buffers of the reference model: the oracle recomputes them
     m_sd = dict(spec)
     assert "model_vision.backbone.net.rope_win.freqs_cos" in m_sd
+
+
+def test_oracle_vit_eva02_backbone_matches_reference_golden():
+    """BASELINE config 1 (APE-Ti): the oracle's restatement of vit_eva02.py (packed qkv, packed SwiGLU, zero-padded 14 x 14
+    windows) + SimpleFPN against the reference run of tests/golden/ref_Ti_512.pt -- backbone stages only (the transformer
+    behind it is the one the other cases pin, and a full 87 296-token CPU forward would take a minute)"""
+    gold = U.load_golden("Ti_512")
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+    orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
+    x, _, _ = orc.preprocess(image)
+    feat = orc.vit(x)
+    for i in range(CONFIGS[cfg_name]["depth"]):
+        U.check_fingerprint(orc.stages[f"vit_block{i}"], gold["stages"][f"vit_block{i}"], FP32_TOL, f"vit_block{i}")
+    U.check_fingerprint(feat, gold["stages"]["last_feat"], FP32_TOL, "last_feat")
+    for k, v in orc.fpn(feat).items():
+        U.check_fingerprint(v, gold["stages"][k], FP32_TOL, k)
