@@ -23,12 +23,21 @@ images sitting in the same phase at the same time; a ticket's results exist afte
 latency-bound phases of one image (proposal selection, decoder, NMS: mostly idle CUs) run next to the GEMM-heavy phases
 of another.  Every image still goes through the batch-1 pipeline; nothing is batched numerically.
 """
+import os
 import weakref
 from types import SimpleNamespace
 
 import torch
 
 from .structures import make_instances
+
+
+# Captured graphs are never destroyed while the process lives: on this stack (ROCm 7.2, torch 2.10) destroying a hipGraph
+# whose capture used side streams, then capturing and launching further graphs, crashed hipGraphLaunch (reproduced:
+# tests/test_model_gpu.py in suite order; keeping the graph objects alive removes it).  Evicted / orphaned graphs are parked
+# here instead -- their private memory pools stay allocated, which is why GraphedForward serves every image size of a stream
+# from few graphs instead of churning through them.
+_RETIRED = []
 
 
 class _Ticket:
@@ -54,6 +63,17 @@ class GraphedForward:
         self.B = int(images_per_step)
         self._graphs = {}
         self._copy_stream = None
+
+    def _retire(self, entry):
+        if getattr(entry, "graph", None) is not None:
+            _RETIRED.append(entry.graph)
+
+    def __del__(self):
+        try:
+            for e in self._graphs.values():
+                self._retire(e)
+        except Exception:       # interpreter shutdown
+            pass
 
     # ------------------------------------------------------------------ device work of one image
     def _device_part(self, image, text, height, width, prompt="name", vit_feat=None):
@@ -201,7 +221,7 @@ class GraphedForward:
             if len(self._graphs) >= self.max_graphs:
                 oldest = next(iter(self._graphs))
                 self.flush(self._graphs[oldest])       # a ticket waiting for its tails keeps its entry alive through ticket.entry
-                self._graphs.pop(oldest)
+                self._retire(self._graphs.pop(oldest))
             e = self._graphs[key] = self._build(images, text, height, width, prompt)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=images[0].device)
