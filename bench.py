@@ -4,9 +4,11 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
 `python -m torch.distributed.run --nproc-per-node N ...` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
-A "step" = `--images-per-step` (default 3) images per rank, EACH a complete batch-1 forward, captured as parallel branches
-of one hipGraph (the latency-bound phases of one image overlap the GEMM-heavy phases of another; measured on one box:
-48 -> 61 / 76 / 69 / 79 images/s for 1 / 2 / 3 / 4 / 8 images per step).  One image goes through the whole hot path: normalise + pad + patchify -> EVA-02 ViT-L ->
+A "step" = `--images-per-step` (default 2) images per rank.  The ViT runs once over the images of a step (every linear at
+B x 4096 rows; rows are independent, so each image's result is bit-identical to its own pass), everything behind it is one
+batch-1 forward per image, the B of them parallel branches of one hipGraph; steps are software-pipelined (the graph of step i
+holds the ViT of step i's images and the tails of step i-1's), and the last step is flushed inside the timed region, so K
+timed steps deliver K x B complete images.  One image goes through the whole hot path: normalise + pad + patchify -> EVA-02 ViT-L ->
 SimpleFPN -> neck -> 6x (VL fusion + deformable encoder layer) -> two-stage proposal selection -> 6x decoder ->
 heads -> class-wise NMS -> masks of the kept detections (upsample, ROIAlign 128, paste) -> detections on the host.
 Inputs (images, text-embedding bank) are resident in HBM before the timed region.  Weights are seeded synthetic
@@ -17,8 +19,9 @@ ape/data/build.py:127); the text bank is broadcast once from rank 0 (RCCL) and e
 records are all-gathered (RCCL over xGMI).  scaling = weak (one image per rank per step).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the bf16 MFMA GEMM, measured with HIP events on
-the launch stream in an instrumented pass right after the timed region) and `cpu_baseline` (the oracle -- a CPU port
-of the reference algorithm -- timed on the host cores of the same box, rank 0, N = 1 only).
+the launch stream in an instrumented pass right after the timed region), `cpu_baseline` (the oracle -- a CPU port
+of the reference algorithm -- one full-depth image timed on the host cores of the same box, rank 0, N = 1 only) and
+`parity` (the bf16 pipeline's heads / detections on image 0 against that oracle forward).
 """
 import argparse
 import json
@@ -39,12 +42,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", default="L_D")
+    ap.add_argument("--size", default="L_D_coco", help="L_D_coco = APE-L_D with the COCO config's top-100 (BASELINE config 2); L_D = top-300")
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--stream-images", type=int, default=8, help="distinct synthetic images cycled per rank")
-    ap.add_argument("--images-per-step", type=int, default=3,
+    ap.add_argument("--images-per-step", type=int, default=2,
                     help="images per rank per step, captured as parallel branches of one hipGraph (each one a batch-1 forward)")
     ap.add_argument("--no-batch-vit", action="store_true", help="one ViT pass per image instead of one per step")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -95,10 +98,13 @@ class GemmMeter:
 
 def pmc_traffic_bytes(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh ->
-    profiles/r01_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
+    profiles/r0N_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md's HBM section prescribes for gfx950).  None when the summary does not list the kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.txt")
-    if not os.path.exists(path):
+    for name in ("r02_pmc_summary.txt", "r01_pmc_summary.txt"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path) and any(l.split("|")[0].strip() == kernel for l in open(path)):
+            break
+    else:
         return None
     for line in open(path):
         cols = [c.strip() for c in line.split("|")]
@@ -110,37 +116,63 @@ def pmc_traffic_bytes(kernel):
     return None
 
 
-def cpu_baseline(model, size, image, text, max_threads=32):
-    """The oracle (CPU port of the reference algorithm, oracle/ape_oracle.py) on the host cores, on a BOUNDED sample of
-    the same workload: the full-resolution image runs through a depth-reduced copy of the model (3 of the ViT blocks
-    = 2 windowed + 1 global, 1 of the encoder layers, 1 of the decoder layers, everything else in full) and the
-    per-layer times are scaled back to the real depth.  A full 24+6+6-layer CPU forward takes minutes."""
+def cpu_baseline(model, size, image, text, max_threads=64):
+    """The oracle (CPU port of the reference algorithm, oracle/ape_oracle.py) on the host cores of this box: one warm-up pass
+    through a depth-reduced copy (thread pool / primitive caches), then ONE full-depth fp32 forward of the same image, timed.
+    Returns (cpu_baseline object, the oracle's stage tensors of that forward) -- the latter feeds the `parity` object."""
     from oracle import ape_oracle
     from oracle.configs import CONFIGS
 
     cfg = dict(CONFIGS[size])
     depth, enc, dec = cfg["depth"], cfg["enc_layers"], cfg["dec_layers"]
-    cfg.update(depth=3, enc_layers=1, dec_layers=1)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    # the reduced oracle reads decoder level 0 heads and the encoder-side heads stored at index `dec`
-    for k in list(sd):
-        for sub in ("class_embed.", "bbox_embed."):
-            if f"{sub}{dec}." in k:
-                sd[k.replace(f"{sub}{dec}.", f"{sub}1.")] = sd[k]
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
+    img, txt = image.cpu(), text.cpu()
+    warm = dict(cfg, depth=3, enc_layers=1, dec_layers=1)
+    sdw = dict(sd)
+    for k in list(sd):       # the reduced oracle reads decoder level 0 heads and the encoder-side heads stored at index `dec`
+        for sub in ("class_embed.", "bbox_embed."):
+            if f"{sub}{dec}." in k:
+                sdw[k.replace(f"{sub}{dec}.", f"{sub}1.")] = sd[k]
+    ape_oracle.ApeOracle(warm, sdw).forward(img, txt)
     orc = ape_oracle.ApeOracle(cfg, sd)
     t0 = time.perf_counter()
-    orc.forward(image.cpu(), text.cpu())
+    orc.forward(img, txt)
     total = time.perf_counter() - t0
     T = orc.timers
-    n_win = len([i for i in range(depth) if i % 3 != 2])
-    layered = T["vit_win_block"] + T["vit_glb_block"] + T["enc_layer"] + T["dec_layer"]
-    est = (total - layered) + T["vit_win_block"] / 2 * n_win + T["vit_glb_block"] * (depth - n_win) + T["enc_layer"] * enc + T["dec_layer"] * dec
-    return {"value": 1.0 / est, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": (f"1 image {tuple(image.shape)}, oracle fp32 with 3/{depth} ViT blocks, 1/{enc} encoder and 1/{dec} decoder "
-                       f"layers measured ({total:.1f} s) and scaled per layer to full depth -> {est:.1f} s/image; torch "
-                       f"{torch.__version__} CPU, {cores} threads")}
+    return ({"value": 1.0 / total, "unit": "images/sec", "cores": cores, "kind": "port",
+             "sample": (f"1 image {tuple(image.shape)}, full depth ({depth} ViT blocks, {enc}+{dec} layers), oracle fp32, after a "
+                        f"depth-reduced warm-up pass: {total:.1f} s (ViT {T.get('vit_win_block', 0) + T.get('vit_glb_block', 0):.1f} s, "
+                        f"encoder {T.get('enc_layer', 0):.1f} s, decoder {T.get('dec_layer', 0):.1f} s); torch {torch.__version__} CPU, "
+                        f"{cores} threads")}, orc.stages)
+
+
+def parity_object(mv, image, text, O):
+    """the bf16 HIP pipeline on image 0 against the oracle's fp32 forward of the same image (same weights): head tensors with
+    the oracle's proposal order injected (max-abs error / max-abs reference), and detection-level agreement of the free run"""
+    def rel(a, b):
+        a, b = a.float().cpu(), b.float().cpu()
+        return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+    st = {}
+    mv.forward_single(image, text, forced_topk=O["topk_proposals"][0].to(image.device), stages=st)
+    out = mv.forward_single(image, text)
+    ob, os_, oc = O["det_boxes"], O["det_scores"], O["det_classes"]
+    gb, gs, gc = out["det_boxes"].cpu(), out["det_scores"].cpu(), out["det_classes"].cpu()
+    used, matched = set(), 0
+    for j in range(len(os_)):
+        cand = ((gc == oc[j]) & ((gs - os_[j]).abs() < 0.05)).nonzero().flatten().tolist()
+        for i in cand:
+            if i not in used and float((gb[i] - ob[j]).abs().max()) < 0.05 * max(1.0, float(ob[j].abs().max())):
+                used.add(i)
+                matched += 1
+                break
+    return {"against": "oracle fp32 (CPU) on image 0, same seeded weights",
+            "pred_logits_relerr": rel(st["pred_logits"], O["pred_logits"][0]), "pred_boxes_relerr": rel(st["pred_boxes"], O["pred_boxes"][0]),
+            "proposal_overlap": len(set(out["topk_proposals"].cpu().tolist()) & set(O["topk_proposals"][0].tolist())) / float(O["topk_proposals"].shape[-1]),
+            "detections_matched": matched / max(len(os_), 1), "match_rule": "same class, |score| < 0.05, box within 5 %",
+            "note": "bf16 storage / fp32 accumulate vs fp32: T3 of DESIGN.md section 5 (the fp32 kernels meet 1e-3: tests/test_model_gpu.py)"}
 
 
 def main():
@@ -219,14 +251,20 @@ def main():
 
     result = None
     if rank == 0:
-        # instrumented pass (eager, NOT part of the timed region): HIP events around every GEMM launch, grouped by the
-        # kernel symbol the library reports; the roofline object is about the symbol with the largest total time
+        # instrumented pass (eager, NOT part of the timed region): the SAME step composition as the timed steps -- one batched
+        # ViT pass over B images, then B tails -- with every branch inline, so each GEMM runs alone between its HIP events;
+        # grouped by the kernel symbol the library reports.  The roofline object is about the symbol with the largest total.
         reps = 3
-        with GemmMeter(ops) as meter:
+        n_tok = (mv.backbone.net.img_size // mv.backbone.net.patch_size) ** 2
+        with ops.inline_forks(), GemmMeter(ops) as meter:
             for i in range(reps):
-                out = mv.forward_single(images[i % len(images)], text)
-                mv.postprocess_instance(out, (S, S), S, S)
+                batch = [images[(i * B + b) % len(images)] for b in range(B)]
+                x = mv.backbone.net.forward_tokens(batch if B > 1 else batch[0], mv._mean, mv._std)
+                for b in range(B):
+                    out = mv.forward_single(batch[b], text, vit_feat=x[b * n_tok:(b + 1) * n_tok])
+                    mv.postprocess_instance(out, (S, S), S, S)
             groups = meter.summary()
+        reps = reps * B                                     # images in the instrumented pass
         dom_name, (dom_n, dom_t, dom_fl) = groups[0]
         all_t, all_fl = sum(g[1][1] for g in groups), sum(g[1][2] for g in groups)
         achieved = dom_fl / dom_t / 1e12
@@ -234,13 +272,16 @@ def main():
             "metric": "images/sec @1024^2 APE-L_D fwd", "value": world * args.steps * B / elapsed, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"APE-{args.size} forward, {B}x{S}x{S} images per rank per step (each a batch-1 forward; the {B} "
-                                   f"forwards are parallel branches of one hipGraph), {args.classes} classes (name prompt), masks on, "
-                                   "top-100 detections; seeded synthetic weights",
-                       "parallelism": f"dp{world}", "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B},
+            "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
+                                   f"{B} images, everything after it one batch-1 forward per image ({B} parallel branches of one "
+                                   f"hipGraph); {args.classes} classes (name prompt), masks on, top-{mv.test_topk_per_image} detections "
+                                   "per image incl. their full-resolution masks on the host; seeded synthetic weights",
+                       "parallelism": f"dp{world}", "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B,
+                       "batched_vit": not args.no_batch_vit,
+                       "software_pipeline": (not args.no_pipeline) and "ViT of step i+1 overlaps the tails of step i; the last step is flushed inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n // reps,
+                         "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n / reps,
                          "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
                          "flops_per_launch": dom_fl / max(dom_n, 1),
                          "all_gemm_kernels": {"ms_per_image": 1e3 * all_t / reps, "tflops": all_fl / all_t / 1e12,
@@ -249,7 +290,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(model, args.size, images[0], text)
+                result["cpu_baseline"], O = cpu_baseline(model, args.size, images[0], text)
+                result["parity"] = parity_object(mv, images[0], text, O)
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {type(exc).__name__}: {exc}"}

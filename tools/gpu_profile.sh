@@ -1,12 +1,14 @@
 #!/bin/bash
-# rocprofv3 kernel-trace + stats of (a) one eager single-image pass loop and (b) the default bench; summaries -> gpurun_out/
+# rocprofv3 kernel-trace + stats of (a) the bench's step composition run eagerly with every branch inline (APE_NO_FORK=1:
+# kernels run one at a time, so the per-kernel averages are isolated durations) and (b) the default bench (graph replay,
+# software pipeline); summaries -> gpurun_out/
 # usage: tools/gpu_profile.sh <tag> [bench args...]
 set -x
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_e /tmp/prof_g
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o eager -- python $R/bench.py --no-graph --images-per-step 1 --no-pipeline --steps 8 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_eager_under_rocprof.json 2> /tmp/prof_e.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o eager -- env APE_NO_FORK=1 python $R/bench.py --no-graph --images-per-step 2 --no-pipeline --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_eager_under_rocprof.json 2> /tmp/prof_e.err
 find /tmp/prof_e -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_eager_kernel_stats.csv \;
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_g -o graph -- python $R/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_graph_under_rocprof.json 2> /tmp/prof_g.err
 find /tmp/prof_g -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_graph_kernel_stats.csv \;
