@@ -207,6 +207,10 @@ class DeformableDETRSegmVL(nn.Module):
 
     def geometry(self, image_size, level_shapes):
         key = (tuple(image_size), tuple(level_shapes), str(self.device))
+        if key in self._geo:
+            self._geo[key] = self._geo.pop(key)           # most recently used last
+        elif len(self._geo) >= 16:                        # ~140 MB of constants per size at 1024^2: keep the 16 latest
+            self._geo.pop(next(iter(self._geo)))
         if key not in self._geo:
             pe = self.position_embedding
             cfg = dict(num_pos_feats=pe.num_pos_feats, temperature=pe.temperature, normalize=pe.normalize, offset=pe.offset,
@@ -312,11 +316,14 @@ class DeformableDETRSegmVL(nn.Module):
 
     # ------------------------------------------------------------------ the hot path, one image
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
-                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None):
+                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None, geo=None):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
         instance: run the detection branch; semantic: metadata dict (entity, thing_classes, stuff_classes) to run the
         semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes;
-        vit_feat: this image's rows of a batched ViT pass (backbone.net.forward_tokens on a list of images)."""
+        vit_feat: this image's rows of a batched ViT pass (backbone.net.forward_tokens on a list of images);
+        geo: a geometry.StaticGeometry loaded with the constants of the REAL image size while `image` is the full square canvas
+        (pixels outside the image = the per-channel mean, i.e. exact zeros after normalisation) -- the size-agnostic form a
+        captured graph needs (runtime.GraphedForward(any_size=True)); instance branch only."""
         dt = self.compute_dtype
         P = self.packed(dt)
         h, w = image.shape[-2:]
@@ -325,7 +332,10 @@ class DeformableDETRSegmVL(nn.Module):
         self.backbone_time = time.perf_counter() - t0
         names = self.neck.in_features
         level_shapes = [maps[f][1] for f in names]
-        geo = self.geometry((h, w), level_shapes)
+        if geo is None:
+            geo = self.geometry((h, w), level_shapes)
+        elif semantic is not None or panoptic:
+            raise NotImplementedError("ape_amd: the size-agnostic (static geometry) forward covers the instance branch")
         t0 = time.perf_counter()
         src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
         def neck_level(i, f):
@@ -475,7 +485,7 @@ class DeformableDETRSegmVL(nn.Module):
             scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=boxes.device)
         xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1) * scale
         finite = torch.isfinite(xyxy).all(1) & torch.isfinite(scores).all(1)
-        xyxy = torch.stack([xyxy[:, 0].clamp(0, w), xyxy[:, 1].clamp(0, h), xyxy[:, 2].clamp(0, w), xyxy[:, 3].clamp(0, h)], -1)
+        xyxy = torch.minimum(xyxy.clamp_min(0.0), scale)          # Boxes.clip to (w, h): the limits are the device tensor `scale`
         xyxy = torch.where(finite[:, None], xyxy, torch.zeros_like(xyxy)).contiguous()
         st = scores.t().contiguous()                                               # [K,Q]
         sorted_scores, order = torch.sort(st, dim=1, descending=True, stable=True)

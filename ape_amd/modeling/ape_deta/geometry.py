@@ -21,6 +21,28 @@ class LevelGeometry:
         self._lvl_pos = {}
 
 
+class StaticGeometry(LevelGeometry):
+    """A LevelGeometry whose tensors are FIXED buffers that `load()` overwrites with the constants of another image size:
+    a captured hipGraph bakes tensor addresses, so handing the forward this object (instead of the per-size cached one)
+    lets ONE graph serve every (h, w) inside the square pad.  Level shapes / starts depend on the pad only."""
+    FIELDS = ("mask", "mask_u8", "valid_ratios", "enc_ref", "proposals", "invalid_u8", "box_scale", "vr4")
+
+    def __init__(self, geo, lvl_pos_key, lvl_pos):
+        super().__init__()
+        self.shapes, self.starts, self.T = geo.shapes, geo.starts, geo.T
+        self.level_ids, self.arange_T, self.pos = geo.level_ids, geo.arange_T, None
+        self.image_size = None
+        for f in self.FIELDS:
+            setattr(self, f, getattr(geo, f).clone())
+        self._lvl_pos = {lvl_pos_key: lvl_pos.clone()}
+
+    def load(self, geo, lvl_pos):
+        for f in self.FIELDS:
+            getattr(self, f).copy_(getattr(geo, f), non_blocking=True)
+        next(iter(self._lvl_pos.values())).copy_(lvl_pos, non_blocking=True)
+        self.image_size = geo.image_size
+
+
 _DIM_T = {}
 
 

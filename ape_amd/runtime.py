@@ -1,6 +1,6 @@
 """hipGraph-replayed, double-buffered forward: the per-image launch sequence (~700 kernels) is captured once per
-(image size, vocabulary, prompt mode) and replayed, and the results of image i travel to the host on a copy stream
-while image i+1 is being computed.
+(image size, vocabulary, prompt mode) -- or once per (vocabulary, prompt mode) with `any_size=True` -- and replayed, and the
+results of image i travel to the host on a copy stream while image i+1 is being computed.
 
 The forward of DeformableDETRSegmVL.forward_single is a fixed sequence of launches with fixed shapes and no host
 synchronisation (data-dependent selection / NMS / top-k are fixed-shape device code), which makes it capturable with
@@ -13,15 +13,23 @@ writes straight into the slot's staging buffer; a copy stream then moves the slo
 `submit()` enqueues an image and returns a ticket, `result(ticket)` waits for that slot's copy only -- so the ~2 ms
 PCIe transfer of one image overlaps the compute of the next.  `__call__` = result(submit(...)) is the synchronous form.
 
-`pipeline=True` (software pipeline over steps): the graph of a step holds the ViT of the NEW images (one batched pass, every
-linear at B x 4096 rows) as one branch and the rest of the forward ("tails": FPN, encoder, proposal selection, decoder,
-heads, NMS, masks) of the PREVIOUS step's images as B more branches, reading the ViT features the previous replay left in
-a persistent buffer.  The GEMM-bound ViT of one batch then overlaps the latency-bound tails of another instead of all
-images sitting in the same phase at the same time; a ticket's results exist after the NEXT submit (or a flush).
+`images_per_step = B > 1`: the ViT runs ONCE over the B images (every linear at B x 4096 rows: the 256 x 256-tile GEMM
+kernels need that many rows to fill the chip; rows are independent, nothing changes numerically) and everything behind it
+is one batch-1 forward per image, the B of them PARALLEL BRANCHES of one graph (ops.fork).
 
-`images_per_step = B > 1`: the forwards of B images are captured as PARALLEL BRANCHES of one graph (ops.fork), so the
-latency-bound phases of one image (proposal selection, decoder, NMS: mostly idle CUs) run next to the GEMM-heavy phases
-of another.  Every image still goes through the batch-1 pipeline; nothing is batched numerically.
+`pipeline=True` (software pipeline over steps): the graph of a step holds the ViT of the NEW images as one branch and the
+rest of the forward ("tails": FPN, encoder, proposal selection, decoder, heads, NMS, masks) of the PREVIOUS step's images as
+B more branches, reading the ViT features the previous replay left in a persistent buffer.  The GEMM-bound ViT of one batch
+then overlaps the latency-bound tails of another instead of all images sitting in the same phase at the same time; a
+ticket's results exist after the NEXT submit (or a flush).
+
+`any_size=True` (mixed-size streams, BASELINE config 4): the graph is SIZE-AGNOSTIC.  Everything that depends on an image's
+(h, w) inside the square pad is data, not launch geometry: the image is written into a fixed S x S canvas (pixels outside
+the image = the per-channel mean, which normalise to the exact zeros the reference pads with), the per-size constants
+(padding masks, sine position embeddings + level embeddings, valid ratios, encoder reference points, anchors, box limits)
+are copied into fixed `StaticGeometry` buffers before the replay, and the rescale to the output frame reads a device
+vector.  One graph then serves every size -- including different sizes inside one step -- with the results of the
+per-size path (tests/test_model_gpu.py::test_any_size_runtime).
 """
 import os
 import weakref
@@ -35,17 +43,17 @@ from .structures import make_instances
 # Captured graphs are never destroyed while the process lives: on this stack (ROCm 7.2, torch 2.10) destroying a hipGraph
 # whose capture used side streams, then capturing and launching further graphs, crashed hipGraphLaunch (reproduced:
 # tests/test_model_gpu.py in suite order; keeping the graph objects alive removes it).  Evicted / orphaned graphs are parked
-# here instead -- their private memory pools stay allocated, which is why GraphedForward serves every image size of a stream
-# from few graphs instead of churning through them.
+# here instead -- their private memory pools stay allocated, which is why a mixed-size stream should use `any_size=True`
+# (one graph) instead of churning through per-size graphs.
 _RETIRED = []
 
 
 class _Ticket:
     """handle of a submitted step (weak-referenceable, unlike SimpleNamespace)"""
-    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "__weakref__")
+    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "__weakref__")
 
-    def __init__(self, entry, single):
-        self.entry, self.single = entry, single
+    def __init__(self, entry, single, frames):
+        self.entry, self.single, self.frames = entry, single, frames      # frames: [(height, width)] of the output masks
         self.slot, self.ready, self.rec6, self.records = None, False, None, None
 
 
@@ -53,14 +61,16 @@ class GraphedForward:
     SLOTS = 2
 
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
-                 pipeline=False):
+                 pipeline=False, any_size=False, max_out_pixels=None):
         self.mv = model_vision
         self.batch_vit = batch_vit
         self.pipeline = bool(pipeline)
+        self.any_size = bool(any_size)
         self.use_graph = use_graph
         self.max_graphs = max_graphs
         self.with_masks = with_masks
         self.B = int(images_per_step)
+        self.max_out_pixels = max_out_pixels          # any_size: largest output frame (height * width) a slot can hold
         self._graphs = {}
         self._copy_stream = None
 
@@ -76,14 +86,18 @@ class GraphedForward:
             pass
 
     # ------------------------------------------------------------------ device work of one image
-    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None):
-        """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame)"""
+    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None, geo=None, frame=None):
+        """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame).
+        frame (any_size): device vector [8] = (sx, sy, sx, sy, width, height, width, height) of the output frame."""
         mv = self.mv
         h, w = image.shape[-2:]
-        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat)
-        boxes = out["det_boxes"].clone()
-        boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
-        boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
+        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo)
+        if frame is None:
+            boxes = out["det_boxes"].clone()
+            boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
+            boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
+        else:
+            boxes = torch.minimum((out["det_boxes"] * frame[:4]).clamp_min(0.0), frame[4:])
         keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
         # dropped rows (empty slots, empty boxes after the rescale) carry score -1 in the record, so the 6-column view that
         # is all-gathered across ranks tells kept from dropped without the keep column
@@ -96,147 +110,176 @@ class GraphedForward:
         masks128 = out.get("det_masks128")
         return rec[order].contiguous(), (masks128[order].contiguous() if masks128 is not None else None), boxes[order].contiguous()
 
-    def _device_all(self, images, text, height, width, prompt):
-        """the B forwards: image 0 on the current stream, the others as forked branches"""
-        from . import ops
-        mv = self.mv
-        if prompt == "expression" and mv.test_topk_per_image != 1:      # (:183-194) forward() applies the same rule
-            saved = mv.test_topk_per_image
-            mv.test_topk_per_image = 1
-            try:
-                return self._device_all(images, text, height, width, prompt)
-            finally:
-                mv.test_topk_per_image = saved
-        if len(images) == 1:
-            return [self._device_part(images[0], text, height, width, prompt)]
-        # The ViT runs ONCE over the B images (every linear sees B x 4096 rows: the 256 x 256-tile GEMM kernels need that
-        # many to fill the chip; rows are independent, so nothing changes numerically).  Everything after it stays one
-        # batch-1 forward per image, the B of them parallel branches of the graph; the finer-grained forks inside a forward
-        # run inline (nested fork/join made hipStreamEndCapture crash on this ROCm, and the image-level overlap already
-        # fills the idle phases).
-        with ops.inline_forks():
-            feats = [None] * len(images)
-            if self.batch_vit:
-                n_tok = (mv.backbone.net.img_size // mv.backbone.net.patch_size) ** 2
-                x = mv.backbone.net.forward_tokens(images, mv._mean, mv._std)
-                feats = [x[b * n_tok:(b + 1) * n_tok] for b in range(len(images))]
-            jobs = [ops.fork(lambda b=b: self._device_part(images[b], text, height, width, prompt, feats[b]), force=True)
-                    for b in range(1, len(images))]
-            outs = [self._device_part(images[0], text, height, width, prompt, feats[0])]
-            return outs + [j.join() for j in jobs]
-
-    def _device_pipelined(self, entry, text, height, width, prompt):
-        """one pipelined step: ViT of entry.images (new) || tails of the features in entry.feat (previous step's images)"""
-        from . import ops
-        mv = self.mv
-        net = mv.backbone.net
-        B = len(entry.images)
-        n_tok = entry.feat.shape[0] // B
-        if prompt == "expression" and mv.test_topk_per_image != 1:
-            saved = mv.test_topk_per_image
-            mv.test_topk_per_image = 1
-            try:
-                return self._device_pipelined(entry, text, height, width, prompt)
-            finally:
-                mv.test_topk_per_image = saved
-        with ops.inline_forks():
-            vjob = ops.fork(lambda: net.forward_tokens(entry.images if B > 1 else entry.images[0], mv._mean, mv._std), force=True)
-            feats = [entry.feat[b * n_tok:(b + 1) * n_tok] for b in range(B)]
-            jobs = [ops.fork(lambda b=b: self._device_part(entry.images[b], text, height, width, prompt, feats[b]), force=True)
-                    for b in range(1, B)]
-            outs = [self._device_part(entry.images[0], text, height, width, prompt, feats[0])] + [j.join() for j in jobs]
-            entry.feat.copy_(vjob.join())             # behind every tail: the next replay reads the new features
-        return outs
+    def _tail(self, e, b, vit_feat):
+        height, width = e.size
+        return self._device_part(e.images[b], e.text, height, width, e.prompt, vit_feat,
+                                 e.sgeo[b] if self.any_size else None, e.frame[b] if self.any_size else None)
 
     def _run_entry(self, e):
-        """the device work of one step of entry `e` on its static image buffers"""
-        height, width = e.size
+        """the device work of one step of entry `e` on its static buffers: (ViT of the images) + B tails"""
+        from . import ops
+        mv = self.mv
+        if e.prompt == "expression" and mv.test_topk_per_image != 1:      # (:183-194) forward() applies the same rule
+            saved = mv.test_topk_per_image
+            mv.test_topk_per_image = 1
+            try:
+                return self._run_entry(e)
+            finally:
+                mv.test_topk_per_image = saved
+        B = len(e.images)
+        net = mv.backbone.net
+        n_tok = (net.img_size // net.patch_size) ** 2
         if self.pipeline:
-            return self._device_pipelined(e, e.text, height, width, e.prompt)
-        return self._device_all(e.images, e.text, height, width, e.prompt)
+            # ViT of the NEW images || tails of the features the previous replay left in e.feat.  Branches do not fork again
+            # (nested fork/join inside image branches made hipStreamEndCapture crash on this ROCm).
+            with ops.inline_forks():
+                vjob = ops.fork(lambda: net.forward_tokens(e.images if B > 1 else e.images[0], mv._mean, mv._std), force=True)
+                feats = [e.feat[b * n_tok:(b + 1) * n_tok] for b in range(B)]
+                jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
+                outs = [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
+                e.feat.copy_(vjob.join())             # behind every tail: the next replay reads the new features
+            return outs
+        if B == 1:
+            return [self._tail(e, 0, None)]
+        with ops.inline_forks():
+            feats = [None] * B
+            if self.batch_vit:
+                x = net.forward_tokens(e.images, mv._mean, mv._std)
+                feats = [x[b * n_tok:(b + 1) * n_tok] for b in range(B)]
+            jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
+            return [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
 
+    # ------------------------------------------------------------------ per-image inputs of the size-agnostic graph
+    def _level_shapes(self):
+        S = self.mv.backbone.padding_constraints.get("square_size", 0)
+        strides = [self.mv.backbone._out_feature_strides[f] for f in self.mv.neck.in_features]
+        return S, [(S // st, S // st) for st in strides]
+
+    def _load_inputs(self, e, images, frames):
+        """any_size: write image b into its canvas, the constants of its (h, w) into its StaticGeometry, and its output frame
+        into the frame vector -- all stream-ordered in front of the replay"""
+        mv = self.mv
+        S, shapes = self._level_shapes()
+        dt = mv.compute_dtype
+        vals = []
+        for b, im in enumerate(images):
+            h, w = im.shape[-2:]
+            if h > S or w > S:
+                raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
+            e.images[b].copy_(e.mean_canvas, non_blocking=True)
+            e.images[b][:, :h, :w].copy_(im, non_blocking=True)
+            g = mv.geometry((h, w), shapes)
+            e.sgeo[b].load(g, mv.transformer.lvl_pos(g, dt))
+            height, width = frames[b]
+            sx, sy = width / w, height / h
+            vals.append([sx, sy, sx, sy, width, height, width, height])
+        e.frame.copy_(torch.tensor(vals, dtype=torch.float32))              # pageable source: staged before the call returns
+
+    # ------------------------------------------------------------------ capture
     def _build(self, images, text, height, width, prompt):
+        from .modeling.ape_deta.geometry import StaticGeometry
         mv = self.mv
         dev = images[0].device
         B = len(images)
-        entry = SimpleNamespace()
-        entry.images = [im.clone() for im in images]
-        entry.text = text             # keeps the bank alive: the graph key holds its address
+        e = SimpleNamespace()
+        e.text = text                 # keeps the bank alive: the graph key holds its address
+        e.size, e.prompt = (height, width), prompt
         # warm-up and capture run fusion_tokens, which (phrase / expression prompts, persistent bank) shifts the phrase bank
         # in place: snapshot it and restore it afterwards so that building a graph does not count as three extra images
         bank = mv.features_phrase_bank.clone() if getattr(mv, "text_feature_bank", False) else None
+        if self.any_size:
+            S, shapes = self._level_shapes()
+            dt = mv.compute_dtype
+            e.mean_canvas = torch.tensor(mv._mean, dtype=torch.float32, device=dev).view(3, 1, 1).expand(3, S, S).contiguous()
+            e.images = [e.mean_canvas.clone() for _ in range(B)]
+            g0 = mv.geometry((S, S), shapes)
+            lp = mv.transformer.lvl_pos(g0, dt)
+            key = next(iter(g0._lvl_pos))
+            e.sgeo = [StaticGeometry(g0, key, lp) for _ in range(B)]
+            e.frame = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+            self._load_inputs(e, images, [(im.shape[-2], im.shape[-1]) for im in images])
+            e.size = (S, S)
+        else:
+            e.images = [im.clone() for im in images]
         if self.pipeline:
             net = mv.backbone.net
             n_tok = (net.img_size // net.patch_size) ** 2
-            entry.feat = torch.zeros((B * n_tok, net.embed_dim), dtype=mv.compute_dtype, device=dev)
-            entry.pending = None          # ticket whose ViT features sit in entry.feat, tails not run yet
-        entry.size, entry.prompt = (height, width), prompt
-        # (no closure over `entry` is stored on it: a reference cycle would leave the captured graph to the garbage collector,
-        # which may then destroy it -- and free its memory pool -- in the middle of a later capture)
-        run = lambda: self._run_entry(entry)  # noqa: E731
+            e.feat = torch.zeros((B * n_tok, net.embed_dim), dtype=mv.compute_dtype, device=dev)
+            e.pending = None          # weakref of the ticket whose ViT features sit in e.feat, tails not run yet
+        # (no closure over `e` is stored on it: a reference cycle would leave the captured graph to the garbage collector)
         for _ in range(2):            # warm every cache (weight packing, geometry, text side) outside the capture
-            run()
+            self._run_entry(e)
         torch.cuda.synchronize()
         if self.use_graph:
-            entry.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(entry.graph):
-                entry.outs = run()
+            e.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(e.graph):
+                e.outs = self._run_entry(e)
         else:
-            entry.graph = None
+            e.graph = None
         if bank is not None:
             mv.features_phrase_bank.copy_(bank)
         k = 1 if prompt == "expression" else mv.test_topk_per_image       # (:183-194) one box per referring expression
         has_masks = self.with_masks and mv.test_mask_on
-        entry.slots = []
+        e.k = k
+        e.maxpix = (self.max_out_pixels or e.size[0] * e.size[1]) if self.any_size else height * width
+        e.slots = []
         for _ in range(self.SLOTS):
             s = SimpleNamespace()
             s.d_rec = torch.empty((B, k, 8), dtype=torch.float32, device=dev)
             s.h_rec = torch.empty((B, k, 8), dtype=torch.float32, pin_memory=True)
-            s.d_masks = torch.empty((B, k, height, width), dtype=torch.uint8, device=dev) if has_masks else None
-            s.h_masks = torch.empty((B, k, height, width), dtype=torch.uint8, pin_memory=True) if has_masks else None
+            s.d_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, device=dev) if has_masks else None
+            s.h_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, pin_memory=True) if has_masks else None
             s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
             s.busy = False
-            entry.slots.append(s)
-        entry.next_slot = 0
-        return entry
+            e.slots.append(s)
+        e.next_slot = 0
+        return e
 
     # ------------------------------------------------------------------ pipelined interface
     @torch.no_grad()
     def submit(self, image, text, height=None, width=None, prompt="name"):
-        """enqueue one image [3,h,w] (fp32, device) -- or a list of `images_per_step` images of one size -- against the text
-        bank [K, D] (device); returns a ticket.  At most SLOTS tickets may be outstanding per (size, vocabulary) entry."""
-        from . import ops
+        """enqueue one image [3,h,w] (fp32, device) -- or a list of `images_per_step` images -- against the text bank [K, D]
+        (device); returns a ticket.  height / width: the output frame (ints, or per-image lists with any_size); default =
+        the image's own size.  Without any_size the images of one step must share a size.  At most SLOTS completed tickets
+        may be outstanding per entry."""
         images = list(image) if isinstance(image, (list, tuple)) else [image]
         if len(images) != self.B:
             raise ValueError(f"GraphedForward.submit: expected {self.B} image(s) per step, got {len(images)}")
-        h, w = images[0].shape[-2:]
-        if any(tuple(im.shape[-2:]) != (h, w) for im in images):
-            raise ValueError("GraphedForward.submit: the images of one step must share a size")
-        height, width = height or h, width or w
+        single = not isinstance(image, (list, tuple))
+        hs = height if isinstance(height, (list, tuple)) else [height] * self.B
+        ws = width if isinstance(width, (list, tuple)) else [width] * self.B
+        frames = [(int(hs[b] or im.shape[-2]), int(ws[b] or im.shape[-1])) for b, im in enumerate(images)]
         # the classifier's text side is a per-vocabulary constant baked into the capture: an in-place update of the bank
         # (text._version) must rebuild the graph, exactly like a new bank
-        key = (h, w, height, width, text.data_ptr(), text._version, tuple(text.shape), prompt)
+        tkey = (text.data_ptr(), text._version, tuple(text.shape), prompt)
+        if self.any_size:
+            key = ("any",) + tkey
+        else:
+            h, w = images[0].shape[-2:]
+            if any(tuple(im.shape[-2:]) != (h, w) for im in images) or any(f != frames[0] for f in frames):
+                raise ValueError("GraphedForward.submit: the images of one step must share a size (or use any_size=True)")
+            key = (h, w) + frames[0] + tkey
         e = self._graphs.get(key)
         if e is None:
             if len(self._graphs) >= self.max_graphs:
                 oldest = next(iter(self._graphs))
                 self.flush(self._graphs[oldest])       # a ticket waiting for its tails keeps its entry alive through ticket.entry
                 self._retire(self._graphs.pop(oldest))
-            e = self._graphs[key] = self._build(images, text, height, width, prompt)
+            e = self._graphs[key] = self._build(images, text, frames[0][0], frames[0][1], prompt)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=images[0].device)
-        single = not isinstance(image, (list, tuple))
+        if any(f[0] * f[1] > e.maxpix for f in frames):
+            raise ValueError(f"GraphedForward.submit: output frame larger than max_out_pixels={e.maxpix}")
+        t = _Ticket(e, single, frames)
         if not self.pipeline:
-            t = _Ticket(e, single)
-            self._replay(e, images, text, height, width, prompt, completes=t)
+            self._replay(e, images, frames, completes=t)
             return t
         # pipelined: this replay runs the tails of the PREVIOUS ticket and the ViT of these images
-        t = _Ticket(e, single)
-        self._replay(e, images, text, height, width, prompt, completes=e.pending() if e.pending is not None else None)
-        e.pending = weakref.ref(t)        # weak: ticket -> entry -> ticket would be a cycle (see _build); a dropped ticket's
-        return t                          # detections are simply not delivered
+        self._replay(e, images, frames, completes=e.pending() if e.pending is not None else None)
+        e.pending = weakref.ref(t)        # weak: ticket -> entry -> ticket would be a cycle; a dropped ticket's detections
+        return t                          # are simply not delivered
 
-    def _replay(self, e, images, text, height, width, prompt, completes):
+    def _replay(self, e, images, frames, completes):
         """enqueue one step (graph replay or eager run) and, for the ticket whose detections it produces, the mask paste into a
         result slot and the slot's transfer to pinned memory on the copy stream"""
         from . import ops
@@ -247,42 +290,70 @@ class GraphedForward:
                 raise RuntimeError("GraphedForward.submit: every result slot is outstanding -- call result() on an earlier ticket first")
             e.next_slot = (e.next_slot + 1) % self.SLOTS
         cur = torch.cuda.current_stream()
-        if images is not None:
-            for buf, im in zip(e.images, images):
-                buf.copy_(im, non_blocking=True)
+        if images is not None and not (self.pipeline and self.any_size):
+            if self.any_size:
+                self._load_inputs(e, images, frames)
+            else:
+                for buf, im in zip(e.images, images):
+                    buf.copy_(im, non_blocking=True)
+        elif images is not None:
+            # pipelined + any_size: the canvases feed the ViT of THIS replay (new images), the static geometry / frame feed its
+            # tails (previous images).  Canvases are loaded now; geometry and frame of the new images after the replay.
+            S = e.size[0]
+            for b, im in enumerate(images):
+                h, w = im.shape[-2:]
+                if h > S or w > S:
+                    raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
+                e.images[b].copy_(e.mean_canvas, non_blocking=True)
+                e.images[b][:, :h, :w].copy_(im, non_blocking=True)
         if e.graph is not None:
             e.graph.replay()
             outs = e.outs
         else:
             outs = self._run_entry(e)
-        if completes is None:
-            return
-        cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
-        has_masks = s.d_masks is not None and outs[0][1] is not None
-        for b, (rec, masks128, boxes) in enumerate(outs):
-            s.d_rec[b].copy_(rec, non_blocking=True)
-            if has_masks:
-                ops.paste_bits(masks128, boxes, height, width, out=s.d_masks[b])     # detector_postprocess (:869-871), into the slot
-        s.computed.record(cur)
-        with torch.cuda.stream(self._copy_stream):
-            self._copy_stream.wait_event(s.computed)
-            s.h_rec.copy_(s.d_rec, non_blocking=True)
-            if has_masks:
-                s.h_masks.copy_(s.d_masks, non_blocking=True)
-            s.copied.record(self._copy_stream)
-        s.busy = True
-        s.has_masks = has_masks
-        completes.slot, completes.ready = s, True
-        completes.rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
+        if completes is not None:
+            cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
+            has_masks = s.d_masks is not None and outs[0][1] is not None
+            k = e.k
+            for b, (rec, masks128, boxes) in enumerate(outs):
+                s.d_rec[b].copy_(rec, non_blocking=True)
+                if has_masks:
+                    fh, fw = completes.frames[b]
+                    ops.paste_bits(masks128, boxes, fh, fw, out=s.d_masks[b, : k * fh * fw].view(k, fh, fw))   # detector_postprocess (:869-871)
+            s.computed.record(cur)
+            with torch.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(s.computed)
+                s.h_rec.copy_(s.d_rec, non_blocking=True)
+                if has_masks:
+                    for b in range(len(outs)):
+                        fh, fw = completes.frames[b]
+                        s.h_masks[b, : k * fh * fw].copy_(s.d_masks[b, : k * fh * fw], non_blocking=True)
+                s.copied.record(self._copy_stream)
+            s.busy = True
+            s.has_masks = has_masks
+            completes.slot, completes.ready = s, True
+            completes.rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
+        if images is not None and self.pipeline and self.any_size:
+            # now the static geometry / frame may take the NEW images' constants (stream-ordered behind the replay)
+            mv = self.mv
+            S, shapes = self._level_shapes()
+            vals = []
+            for b, im in enumerate(images):
+                h, w = im.shape[-2:]
+                g = mv.geometry((h, w), shapes)
+                e.sgeo[b].load(g, mv.transformer.lvl_pos(g, mv.compute_dtype))
+                fh, fw = frames[b]
+                sx, sy = fw / w, fh / h
+                vals.append([sx, sy, sx, sy, fw, fh, fw, fh])
+            e.frame.copy_(torch.tensor(vals, dtype=torch.float32))          # pageable source: staged before the call returns
 
     def flush(self, entry=None):
         """pipelined mode: run the tails of the ticket whose ViT features are waiting (one more replay; its ViT branch recomputes
         the features of the images already in the static buffers, which nobody consumes)"""
         for e in ([entry] if entry is not None else list(self._graphs.values())):
             if self.pipeline and e.pending is not None:
-                height, width = e.size
                 t, e.pending = e.pending(), None
-                self._replay(e, None, e.text, height, width, e.prompt, completes=t)
+                self._replay(e, None, None, completes=t)
 
     def result(self, ticket):
         """wait for the ticket's transfer; returns (instances on the host, device record view [k,6]) -- lists / [B,k,6] when the
@@ -294,15 +365,15 @@ class GraphedForward:
         s = ticket.slot
         s.copied.synchronize()
         s.busy = False
-        height, width = e.size
         insts = []
+        k = e.k
         for b in range(self.B):
             hr = s.h_rec[b]
             n = int((hr[:, 7] > 0.5).sum())                 # kept detections are a prefix (sorted on the device)
-            inst = make_instances((height, width), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(),
-                                  s.h_masks[b, :n].view(torch.bool) if s.has_masks else None,    # zero-copy view of the pinned buffer
-                                  query_index=hr[:n, 6].long())
-            insts.append(inst)
+            fh, fw = ticket.frames[b]
+            masks = s.h_masks[b, : k * fh * fw].view(k, fh, fw)[:n].view(torch.bool) if s.has_masks else None   # zero-copy
+            insts.append(make_instances((fh, fw), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(), masks,
+                                        query_index=hr[:n, 6].long()))
         if ticket.single:
             return insts[0], ticket.rec6
         return insts, ticket.rec6

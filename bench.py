@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--stream-images", type=int, default=8, help="distinct synthetic images cycled per rank")
     ap.add_argument("--images-per-step", type=int, default=2,
                     help="images per rank per step, captured as parallel branches of one hipGraph (each one a batch-1 forward)")
+    ap.add_argument("--stream", choices=["square", "coco"], default="square",
+                    help="square: S x S images (BASELINE config 2); coco: the synthetic COCO-shaped stream of config 4 -- 1000 sizes, "
+                         "long side S, short side U[480, S] (seed 5), served by ONE size-agnostic graph (GraphedForward any_size)")
     ap.add_argument("--no-batch-vit", action="store_true", help="one ViT pass per image instead of one per step")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="no software pipeline over steps (ViT of step i+1 || tails of step i inside one graph)")
@@ -202,13 +205,23 @@ def main():
 
     B = args.images_per_step
     graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
-                             pipeline=not args.no_pipeline)
+                             pipeline=not args.no_pipeline, any_size=args.stream == "coco")
     dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev)
     # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
     text = dp.broadcast_text_bank(bank, args.classes, 1024)
     # rank r owns images r, r+N, ... of the synthetic stream
     images = make_images(args.stream_images, S, seed=100 + rank, device=dev)
+    if args.stream == "coco":
+        # 1000 sizes, long side S, short side U[480, S] rounded, either orientation (seed 5); image i of the
+        # stream = the top-left (h_i, w_i) crop of a base image (views: no extra memory); rank r takes i = r, r + N, ...
+        g5 = torch.Generator().manual_seed(5)
+        short = torch.randint(480, S + 1, (1000,), generator=g5).tolist()
+        tall = (torch.rand(1000, generator=g5) < 0.3).tolist()
+        sizes = [(S, sh) if t else (sh, S) for sh, t in zip(short, tall)]
+        mine = sizes[rank::world]
+        base = images
+        images = [base[i % len(base)][:, :h, :w] for i, (h, w) in enumerate(mine)]
 
     # One step = one image per rank, submitted to the double-buffered runtime: the forward of image i is enqueued (hipGraph
     # replay + mask paste + record all-gather), then the host collects image i-1, whose device->host transfer ran on the
@@ -258,11 +271,12 @@ def main():
         n_tok = (mv.backbone.net.img_size // mv.backbone.net.patch_size) ** 2
         with ops.inline_forks(), GemmMeter(ops) as meter:
             for i in range(reps):
-                batch = [images[(i * B + b) % len(images)] for b in range(B)]
+                batch = [images[(i * B + b) % len(images)].contiguous() for b in range(B)]
                 x = mv.backbone.net.forward_tokens(batch if B > 1 else batch[0], mv._mean, mv._std)
                 for b in range(B):
                     out = mv.forward_single(batch[b], text, vit_feat=x[b * n_tok:(b + 1) * n_tok])
-                    mv.postprocess_instance(out, (S, S), S, S)
+                    hh, ww = batch[b].shape[-2:]
+                    mv.postprocess_instance(out, (hh, ww), hh, ww)
             groups = meter.summary()
         reps = reps * B                                     # images in the instrumented pass
         dom_name, (dom_n, dom_t, dom_fl) = groups[0]
@@ -277,7 +291,7 @@ def main():
                                    f"hipGraph); {args.classes} classes (name prompt), masks on, top-{mv.test_topk_per_image} detections "
                                    "per image incl. their full-resolution masks on the host; seeded synthetic weights",
                        "parallelism": f"dp{world}", "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B,
-                       "batched_vit": not args.no_batch_vit,
+                       "batched_vit": not args.no_batch_vit, "stream": args.stream,
                        "software_pipeline": (not args.no_pipeline) and "ViT of step i+1 overlaps the tails of step i; the last step is flushed inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
@@ -290,8 +304,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"], O = cpu_baseline(model, args.size, images[0], text)
-                result["parity"] = parity_object(mv, images[0], text, O)
+                result["cpu_baseline"], O = cpu_baseline(model, args.size, images[0].contiguous(), text)
+                result["parity"] = parity_object(mv, images[0].contiguous(), text, O)
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 result["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                           "sample": f"failed: {type(exc).__name__}: {exc}"}

@@ -203,6 +203,39 @@ def test_software_pipelined_runtime(B):
         assert inst.pred_masks.shape == m.shape and (inst.pred_masks != m).float().mean().item() < 1e-3
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_any_size_runtime(pipeline):
+    """any_size=True: ONE size-agnostic graph (image canvas + StaticGeometry buffers + device frame vector) serves a stream
+    of different image sizes -- also different sizes inside one step -- with the results of the per-size forward"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_padded", torch.float32)
+    mv = model.model_vision
+    g = torch.Generator().manual_seed(5)
+    sizes = [(200, 144), (256, 256), (128, 256), (176, 208), (240, 96), (256, 160)]
+    imgs = [torch.randint(0, 256, (3, h, w), generator=g).float().cuda() for h, w in sizes]
+    frames = [(2 * h, w + 16) for h, w in sizes]                       # output frames differ from the input sizes
+    ref = []
+    for im, (fh, fw) in zip(imgs, frames):
+        r = model([{"image": im, "height": fh, "width": fw, "text_features": text}])[0]["instances"]
+        ref.append((r.pred_boxes.tensor.clone(), r.scores.clone(), r.pred_classes.clone(), r.pred_masks.clone()))
+    run = GraphedForward(mv, images_per_step=2, pipeline=pipeline, any_size=True, max_out_pixels=512 * 272)
+    got, queue = [], []
+    for rnd_ in range(2):                                                # second round replays the captured graph
+        for i in range(0, len(imgs), 2):
+            queue.append(run.submit(imgs[i:i + 2], text, [f[0] for f in frames[i:i + 2]], [f[1] for f in frames[i:i + 2]]))
+            if len(queue) > (2 if pipeline else 1):      # a pipelined ticket completes with the next submit
+                got.extend(_own(run.result(queue.pop(0))[0]))
+    while queue:
+        got.extend(_own(run.result(queue.pop(0))[0]))
+    assert len(run._graphs) == 1 and len(got) == 2 * len(imgs)
+    for i, inst in enumerate(got):
+        b, sc, c, m = ref[i % len(imgs)]
+        frac = U.match_detections(inst.pred_boxes, inst.scores, inst.pred_classes, b, sc, c)
+        assert frac >= 0.99, (i, frac)
+        assert inst.pred_masks.shape == m.shape and (inst.pred_masks != m).float().mean().item() < 1e-3, i
+
+
 def test_eval_dataset_panoptic_on_gpu():
     """evaluation-dataset mode + panoptic merge with the fp32 HIP kernels"""
     model, orc, image, text, gold, image_c, text_c = _run("tiny_panoptic", torch.float32)
