@@ -69,6 +69,9 @@ SIGNATURES = {
                                    c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ape_hip_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p]),
+    "ape_hip_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int, c_void_p, c_float, c_float, c_float,
+                                 c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
     "ape_hip_head_gemv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ape_hip_attention_strided": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_float, c_int, c_void_p]),

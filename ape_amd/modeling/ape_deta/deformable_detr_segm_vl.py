@@ -205,6 +205,11 @@ class DeformableDETRSegmVL(nn.Module):
                         outc=(conv(self.output_conv),) + gn(self.output_conv), maskc=conv(self.mask_conv))
         return self._pack.get(self, dt, build)
 
+    def pos_cfg(self):
+        pe = self.position_embedding
+        return dict(num_pos_feats=pe.num_pos_feats, temperature=pe.temperature, normalize=pe.normalize, offset=pe.offset,
+                    eps=pe.eps, scale=pe.scale)
+
     def geometry(self, image_size, level_shapes):
         key = (tuple(image_size), tuple(level_shapes), str(self.device))
         if key in self._geo:

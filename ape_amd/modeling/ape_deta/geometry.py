@@ -36,6 +36,19 @@ class StaticGeometry(LevelGeometry):
             setattr(self, f, getattr(geo, f).clone())
         self._lvl_pos = {lvl_pos_key: lvl_pos.clone()}
 
+    def generate(self, square, image_size, pos_cfg, level_embeds):
+        """overwrite the buffers with the constants of `image_size` = (h, w), computed on the device by one kernel
+        (csrc/geometry.hip restates build_geometry / lvl_pos operation by operation)"""
+        from ... import ops
+        h, w = image_size
+        lp = next(iter(self._lvl_pos.values()))
+        dim_t = dim_t_table(pos_cfg["num_pos_feats"], pos_cfg["temperature"], lp.device)
+        ops.geometry(square, h, w, self.shapes, dim_t, level_embeds, pos_cfg["offset"], pos_cfg["eps"], pos_cfg["scale"],
+                     lvl_pos=lp, mask_u8=self.mask_u8, mask=self.mask.view(torch.uint8), invalid_u8=self.invalid_u8,
+                     enc_ref=self.enc_ref, proposals=self.proposals, valid_ratios=self.valid_ratios, vr4=self.vr4,
+                     box_scale=self.box_scale)
+        self.image_size = (h, w)
+
     def load(self, geo, lvl_pos):
         for f in self.FIELDS:
             getattr(self, f).copy_(getattr(geo, f), non_blocking=True)

@@ -182,6 +182,25 @@ def gemv(x, w, bias=None, alpha=1.0):
     return out
 
 
+def geometry(S, h, w, level_shapes, dim_t, level_embeds, offset, eps, scale, *, lvl_pos, mask_u8, mask, invalid_u8, enc_ref,
+             proposals, valid_ratios, vr4, box_scale):
+    """fill the per-image-size constant buffers of the deformable encoder for an (h, w) image inside the S x S pad
+    (csrc/geometry.hip; the tensor-level definition is modeling/ape_deta/geometry.build_geometry + lvl_pos)."""
+    _dev(dim_t, level_embeds, lvl_pos, mask_u8, mask, invalid_u8, enc_ref, proposals, valid_ratios, vr4, box_scale)
+    L = len(level_shapes)
+    T = sum(a * b for a, b in level_shapes)
+    if lvl_pos.shape[0] != T or mask_u8.numel() != T or enc_ref.shape != (T, L, 2) or proposals.shape != (T, 4):
+        raise ValueError("ape_amd.ops.geometry: buffer shapes do not match the level shapes")
+    for t in (lvl_pos, mask_u8, mask, invalid_u8, enc_ref, proposals, valid_ratios, vr4, box_scale, dim_t, level_embeds):
+        if not t.is_contiguous():
+            raise ValueError("ape_amd.ops.geometry: contiguous buffers only")
+    hw = (ctypes.c_int * (2 * L))(*[int(v) for ab in level_shapes for v in ab])
+    rc = _lib.load().ape_hip_geometry(int(S), int(h), int(w), L, hw, _p(dim_t), dim_t.numel(), _p(level_embeds), float(offset),
+                                     float(eps), float(scale), _p(lvl_pos), _dt(lvl_pos), _p(mask_u8), _p(mask), _p(invalid_u8),
+                                     _p(enc_ref), _p(proposals), _p(valid_ratios), _p(vr4), _p(box_scale), _stream())
+    _lib.check(rc, "ape_hip_geometry")
+
+
 def head_gemv(x, w, bias=None, alpha=1.0):
     """out[h, n] = alpha * x[h, :] . w[h, n, :] + bias[h, n]; x [H, D], w [H, N, D], bias [H, N] (all fp32) -> [H, N] fp32."""
     _dev(x, w, bias)

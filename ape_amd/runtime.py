@@ -155,6 +155,13 @@ class GraphedForward:
         strides = [self.mv.backbone._out_feature_strides[f] for f in self.mv.neck.in_features]
         return S, [(S // st, S // st) for st in strides]
 
+    def _geometry_into(self, sgeo, S, h, w):
+        """the constants of an (h, w) image, generated on the device into the graph's fixed buffers (one launch)"""
+        mv = self.mv
+        if not mv.position_embedding.normalize:
+            raise NotImplementedError("ape_amd: the geometry kernel implements the normalised sine embedding of the APE configs")
+        sgeo.generate(S, (h, w), mv.pos_cfg(), mv.transformer.packed(mv.compute_dtype)["level_embeds"])
+
     def _load_inputs(self, e, images, frames):
         """any_size: write image b into its canvas, the constants of its (h, w) into its StaticGeometry, and its output frame
         into the frame vector -- all stream-ordered in front of the replay"""
@@ -168,8 +175,7 @@ class GraphedForward:
                 raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
             e.images[b].copy_(e.mean_canvas, non_blocking=True)
             e.images[b][:, :h, :w].copy_(im, non_blocking=True)
-            g = mv.geometry((h, w), shapes)
-            e.sgeo[b].load(g, mv.transformer.lvl_pos(g, dt))
+            self._geometry_into(e.sgeo[b], S, h, w)
             height, width = frames[b]
             sx, sy = width / w, height / h
             vals.append([sx, sy, sx, sy, width, height, width, height])
@@ -340,8 +346,7 @@ class GraphedForward:
             vals = []
             for b, im in enumerate(images):
                 h, w = im.shape[-2:]
-                g = mv.geometry((h, w), shapes)
-                e.sgeo[b].load(g, mv.transformer.lvl_pos(g, mv.compute_dtype))
+                self._geometry_into(e.sgeo[b], S, h, w)
                 fh, fw = frames[b]
                 sx, sy = fw / w, fh / h
                 vals.append([sx, sy, sx, sy, fw, fh, fw, fh])

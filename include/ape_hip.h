@@ -284,6 +284,19 @@ int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, 
 int ape_hip_box_refine(const float* delta, int ldd, const float* ref, const float* vr4, int L, int Q, float eps, float* new_ref,
                        float* ref_in, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-image-size constants of the deformable encoder for an (h, w) image inside the S x S pad, written straight into the
+ * fixed buffers a captured graph reads: padding masks (deformable_detr_segm_vl.py:382-388), sine position embedding
+ * (detrex PositionEmbeddingSine, ape_deta_r50.py:35-40) + level embedding (deformable_transformer_vl.py:461) as
+ * lvl_pos [T, 2*npf] (f32 / bf16), valid ratios (:402-410), encoder reference points [T, L, 2] (:371-400), logit-space
+ * anchors [T, 4] with +inf where unusable and the unusable mask (:321-369), box limits (w, h, w, h).
+ * level_hw: HOST int [L, 2]; dim_t: device [npf] = temperature ** (2 * (i / 2) / npf).  -- csrc/geometry.hip
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_geometry(int S, int h, int w, int L, const int* level_hw, const float* dim_t, int npf, const float* level_embeds,
+                     float offset, float eps, float scale, void* lvl_pos, int lvl_pos_dt, uint8_t* mask_u8, uint8_t* mask_bool,
+                     uint8_t* invalid_u8, float* enc_ref, float* proposals, float* valid_ratios, float* vr4, float* box_scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -592,3 +592,34 @@ def test_gemm_p8(ops, tile, stagger, monkeypatch):
     ops.gemm(big[:, 256:512], w, None, out=out[:, 256:768], tile64=tile)
     assert relerr(out[:, 256:768], ref_ops.gemm(big[:, 256:512], w, None)) < 6e-3
     assert out[:, :256].abs().max().item() == 0 and out[:, 768:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_geometry_kernel(ops, dt):
+    """csrc/geometry.hip (per-image-size constants written into the graph's fixed buffers) == the tensor-level definition
+    geometry.build_geometry + level embedding, for full, padded and extreme image sizes"""
+    if SELF:
+        pytest.skip("device kernel vs its tensor-level definition")
+    from ape_amd.modeling.ape_deta import geometry as G
+    S = 512
+    shapes = [(S // st, S // st) for st in (4, 8, 16, 32, 64)]
+    cfg = dict(num_pos_feats=128, temperature=10000, normalize=True, offset=-0.5, eps=1e-6, scale=2 * 3.141592653589793)
+    lev = rnd(5, 256, seed=1)
+    for (h, w) in [(512, 512), (384, 512), (512, 299), (480, 17), (33, 512), (1, 1), (511, 257)]:
+        g = G.build_geometry(S, (h, w), shapes, torch.device(DEV), cfg)
+        lp = (g.pos + lev[g.level_ids]).to(dt).contiguous()
+        sg = G.StaticGeometry(G.build_geometry(S, (S, S), shapes, torch.device(DEV), cfg), "k", torch.zeros_like(lp))
+        sg.generate(S, (h, w), cfg, lev)
+        assert torch.equal(sg.mask, g.mask) and torch.equal(sg.mask_u8, g.mask_u8) and torch.equal(sg.invalid_u8, g.invalid_u8), (h, w)
+        assert torch.equal(sg.valid_ratios, g.valid_ratios) and torch.equal(sg.vr4, g.vr4) and torch.equal(sg.box_scale, g.box_scale)
+        fin = torch.isfinite(g.proposals)
+        assert torch.equal(torch.isfinite(sg.proposals), fin), (h, w)           # same usable / unusable pattern
+        e_prop = (sg.proposals[fin] - g.proposals[fin]).abs().max().item() if fin.any() else 0.0
+        e_ref = (sg.enc_ref - g.enc_ref).abs().max().item()
+        assert e_prop <= 2e-6 and e_ref <= 1e-6, (h, w, e_prop, e_ref)          # logf / division: last-bit differences
+        got = next(iter(sg._lvl_pos.values())).float()
+        usable = ~g.mask                                  # fully padded rows / columns: sin / cos of ~ -3e6 (chaotic), never attended
+        e_all = (got - lp.float()).abs().max().item()
+        e_use = (got[usable] - lp.float()[usable]).abs().max().item()
+        print(f"geometry kernel {dt} {h}x{w}: lvl_pos max abs diff usable {e_use:.2e} all {e_all:.2e}")
+        assert e_use <= (1e-6 if dt == torch.float32 else 8e-3), (h, w, e_use)
