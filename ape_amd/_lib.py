@@ -98,6 +98,13 @@ SIGNATURES = {
                                               c_void_p]),
     "ape_hip_box_refine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_bilinear_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_resize_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int]),
+    "ape_hip_resize_tile_rows": (c_int, [c_void_p, c_int, POINTER(c_int)]),
+    "ape_hip_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                           c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ape_hip_rle_workspace_words": (c_int, [c_int, c_int, c_int, c_int]),
+    "ape_hip_rle_encode": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ape_hip_rle_to_string": (c_int, [c_void_p, c_int, c_void_p, c_int]),
 }
 
 _lib = None

@@ -8,9 +8,11 @@ loaded with `DetectionCheckpointer` and the test-time resize comes from `cfg.dat
 model (`ape_amd.modeling.build.build_ape`) and the resize parameters.
 
 Input pipeline.  The reference resizes on the host with PIL (`ResizeTransform.apply_image`, bilinear with
-PIL's antialiasing filter support) and the model normalises + pads on the device.  Here the host does the same PIL
-resize (same library, so the same pixels) when PIL is importable, the upload goes through a pinned staging buffer, and
-normalise + pad are fused into the patch-embedding gather (csrc/spatial.hip `patchify`)."""
+PIL's antialiasing filter support), converts to float32 CHW on the host, and the model normalises + pads on the device.
+Here the ORIGINAL uint8 image is uploaded through a pinned staging buffer (3 bytes per source pixel instead of 12 per
+resized pixel) and one kernel (csrc/imageio.hip `resize_u8_kernel`, bit exact with Pillow's two-pass fixed-point resampler)
+does BGR -> RGB, the resize and the float32 CHW conversion; normalise + pad are fused into the patch-embedding gather
+(csrc/spatial.hip `patchify`).  There is no host resize in this package."""
 import numpy as np
 import torch
 
@@ -23,14 +25,6 @@ def shortest_edge_size(h, w, short_edge_length, max_size):
         s = max_size * 1.0 / max(newh, neww)
         newh, neww = newh * s, neww * s
     return int(newh + 0.5), int(neww + 0.5)
-
-
-def resize_image(img, newh, neww):
-    """HWC uint8 -> HWC uint8, PIL bilinear (what detectron2's ResizeTransform.apply_image does for uint8 images)"""
-    if img.shape[0] == newh and img.shape[1] == neww:
-        return img
-    from PIL import Image
-    return np.asarray(Image.fromarray(img).resize((neww, newh), Image.BILINEAR))
 
 
 class DefaultPredictor:
@@ -53,7 +47,7 @@ class DefaultPredictor:
         self._pinned = None
 
     def _upload(self, image_hwc):
-        """HWC uint8 (host) -> CHW float32 on the model's device through a pinned staging buffer"""
+        """HWC uint8 (host) -> the same bytes on the model's device through a pinned staging buffer"""
         dev = next(self.model.parameters()).device
         t = torch.from_numpy(np.ascontiguousarray(image_hwc))
         if dev.type == "cuda":
@@ -62,20 +56,29 @@ class DefaultPredictor:
             buf = self._pinned[: t.numel()].view(t.shape)
             buf.copy_(t)
             t = buf.to(dev, non_blocking=True)
-        return t.permute(2, 0, 1).float().contiguous()
+        return t
+
+    def _resize_params(self):
+        """(short_edge_length, max_size) of the test augmentation (ResizeShortestEdge with a single length in the APE configs)"""
+        if self.aug is not None and hasattr(self.aug, "short_edge_length"):
+            sel = self.aug.short_edge_length
+            return int(sel[0] if isinstance(sel, (tuple, list)) else sel), int(self.aug.max_size)
+        return self.short_edge_length, self.max_size
+
+    def preprocess(self, original_image):
+        """BGR uint8 [H, W, 3] (host) -> the model's `image` input: float32 [3, newh, neww] on the device (:213-220)"""
+        from . import ops
+        height, width = original_image.shape[:2]
+        sel, mx = self._resize_params()
+        newh, neww = shortest_edge_size(height, width, sel, mx)
+        raw = self._upload(original_image)
+        return ops.resize_bilinear_u8(raw, newh, neww, float_chw=True, flip=self.input_format == "RGB")
 
     @torch.no_grad()
     def __call__(self, original_image, text_prompt=None, mask_prompt=None):
         """original_image: np.ndarray [H, W, 3] uint8 in BGR order (cv2.imread) -> predictions dict of the model"""
-        if self.input_format == "RGB":
-            original_image = original_image[:, :, ::-1]
         height, width = original_image.shape[:2]
-        if self.aug is not None:
-            image = self.aug.get_transform(original_image).apply_image(original_image)
-        else:
-            newh, neww = shortest_edge_size(height, width, self.short_edge_length, self.max_size)
-            image = resize_image(np.ascontiguousarray(original_image), newh, neww)
-        inputs = {"image": self._upload(image), "height": height, "width": width}
+        inputs = {"image": self.preprocess(original_image), "height": height, "width": width}
         if text_prompt is not None:
             inputs["prompt"] = "text"
             inputs["text_prompt"] = text_prompt

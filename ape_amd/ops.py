@@ -662,3 +662,122 @@ def fork(fn, force=False):
         done = torch.cuda.Event()
         done.record(side)
     return _Joined(result, done, keep=fn)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Input pipeline / evaluator wire format (csrc/imageio.hip).  The coefficient tables and the RLE string are HOST functions
+# of the library (plain C, usable without a device); the pixel work are kernels.
+# ------------------------------------------------------------------------------------------------------------------
+def resize_coeffs(in_size, out_size):
+    """Pillow's bilinear coefficients of one axis: (bounds [out, 2] int32, kk [out, ksize] int32) as host tensors"""
+    lib = _lib.load()
+    ks = lib.ape_hip_resize_coeffs(int(in_size), int(out_size), None, None, 0)
+    if ks <= 0:
+        _lib.check(ks, "ape_hip_resize_coeffs")
+    bounds = torch.empty((out_size, 2), dtype=torch.int32)
+    kk = torch.empty((out_size, ks), dtype=torch.int32)
+    rc = lib.ape_hip_resize_coeffs(int(in_size), int(out_size), ctypes.c_void_p(bounds.data_ptr()), ctypes.c_void_p(kk.data_ptr()), ks)
+    if rc != ks:
+        _lib.check(rc if rc < 0 else -1, "ape_hip_resize_coeffs")
+    return bounds, kk
+
+
+class _ResizePlan:
+    """device coefficient tables + tiling of one (H, W) -> (newh, neww) resize; built once per size pair"""
+
+    def __init__(self, H, W, newh, neww, device):
+        self.key = (H, W, newh, neww)
+        self.bh = self.kh = self.bv = self.kv = None
+        self.ks_h = self.ks_v = 0
+        self.tile_h, self.lds_rows = 32, 32
+        if neww != W:
+            b, k = resize_coeffs(W, neww)
+            self.bh, self.kh, self.ks_h = b.to(device), k.to(device), k.shape[1]
+        if newh != H:
+            b, k = resize_coeffs(H, newh)
+            th = ctypes.c_int(0)
+            rows = _lib.load().ape_hip_resize_tile_rows(ctypes.c_void_p(b.data_ptr()), newh, ctypes.byref(th))
+            if rows <= 0:
+                _lib.check(rows if rows < 0 else -1, "ape_hip_resize_tile_rows")
+            self.tile_h, self.lds_rows = th.value, rows
+            self.bv, self.kv, self.ks_v = b.to(device), k.to(device), k.shape[1]
+
+
+_RESIZE_PLANS = {}
+
+
+def resize_bilinear_u8(src, newh, neww, *, out=None, float_chw=False, flip=False):
+    """PIL `Image.resize((neww, newh), BILINEAR)` of an HWC uint8 device image, bit exact.  float_chw=False -> uint8
+    [newh, neww, 3]; True -> float32 [3, newh, neww] (the model's `image` input; `out` may be a view with free row / plane
+    strides, e.g. the top-left corner of a larger canvas).  flip reverses the channel order (BGR <-> RGB)."""
+    _dev(src, out)
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3 or src.stride(2) != 1 or src.stride(1) != 3:
+        raise ValueError("ape_amd.ops.resize_bilinear_u8: src must be uint8 [H, W, 3] with packed pixels")
+    H, W = src.shape[:2]
+    key = (H, W, newh, neww, src.device.index)
+    plan = _RESIZE_PLANS.get(key)
+    if plan is None:
+        if len(_RESIZE_PLANS) > 256:
+            _RESIZE_PLANS.clear()
+        plan = _RESIZE_PLANS[key] = _ResizePlan(H, W, newh, neww, src.device)
+    if float_chw:
+        if out is None:
+            out = torch.empty((3, newh, neww), dtype=torch.float32, device=src.device)
+        if out.dtype != torch.float32 or tuple(out.shape) != (3, newh, neww) or out.stride(2) != 1:
+            raise ValueError("ape_amd.ops.resize_bilinear_u8: out must be float32 [3, newh, neww] with contiguous rows")
+        kind, ld, plane = 1, out.stride(1), out.stride(0)
+    else:
+        if out is None:
+            out = torch.empty((newh, neww, 3), dtype=torch.uint8, device=src.device)
+        if out.dtype != torch.uint8 or tuple(out.shape) != (newh, neww, 3) or out.stride(2) != 1 or out.stride(1) != 3:
+            raise ValueError("ape_amd.ops.resize_bilinear_u8: out must be uint8 [newh, neww, 3] with packed pixels")
+        kind, ld, plane = 0, out.stride(0), 0
+    rc = _lib.load().ape_hip_resize_bilinear_u8(_p(src), H, W, src.stride(0), _p(plan.bh), _p(plan.kh), plan.ks_h, _p(plan.bv),
+                                                _p(plan.kv), plan.ks_v, newh, neww, plan.tile_h, plan.lds_rows, _p(out), kind,
+                                                ld, plane, int(bool(flip)), _stream())
+    _lib.check(rc, "ape_hip_resize_bilinear_u8")
+    return out
+
+
+def rle_encode(masks, cap=4096, counts=None, nruns=None):
+    """COCO run lengths of n row-major masks [n, H, W] (uint8 / bool, non-zero = foreground): (counts [n, cap] int32 view of
+    uint32, nruns [n] int32) on the device; nruns[i] > cap marks a truncated encoding.  counts / nruns: optional
+    preallocated outputs (contiguous int32 [n, cap] / [n])."""
+    _dev(masks)
+    if masks.dtype == torch.bool:
+        masks = masks.view(torch.uint8)
+    if masks.dtype != torch.uint8 or masks.dim() != 3 or not masks.is_contiguous():
+        raise ValueError("ape_amd.ops.rle_encode: masks must be contiguous uint8 / bool [n, H, W]")
+    n, H, W = masks.shape
+    if counts is None:
+        counts = torch.empty((n, cap), dtype=torch.int32, device=masks.device)
+    if nruns is None:
+        nruns = torch.zeros((n,), dtype=torch.int32, device=masks.device)
+    _dev(counts, nruns)
+    if (counts.dtype != torch.int32 or nruns.dtype != torch.int32 or tuple(counts.shape) != (n, cap) or tuple(nruns.shape) != (n,)
+            or not counts.is_contiguous() or not nruns.is_contiguous()):
+        raise ValueError("ape_amd.ops.rle_encode: counts / nruns must be contiguous int32 [n, cap] / [n]")
+    if n == 0:
+        return counts, nruns
+    lib = _lib.load()
+    words = lib.ape_hip_rle_workspace_words(n, H, W, cap)
+    if words <= 0:
+        raise ValueError("ape_amd.ops.rle_encode: workspace exceeds 2^31 words; encode fewer masks per call")
+    ws = torch.empty((words,), dtype=torch.int32, device=masks.device)
+    rc = lib.ape_hip_rle_encode(_p(masks), n, H, W, _p(ws), _p(counts), cap, _p(nruns), _stream())
+    _lib.check(rc, "ape_hip_rle_encode")
+    return counts, nruns
+
+
+def rle_to_string(counts):
+    """host: run lengths (1-D int32/uint32 host tensor or sequence) -> the bytes stored under "counts" in COCO json"""
+    c = torch.as_tensor(counts, dtype=torch.int64).to(torch.int32).contiguous() if not isinstance(counts, torch.Tensor) \
+        else counts.contiguous()
+    if c.is_cuda or c.dtype not in (torch.int32,):
+        raise ValueError("ape_amd.ops.rle_to_string: counts must be a host int32 tensor")
+    n = c.numel()
+    buf = ctypes.create_string_buffer(max(8, 7 * n))
+    rc = _lib.load().ape_hip_rle_to_string(ctypes.c_void_p(c.data_ptr()), n, buf, len(buf))
+    if rc < 0:
+        raise RuntimeError("ape_hip_rle_to_string: buffer too small")
+    return buf.raw[:rc]

@@ -61,7 +61,7 @@ class GraphedForward:
     SLOTS = 2
 
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
-                 pipeline=False, any_size=False, max_out_pixels=None):
+                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096):
         self.mv = model_vision
         self.batch_vit = batch_vit
         self.pipeline = bool(pipeline)
@@ -71,6 +71,12 @@ class GraphedForward:
         self.with_masks = with_masks
         self.B = int(images_per_step)
         self.max_out_pixels = max_out_pixels          # any_size: largest output frame (height * width) a slot can hold
+        # "bitmask": pred_masks [n, H, W] bool on the host (the reference's output contract, ~1 MB per mask over PCIe);
+        # "rle": the evaluators' wire format instead -- the pasted masks are run-length encoded on the device
+        # (ops.rle_encode) and only the runs travel; instances carry `pred_masks_rle` (ape_amd/evaluation.py)
+        if mask_format not in ("bitmask", "rle"):
+            raise ValueError("GraphedForward: mask_format is 'bitmask' or 'rle'")
+        self.mask_format, self.rle_cap = mask_format, int(rle_cap)
         self._graphs = {}
         self._copy_stream = None
 
@@ -234,7 +240,12 @@ class GraphedForward:
             s.d_rec = torch.empty((B, k, 8), dtype=torch.float32, device=dev)
             s.h_rec = torch.empty((B, k, 8), dtype=torch.float32, pin_memory=True)
             s.d_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, device=dev) if has_masks else None
-            s.h_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, pin_memory=True) if has_masks else None
+            rle = has_masks and self.mask_format == "rle"
+            s.h_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, pin_memory=True) if has_masks and not rle else None
+            s.d_runs = torch.empty((B, k, self.rle_cap), dtype=torch.int32, device=dev) if rle else None
+            s.d_nruns = torch.zeros((B, k), dtype=torch.int32, device=dev) if rle else None
+            s.h_runs = torch.empty((B, k, self.rle_cap), dtype=torch.int32, pin_memory=True) if rle else None
+            s.h_nruns = torch.zeros((B, k), dtype=torch.int32, pin_memory=True) if rle else None
             s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
             s.busy = False
             e.slots.append(s)
@@ -325,12 +336,17 @@ class GraphedForward:
                 s.d_rec[b].copy_(rec, non_blocking=True)
                 if has_masks:
                     fh, fw = completes.frames[b]
-                    ops.paste_bits(masks128, boxes, fh, fw, out=s.d_masks[b, : k * fh * fw].view(k, fh, fw))   # detector_postprocess (:869-871)
+                    pasted = ops.paste_bits(masks128, boxes, fh, fw, out=s.d_masks[b, : k * fh * fw].view(k, fh, fw))   # detector_postprocess (:869-871)
+                    if s.d_runs is not None:
+                        ops.rle_encode(pasted, cap=self.rle_cap, counts=s.d_runs[b], nruns=s.d_nruns[b])
             s.computed.record(cur)
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(s.computed)
                 s.h_rec.copy_(s.d_rec, non_blocking=True)
-                if has_masks:
+                if has_masks and s.d_runs is not None:
+                    s.h_runs.copy_(s.d_runs, non_blocking=True)
+                    s.h_nruns.copy_(s.d_nruns, non_blocking=True)
+                elif has_masks:
                     for b in range(len(outs)):
                         fh, fw = completes.frames[b]
                         s.h_masks[b, : k * fh * fw].copy_(s.d_masks[b, : k * fh * fw], non_blocking=True)
@@ -376,12 +392,30 @@ class GraphedForward:
             hr = s.h_rec[b]
             n = int((hr[:, 7] > 0.5).sum())                 # kept detections are a prefix (sorted on the device)
             fh, fw = ticket.frames[b]
-            masks = s.h_masks[b, : k * fh * fw].view(k, fh, fw)[:n].view(torch.bool) if s.has_masks else None   # zero-copy
+            extra = {}
+            masks = None
+            if s.has_masks and s.h_runs is not None:
+                extra["pred_masks_rle"] = self._rles(s, b, n, fh, fw)
+            elif s.has_masks:
+                masks = s.h_masks[b, : k * fh * fw].view(k, fh, fw)[:n].view(torch.bool)   # zero-copy
             insts.append(make_instances((fh, fw), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(), masks,
-                                        query_index=hr[:n, 6].long()))
+                                        query_index=hr[:n, 6].long(), **extra))
         if ticket.single:
             return insts[0], ticket.rec6
         return insts, ticket.rec6
+
+    def _rles(self, s, b, n, fh, fw):
+        """COCO RLE dicts of the first n (kept) detections of image b of slot s; a mask with more runs than the slot's buffer
+        holds is encoded again from the slot's device masks (still this ticket's until the slot is reused)"""
+        from . import evaluation
+        rles = evaluation.rles_from_runs(s.h_runs[b, :n], torch.clamp(s.h_nruns[b, :n], max=self.rle_cap), (fh, fw))
+        over = (s.h_nruns[b, :n] > self.rle_cap).nonzero().flatten().tolist()
+        if over:
+            k = s.d_rec.shape[1]
+            dm = s.d_masks[b, : k * fh * fw].view(k, fh, fw)
+            for i, r in zip(over, evaluation.encode_masks(dm[torch.tensor(over, device=dm.device)], cap=self.rle_cap * 8)):
+                rles[i] = r
+        return rles
 
     def __call__(self, image, text, height=None, width=None, prompt="name"):
         """synchronous form: image -> (instances on the host, device record [k,6])"""

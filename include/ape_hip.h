@@ -297,6 +297,43 @@ int ape_hip_geometry(int S, int h, int w, int L, const int* level_hw, const floa
                      uint8_t* invalid_u8, float* enc_ref, float* proposals, float* valid_ratios, float* vr4, float* box_scale,
                      void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline: the predictor's test-time resize, ape/engine/defaults.py:213-222
+ * (`self.aug.get_transform(img).apply_image(img)` = ResizeShortestEdge -> PIL Image.resize(BILINEAR) on uint8), bit
+ * exact with Pillow's Resample.c (separable triangle filter, 22-bit fixed-point coefficients, horizontal pass to uint8,
+ * vertical pass to uint8).  -- csrc/imageio.hip
+ *   resize_coeffs    : HOST function.  Coefficients of one axis (Pillow precompute_coeffs + normalize_coeffs_8bpc):
+ *                      bounds [out, 2] = (first source index, count), kk [out, ksize_cap] int32.  Returns ksize (also with
+ *                      bounds = kk = NULL, to size the arrays); the caller uploads both arrays to the device.
+ *   resize_tile_rows : HOST function.  From the HOST copy of the vertical bounds: output-tile height (*tile_h) and the
+ *                      LDS rows (return value) the kernel needs.
+ *   resize_bilinear_u8: src HWC uint8 [H, src_ld bytes] -> dst_kind 0: uint8 HWC (dst_ld bytes per row), 1: float32 CHW
+ *                      (dst_ld floats per row, dst_plane floats per channel) = the model's `image` input
+ *                      (defaults.py:220 `image.astype("float32").transpose(2, 0, 1)`); flip = 1 reverses the channel order
+ *                      (defaults.py:216 BGR -> RGB).  bounds_* / kk_* are DEVICE arrays; NULL = that axis keeps its size.
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk, int ksize_cap);
+int ape_hip_resize_tile_rows(const int32_t* bounds_v_host, int newh, int* tile_h);
+int ape_hip_resize_bilinear_u8(const uint8_t* src, int H, int W, int src_ld, const int32_t* bounds_h, const int32_t* kk_h,
+                               int ks_h, const int32_t* bounds_v, const int32_t* kk_v, int ks_v, int newh, int neww, int tile_h,
+                               int lds_rows, void* dst, int dst_kind, int dst_ld, int dst_plane, int flip, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Evaluator wire format: COCO run-length encoding of the pasted instance masks, what
+ * instances_to_coco_json (ape/evaluation/d3_evaluation.py:441-493, refcoco_evaluation.py:425-477, demo/demo_lazy.py:189-198)
+ * obtains from pycocotools `mask_util.encode(np.array(mask[:, :, None], order="F"))` (cocoapi maskApi.c rleEncode /
+ * rleToString).  -- csrc/imageio.hip
+ *   rle_encode   : masks [n, H, W] uint8 (0 / non-zero, row-major) -> counts [n, cap] uint32 = column-major run lengths
+ *                  starting with the zeros, nruns [n].  nruns[i] > cap means the encoding was truncated (call again with a
+ *                  larger cap).  workspace: ape_hip_rle_workspace_words(n, H, W, cap) uint32.
+ *   rle_to_string: HOST function, counts -> the ASCII string stored under "counts"; returns its length (-needed if the
+ *                  buffer is too small).
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_rle_workspace_words(int n, int H, int W, int cap);
+int ape_hip_rle_encode(const uint8_t* masks, int n, int H, int W, uint32_t* workspace, uint32_t* counts, int cap, uint32_t* nruns,
+                       void* stream);
+int ape_hip_rle_to_string(const uint32_t* counts, int n, char* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -366,3 +366,50 @@ def box_refine(delta, ref, vr4, eps=1e-3):
         x = ref.clamp(min=0, max=1)
         new_ref = (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()
     return new_ref, (new_ref[:, None, :] * vr4[None]).contiguous()
+
+
+# ---- input pipeline / evaluator wire format: the definitions are the libraries the reference calls (Pillow) and the
+#      oracle's restatement of pycocotools' RLE (oracle/imageio.py)
+def resize_coeffs(in_size, out_size):
+    from oracle import imageio as O
+    b, k = O.precompute_coeffs(in_size, out_size)
+    return torch.from_numpy(b), torch.from_numpy(k)
+
+
+def resize_bilinear_u8(src, newh, neww, *, out=None, float_chw=False, flip=False):
+    import numpy as np
+    from PIL import Image
+    a = src.cpu().numpy()
+    r = np.asarray(Image.fromarray(a).resize((neww, newh), Image.BILINEAR)) if (newh, neww) != a.shape[:2] else a
+    if flip:
+        r = r[:, :, ::-1]
+    t = torch.from_numpy(np.ascontiguousarray(r)).to(src.device)
+    if float_chw:
+        t = t.permute(2, 0, 1).float()
+    if out is not None:
+        out.copy_(t)
+        return out
+    return t.contiguous()
+
+
+def rle_encode(masks, cap=4096, counts=None, nruns=None):
+    from oracle import imageio as O
+    n = masks.shape[0]
+    out_c, out_n = counts, nruns
+    counts = torch.zeros((n, cap), dtype=torch.int32)
+    nruns = torch.zeros((n,), dtype=torch.int32)
+    for i in range(n):
+        c = O.rle_encode(masks[i].cpu().numpy() != 0)
+        nruns[i] = len(c)
+        m = min(len(c), cap)
+        counts[i, :m] = torch.tensor(c[:m], dtype=torch.int64).to(torch.int32)
+    if out_c is not None:
+        out_c.copy_(counts)
+        out_n.copy_(nruns)
+        return out_c, out_n
+    return counts.to(masks.device), nruns.to(masks.device)
+
+
+def rle_to_string(counts):
+    from oracle import imageio as O
+    return O.rle_to_string([int(c) & 0xFFFFFFFF for c in (counts.tolist() if hasattr(counts, "tolist") else counts)])
