@@ -1,2 +1,2 @@
 """ape/modeling/__init__.py (hot-path part)"""
-from . import ape_deta, backbone  # noqa: F401
+from . import ape_deta, backbone, text  # noqa: F401

@@ -75,6 +75,10 @@ SIGNATURES = {
     "ape_hip_head_gemv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ape_hip_attention_strided": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_float, c_int, c_void_p]),
+    "ape_hip_attention_causal": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                         c_int, c_int, c_float, c_int, c_void_p]),
+    "ape_hip_embed_tokens": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_int, c_void_p]),
     "ape_hip_patchify": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), c_void_p,
                                  c_int, c_int, c_void_p]),
     "ape_hip_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),

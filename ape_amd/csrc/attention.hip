@@ -1,4 +1,5 @@
-// Flash-style scaled-dot-product attention for gfx950 (non-causal, no mask, no dropout).
+// Flash-style scaled-dot-product attention for gfx950 (no dropout; optional causal mask for the CLIP text tower,
+// ape/modeling/text/eva02_clip/transformer.py:714-720 -- key tiles above the diagonal of a workgroup are never loaded).
 //
 // Replaces F.scaled_dot_product_attention at ape/modeling/backbone/vit_eva_clip.py:261-263 (16 heads x 64;
 // 4 windows x 1024 tokens or 1 x 4096 tokens) and the attention core of nn.MultiheadAttention used by the
@@ -22,6 +23,7 @@ struct AttnParams {
   int bstride;       // rows (tokens) between consecutive batch items / windows, >= N
   float scale_log2;  // scale * log2(e)
   float scale;
+  int causal;        // f32 kernel: keys > query are masked (the bf16 kernel takes it as a template argument)
 };
 
 __device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
@@ -32,7 +34,7 @@ __device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
 
 // QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
-template <int HD, int QT>
+template <int HD, int QT, bool CAUSAL = false>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
@@ -108,7 +110,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     for (int d = 0; d < DT; ++d) oacc[u][d] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   }
 
-  const int nt = (N + 63) / 64;
+  int nt = (N + 63) / 64;
+  if (CAUSAL) {                          // key tiles beyond the workgroup's last query are fully masked: skip them
+    const int last_q = min(N - 1, qblk * (64 * QT) + 64 * QT - 1);
+    nt = min(nt, last_q / 64 + 1);
+  }
   issue(0, 0);
   __syncthreads();                       // s_waitcnt vmcnt(0) + barrier: tile 0 has landed for every wave
   for (int t = 0; t < nt; ++t) {
@@ -140,6 +146,18 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (kbase + i * 16 + r >= N) sacc[u][i][r] = -INFINITY;
+    }
+    if (CAUSAL) {
+      // key > query -> -inf.  Key 0 is visible to every query, so the running maximum is finite from tile 0 on and a fully
+      // masked later tile contributes exact zeros.
+      const int kbase = t * 64 + fq * 4;
+#pragma unroll
+      for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kbase + i * 16 + r > qrow[u]) sacc[u][i][r] = -INFINITY;
     }
     uint4 pk[QT][2];
 #pragma unroll
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
         float a = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) a = fmaf(q[d], sK[c0 + kk][d], a);
-        if (key0 + c0 + kk >= N) a = -INFINITY;
+        if (key0 + c0 + kk >= N || (p.causal && key0 + c0 + kk > qrow)) a = -INFINITY;
         s[kk] = a;
         mx = fmaxf(mx, a);
       }
@@ -284,14 +302,15 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
   }
 }
 
-extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
-                                         int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream) {
+static int attention_launch(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int B, int N,
+                            int bstride, int H, int HD, float scale, int dt, int causal, void* stream) {
   APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
   APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64), "ape_hip_attention: bad shape (HD must be 32 or 64)");
   APE_CHECK_ARG(bstride >= N, "ape_hip_attention: batch stride %d < N %d", bstride, N);
   AttnParams p;
   p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H; p.bstride = bstride;
   p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+  p.causal = causal;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(N, 64), H, B);
   if (dt == APE_DT_BF16) {
@@ -302,7 +321,11 @@ extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, 
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
     const bool big = (size_t)ceil_div(N, 128) * H * B >= 512;
     if (big) grid.x = ceil_div(N, 128);
-    if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p); }
+    if (causal) {
+      APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
+      if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true>), grid, dim3(256), 0, s, p);
+    } else if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p); }
     else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
   } else {
     if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
@@ -310,6 +333,16 @@ extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, 
   }
   APE_CHECK_LAUNCH("ape_hip_attention");
   return 0;
+}
+
+extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                         int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream) {
+  return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, B, N, bstride, H, HD, scale, dt, 0, stream);
+}
+
+extern "C" int ape_hip_attention_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                        int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream) {
+  return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, B, N, bstride, H, HD, scale, dt, 1, stream);
 }
 
 extern "C" int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,

@@ -146,3 +146,47 @@ extern "C" int ape_hip_gather_rows(const void* x, int ldx, const int* idx, int n
   APE_CHECK_LAUNCH("ape_hip_gather_rows");
   return 0;
 }
+
+// ---- token embedding of the CLIP text tower (ape/modeling/text/eva02_clip/transformer.py:724-726,
+//      clip_wrapper_eva02.py:136-138): out[b * Lp + t] = table[tokens[b, t]] + pos[t] for t < L, zero rows for L <= t < Lp
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int32_t* __restrict__ tokens, int ldt, const T* __restrict__ table,
+                                                           int ldtab, const T* __restrict__ pos, int ldpos, float* __restrict__ out,
+                                                           int ldo, int L, int Lp, int W, int vocab) {
+  const int row = blockIdx.x, b = row / Lp, t = row % Lp;
+  float* o = out + (size_t)row * ldo;
+  if (t >= L) {
+    for (int c = threadIdx.x * 4; c < W; c += 1024) *reinterpret_cast<float4*>(o + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  int tok = tokens[(size_t)b * ldt + t];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  const T* e = table + (size_t)tok * ldtab;
+  const T* p = pos + (size_t)t * ldpos;
+  for (int c = threadIdx.x * 4; c < W; c += 1024) {
+    float a[4], q[4];
+    ld4<T>(e + c, a);
+    ld4<T>(p + c, q);
+    // summed in fp32 (the residual stream is fp32 here; the reference adds in the parameter dtype)
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = a[i] + q[i];
+    *reinterpret_cast<float4*>(o + c) = make_float4(r[0], r[1], r[2], r[3]);
+  }
+}
+
+extern "C" int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* table, int ldtab, const void* pos, int ldpos, int dt,
+                                    float* out, int ldo, int B, int L, int Lp, int W, int vocab, void* stream) {
+  APE_CHECK_ARG(tokens && table && pos && out && B > 0 && L > 0 && Lp >= L && vocab > 0, "ape_hip_embed_tokens: bad arguments");
+  APE_CHECK_ARG(W % 4 == 0 && ldtab % 4 == 0 && ldpos % 4 == 0 && ldo % 4 == 0, "ape_hip_embed_tokens: widths must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(B * Lp), block(256);
+  if (dt == APE_DT_BF16)
+    hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, block, 0, s, tokens, ldt, (const bf16_t*)table, ldtab, (const bf16_t*)pos,
+                       ldpos, out, ldo, L, Lp, W, vocab);
+  else
+    hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, block, 0, s, tokens, ldt, (const float*)table, ldtab, (const float*)pos, ldpos,
+                       out, ldo, L, Lp, W, vocab);
+  APE_CHECK_LAUNCH("ape_hip_embed_tokens");
+  return 0;
+}

@@ -323,8 +323,8 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     return out
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None):
-    """softmax(scale * q k^T) v per (window, head).  q,k: [rows, >=heads*head_dim] views; vt: V transposed
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False):
+    """softmax(scale * q k^T) v per (window, head); causal: keys after the query are masked (CLIP text tower).  q,k: [rows, >=heads*head_dim] views; vt: V transposed
     [heads*head_dim, >= round_up(rows, 64)] (finite padding); returns [rows, heads*head_dim].  Window b owns rows
     b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride)."""
     _dev(q, k, vt, out)
@@ -334,9 +334,27 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=No
     stride = n if stride is None else int(stride)
     if out is None:
         out = (torch.empty if stride == n else torch.zeros)((batch * stride, heads * head_dim), dtype=q.dtype, device=q.device)
-    rc = _lib.load().ape_hip_attention_strided(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, stride,
-                                              heads, head_dim, float(scale), _dt(q), _stream())
+    fn = _lib.load().ape_hip_attention_causal if causal else _lib.load().ape_hip_attention_strided
+    rc = fn(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, stride, heads, head_dim, float(scale),
+            _dt(q), _stream())
     _lib.check(rc, "ape_hip_attention")
+    return out
+
+
+def embed_tokens(tokens, table, pos, length, stride):
+    """CLIP text tower input: out[b * stride + t] = table[tokens[b, t]] + pos[t] (t < length), zero rows up to `stride`;
+    tokens int32 [B, ctx]; table [vocab, W], pos [ctx, W] (f32 / bf16) -> fp32 [B * stride, W]"""
+    _dev(tokens, table, pos)
+    if tokens.dtype != torch.int32 or tokens.dim() != 2 or tokens.stride(1) != 1:
+        raise ValueError("ape_amd.ops.embed_tokens: tokens must be int32 [B, ctx] with unit inner stride")
+    _rowmajor(table, "table"), _rowmajor(pos, "pos")
+    if table.dtype != pos.dtype or table.shape[1] != pos.shape[1] or length > tokens.shape[1] or length > pos.shape[0] or stride < length:
+        raise ValueError("ape_amd.ops.embed_tokens: inconsistent table / pos / length / stride")
+    B, W = tokens.shape[0], table.shape[1]
+    out = torch.empty((B * stride, W), dtype=torch.float32, device=tokens.device)
+    rc = _lib.load().ape_hip_embed_tokens(_p(tokens), tokens.stride(0), _p(table), _ld(table), _p(pos), _ld(pos), _dt(table), _p(out),
+                                         W, B, int(length), int(stride), W, table.shape[0], _stream())
+    _lib.check(rc, "ape_hip_embed_tokens")
     return out
 
 

@@ -185,6 +185,10 @@ int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void
  * (196 tokens per window, stored at a stride of 200 so that every window starts 16-byte aligned in Vt). */
 int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                               int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream);
+/* the same with a causal mask (keys after the query are masked): the CLIP text tower's attention
+ * (ape/modeling/text/eva02_clip/transformer.py:474-478 with the mask built at :714-720).  bf16: HD = 64. */
+int ape_hip_attention_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                              int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------
@@ -333,6 +337,16 @@ int ape_hip_rle_workspace_words(int n, int H, int W, int cap);
 int ape_hip_rle_encode(const uint8_t* masks, int n, int H, int W, uint32_t* workspace, uint32_t* counts, int cap, uint32_t* nruns,
                        void* stream);
 int ape_hip_rle_to_string(const uint32_t* counts, int n, char* out, int cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Text tower, token embedding: ape/modeling/text/eva02_clip/transformer.py:724-726 /
+ * clip_wrapper_eva02.py:136-138  x = token_embedding(text) + positional_embedding.
+ * tokens [B, ldt] int32; table [vocab, ldtab], pos [ctx, ldpos] (dt f32 / bf16); out [B * Lp, ldo] fp32 with rows
+ * b * Lp + t: the first L positions of every text, zero rows for L <= t < Lp (Lp = the attention's batch stride).
+ * The rest of the tower runs on ape_hip_gemm / ape_hip_layernorm / ape_hip_attention_causal.  -- csrc/spatial.hip
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* table, int ldtab, const void* pos, int ldpos, int dt, float* out,
+                         int ldo, int B, int L, int Lp, int W, int vocab, void* stream);
 
 #ifdef __cplusplus
 }

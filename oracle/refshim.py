@@ -539,3 +539,37 @@ def install():
                 setattr(A, name, obj)
     _installed = True
     return sys.modules["ape"]
+
+
+def install_text():
+    """Load the reference's CLIP text tower files (ape/modeling/text/eva02_clip/{utils,rope,transformer,tokenizer}.py) under
+    stand-ins for timm / torchvision / ftfy.  Returns (transformer module, tokenizer module)."""
+    install()
+    if "ape.modeling.text.eva02_clip.transformer" in sys.modules:
+        return sys.modules["ape.modeling.text.eva02_clip.transformer"], sys.modules["ape.modeling.text.eva02_clip.tokenizer"]
+    _mod("timm.models.layers", trunc_normal_=nn.init.trunc_normal_)
+    _mod("timm.layers", trunc_normal_=nn.init.trunc_normal_)
+    _mod("torchvision.ops.misc", FrozenBatchNorm2d=nn.BatchNorm2d)
+    if "ftfy" not in sys.modules:
+        try:
+            import ftfy  # noqa: F401
+        except ImportError:
+            _mod("ftfy", fix_text=lambda s: s)          # identity on clean text (the tests use ASCII / NFC strings)
+    _mod("ape.modeling.text.eva02_clip")
+
+    def load(name):
+        modname = f"ape.modeling.text.eva02_clip.{name}"
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, "ape/modeling/text/eva02_clip", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        setattr(sys.modules["ape.modeling.text.eva02_clip"], name, m)
+        spec.loader.exec_module(m)
+        return m
+
+    load("utils")
+    load("rope")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr = load("transformer")
+    tok = load("tokenizer")
+    return tr, tok

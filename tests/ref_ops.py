@@ -187,7 +187,14 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     return o.to(odt)
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None):
+def embed_tokens(tokens, table, pos, length, stride):
+    B, W = tokens.shape[0], table.shape[1]
+    out = torch.zeros((B, stride, W), dtype=torch.float32, device=tokens.device)
+    out[:, :length] = table[tokens[:, :length].long()].float() + pos[:length].float()[None]
+    return out.reshape(B * stride, W)
+
+
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False):
     E = heads * head_dim
     stride = n if stride is None else stride
     rows = batch * stride
@@ -201,6 +208,8 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=No
     qf, kf = win(q), win(k)
     vf = vt[:, :rows].float().reshape(heads, head_dim, batch, stride)[..., :n].permute(2, 0, 3, 1)
     att = (qf @ kf.transpose(-1, -2)) * scale
+    if causal:
+        att = att + torch.full((n, n), float("-inf"), device=att.device).triu_(1)
     o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                       # [batch, n, heads, head_dim]
     full = o.new_zeros((batch, stride, heads, head_dim))
     full[:, :n] = o

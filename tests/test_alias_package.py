@@ -20,6 +20,7 @@ TARGETS = [
     ("ape.modeling.backbone.vit_eva_clip", ["SimpleFeaturePyramid", "ViT"]),
     ("ape.modeling.backbone.vit_eva02", ["SimpleFeaturePyramid", "ViT"]),
     ("ape.engine.defaults", ["DefaultPredictor"]),
+    ("ape.modeling.text", ["EVA02CLIP"]),
 ]
 
 SCRIPT = r"""
