@@ -102,6 +102,16 @@ SIGNATURES = {
                                               c_void_p]),
     "ape_hip_box_refine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_bilinear_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_enc_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_proposal_topk": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_proposal_order": (c_int, [c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_proposal_quota": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_int),
+                                       c_int, c_int, c_void_p, c_void_p]),
+    "ape_hip_det_sort": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "ape_hip_det_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
     "ape_hip_resize_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int]),
     "ape_hip_resize_tile_rows": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "ape_hip_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

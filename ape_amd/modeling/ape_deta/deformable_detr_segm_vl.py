@@ -483,26 +483,10 @@ class DeformableDETRSegmVL(nn.Module):
         (deformable_detr_segm_vl.py:759-810 + ape_deta/fast_rcnn.py:97-201).  Fixed-shape outputs:
         det_boxes [k,4], det_scores [k] (-1 = empty slot), det_classes [k], det_query [k]."""
         h, w = image_size
-        Q, K = logits.shape
-        scores = logits.sigmoid()
-        cx, cy, bw, bh = boxes.unbind(-1)
         if scale is None:
             scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=boxes.device)
-        xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1) * scale
-        finite = torch.isfinite(xyxy).all(1) & torch.isfinite(scores).all(1)
-        xyxy = torch.minimum(xyxy.clamp_min(0.0), scale)          # Boxes.clip to (w, h): the limits are the device tensor `scale`
-        xyxy = torch.where(finite[:, None], xyxy, torch.zeros_like(xyxy)).contiguous()
-        st = scores.t().contiguous()                                               # [K,Q]
-        sorted_scores, order = torch.sort(st, dim=1, descending=True, stable=True)
-        valid = (sorted_scores > self.test_score_thresh) & finite[order]
-        keep = ops.nms_classes(xyxy, order.to(torch.int32).contiguous(), self.test_nms_thresh, valid.to(torch.uint8).contiguous())
-        masked = torch.where(keep.bool(), sorted_scores, torch.full_like(sorted_scores, -1.0)).reshape(-1)
-        k = min(self.test_topk_per_image, masked.numel())
-        top_scores, flat = torch.sort(masked, descending=True, stable=True)
-        top_scores, flat = top_scores[:k], flat[:k]
-        cls = torch.div(flat, Q, rounding_mode="floor")
-        qidx = order.reshape(-1)[flat]
-        return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)
+        return ops.detections(logits.float() if logits.dtype != torch.float32 else logits, boxes.float().contiguous(), scale,
+                              self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image)
 
     # ------------------------------------------------------------------ reference entry point
     @torch.no_grad()

@@ -19,11 +19,6 @@ from . import geometry as G
 from ._containers import FFN, SelfAttention, TransformerLayer
 
 
-def stable_topk(values, k):
-    """indices of the k largest values, ties by lowest index (the defined tie rule; torch.topk's is unspecified)"""
-    return torch.sort(values, descending=True, stable=True)[1][:k]
-
-
 class DeformableDetrTransformerEncoderVL(nn.Module):
     def __init__(self, embed_dim=256, num_heads=8, feedforward_dim=1024, attn_dropout=0.1, ffn_dropout=0.1, num_layers=6,
                  post_norm=False, num_feature_levels=4, vl_layer=None, use_act_checkpoint=False, pytorch_attn=False):
@@ -184,62 +179,6 @@ class DeformableDetrTransformerVL(nn.Module):
             geo._lvl_pos[key] = (geo.pos + self.level_embeds.detach().float()[geo.level_ids]).to(dt).contiguous()
         return geo._lvl_pos[key]
 
-    # ------------------------------------------------------------------ two-stage selection (:565-627)
-    def select_proposals(self, logit, boxes, geo):
-        """logit [T] fp32, boxes [T,4] xyxy in [0,1] -> topk_proposals [num_queries] int64.
-        Sync-free (fixed shapes); torch glue around the HIP NMS (ape_amd.ops.nms_segments)."""
-        dev = logit.device
-        T, L = logit.numel(), len(geo.shapes)
-        k = min(self.pre_nms_topk, T)
-        nq = self.two_stage_num_proposals
-        prob = logit.sigmoid()
-        cands = []
-        for lvl, ((H, W), start) in enumerate(zip(geo.shapes, geo.starts)):
-            n_l = H * W
-            # torch.topk(sigmoid * level_mask, k) with ties by lowest index: the level's tokens by descending score,
-            # then (levels shorter than k) the lowest-index tokens of OTHER levels, whose masked score is exactly 0
-            inl = start + stable_topk(prob[start:start + n_l], min(k, n_l))
-            if n_l < k:
-                extra = torch.arange(k - n_l, device=dev)
-                extra = torch.where(extra >= start, extra + n_l, extra)
-                inl = torch.cat([inl, extra])
-            cands.append(inl)
-        cand = torch.cat(cands)
-        n = cand.numel()
-        sc, lv, bx = logit[cand], geo.level_ids[cand], boxes[cand]
-        o1 = torch.sort(sc, descending=True, stable=True)[1]          # global descending-score order (batched_nms output order)
-        o2 = torch.sort(lv[o1], stable=True)[1]                       # level-major, score order kept inside a level
-        order = o1[o2]
-        ar = torch.arange(L, device=dev)
-        counts = (lv[None, :] == ar[:, None]).sum(1)
-        seg = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
-        # static bound on a level's segment: its own top-k plus the zero-score fillers the short levels borrow (all of
-        # which may come from one level); lets the scan kernel stage the segment's bit matrix in LDS when it fits
-        max_seg = min(n, k + sum(max(0, k - h * w) for h, w in geo.shapes))
-        keep_s = ops.nms_segments(bx[order].float().contiguous(), lv[order].to(torch.int32).contiguous(), seg, max_seg,
-                                  self.nms_thresh_enc)
-        keep1 = torch.zeros(n, dtype=torch.bool, device=dev)
-        keep1[o2] = keep_s.bool()                                     # flags in o1 (score) order
-        cand1, lv1 = cand[o1], lv[o1]
-        # "nms proposals < num_queries -> naive top-k" fallback (:600-606), selected on the device
-        alt = stable_topk(logit, min(nq, T))
-        pad = n - alt.numel()
-        cand_alt = torch.cat([alt, alt.new_zeros(pad)]) if pad > 0 else alt[:n]
-        valid_alt = torch.arange(n, device=dev) < alt.numel()
-        use_alt = keep1.sum() < nq
-        candx = torch.where(use_alt, cand_alt, cand1)
-        valid = torch.where(use_alt, valid_alt, keep1)
-        lvx = torch.where(use_alt, geo.level_ids[cand_alt], lv1)
-        is_lvl = (lvx[None, :] == ar[:, None]) & valid[None, :]
-        sel = (is_lvl & (is_lvl.cumsum(1) <= nq // L)).any(0)
-        need = nq - sel.sum()
-        notsel = valid & ~sel
-        sel = sel | (notsel & (notsel.cumsum(0) <= need))
-        slot = torch.where(sel, sel.cumsum(0) - 1, torch.full_like(candx, nq))
-        out = torch.zeros(nq + 1, dtype=torch.long, device=dev)
-        out.scatter_(0, slot, candx)
-        return out[:nq]
-
     # ------------------------------------------------------------------ forward (:422-699), batch 1
     def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None, after_encoder=None):
         """src [T,256] neck output (token-major, levels concatenated), l [1, l_dim] fp32 fusion token(s).
@@ -263,19 +202,17 @@ class DeformableDetrTransformerVL(nn.Module):
         ops.gemm(h2[:, :E], P["w3"][0], P["b3"][0], out=d[:, :4])
         ops.gemm(h2[:, E:], P["w3"][1], P["b3"][1], out=d[:, 4:])
         cls2 = ops.gemm(om, P["wcls"], P["bcls"], out_dtype=torch.float32)                       # [T, 2]
-        # ambiguous heads (:508-533): per token keep the (logit, box) pair with the larger logit (first on ties)
-        pick = cls2[:, 1] > cls2[:, 0]
-        enc_class = torch.where(pick, cls2[:, 1], cls2[:, 0])
-        enc_coord = torch.where(pick[:, None], d[:, 4:], d[:, :4]) + geo.proposals
+        # ambiguous heads (:508-533): per token keep the (logit, box) pair with the larger logit (first on ties), add the
+        # anchors, and produce the clamped corner boxes the proposal NMS works on -- one kernel (csrc/topk.hip)
+        enc_class, enc_coord, xyxy = ops.enc_finalize(cls2, d, geo.proposals)
         if stages is not None:
             stages.update(memory=memory, query_l=l_out, output_memory=om, enc_class=enc_class, enc_coord_unact=enc_coord)
         if forced_topk is not None:
             topk = forced_topk.to(om.device).long()
         else:
-            cs = enc_coord.sigmoid()
-            xyxy = torch.stack([cs[:, 0] - 0.5 * cs[:, 2], cs[:, 1] - 0.5 * cs[:, 3], cs[:, 0] + 0.5 * cs[:, 2],
-                                cs[:, 1] + 0.5 * cs[:, 3]], -1).clamp(0, 1)
-            topk = self.select_proposals(enc_class, xyxy, geo)
+            # two-stage selection (:565-627): per-level top-k, NMS 0.9, per-level quota, fallback -- fixed-shape device code
+            topk = ops.select_proposals(enc_class, xyxy, geo.shapes, self.pre_nms_topk, self.two_stage_num_proposals,
+                                        self.nms_thresh_enc)
         coords = enc_coord[topk]                                          # [Q,4] unactivated
         reference = coords.sigmoid()
         pe = G.proposal_pos_embed(coords).to(dt).contiguous()

@@ -799,3 +799,100 @@ def rle_to_string(counts):
     if rc < 0:
         raise RuntimeError("ape_hip_rle_to_string: buffer too small")
     return buf.raw[:rc]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Data-dependent selections (csrc/topk.hip): fixed shapes, no host synchronisation
+# ------------------------------------------------------------------------------------------------------------------
+def _level_arrays(level_shapes):
+    L = len(level_shapes)
+    ns = [int(h) * int(w) for h, w in level_shapes]
+    starts = [sum(ns[:i]) for i in range(L)]
+    return (ctypes.c_int * L)(*starts), (ctypes.c_int * L)(*ns), L, starts, ns
+
+
+def _f32c(t, name, shape=None):
+    if t.dtype != torch.float32 or not t.is_contiguous() or (shape is not None and tuple(t.shape) != tuple(shape)):
+        raise ValueError(f"ape_amd.ops: {name} must be contiguous float32" + (f" {tuple(shape)}" if shape is not None else ""))
+    return t
+
+
+def enc_finalize(cls2, d, anchors):
+    """two-stage heads (deformable_transformer_vl.py:503-533): cls2 [T,2] (main | ambiguous logit), d [T,8] (main | ambiguous
+    box deltas), anchors [T,4] -> (enc_class [T], enc_coord_unact [T,4], clamped xyxy of sigmoid(enc_coord) [T,4])"""
+    _dev(cls2, d, anchors)
+    T = cls2.shape[0]
+    _f32c(cls2, "cls2", (T, 2)), _f32c(d, "d", (T, 8)), _f32c(anchors, "anchors", (T, 4))
+    enc_class = torch.empty((T,), dtype=torch.float32, device=cls2.device)
+    enc_coord = torch.empty((T, 4), dtype=torch.float32, device=cls2.device)
+    xyxy = torch.empty((T, 4), dtype=torch.float32, device=cls2.device)
+    rc = _lib.load().ape_hip_enc_finalize(_p(cls2), _p(d), _p(anchors), T, _p(enc_class), _p(enc_coord), _p(xyxy), _stream())
+    _lib.check(rc, "ape_hip_enc_finalize")
+    return enc_class, enc_coord, xyxy
+
+
+def select_proposals(logit, xyxy, level_shapes, pre_nms_topk, num_queries, iou_thr):
+    """two-stage proposal selection (deformable_transformer_vl.py:565-627): per-level top-k of sigmoid(logit) (ties: lowest
+    index), per-level NMS, per-level quota + fill-up, "naive top-k" fallback -> topk_proposals [num_queries] int64.
+    logit [T] fp32, xyxy [T,4] fp32 in [0,1]; five launches, no host synchronisation."""
+    _dev(logit, xyxy)
+    T = logit.numel()
+    _f32c(logit, "logit", (T,)), _f32c(xyxy, "xyxy", (T, 4))
+    starts_c, ns_c, L, starts, ns = _level_arrays(level_shapes)
+    if sum(ns) != T:
+        raise ValueError("ape_amd.ops.select_proposals: level shapes do not add up to the token count")
+    k, k_alt = min(int(pre_nms_topk), T), min(int(num_queries), T)
+    n = L * k
+    dev = logit.device
+    lib = _lib.load()
+    cand = torch.empty((n,), dtype=torch.int32, device=dev)
+    alt = torch.empty((k_alt,), dtype=torch.int32, device=dev)
+    _lib.check(lib.ape_hip_proposal_topk(_p(logit), T, starts_c, ns_c, L, k, k_alt, _p(cand), _p(alt), _stream()), "ape_hip_proposal_topk")
+    boxes_b = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    ints = torch.empty((4 * n + L + 1,), dtype=torch.int32, device=dev)
+    groups_b, cand_a, lv_a, pos_b, seg = ints[:n], ints[n:2 * n], ints[2 * n:3 * n], ints[3 * n:4 * n], ints[4 * n:]
+    rc = lib.ape_hip_proposal_order(_p(cand), n, _p(logit), _p(xyxy), starts_c, ns_c, L, _p(boxes_b), _p(groups_b), _p(seg), _p(cand_a),
+                                    _p(lv_a), _p(pos_b), _stream())
+    _lib.check(rc, "ape_hip_proposal_order")
+    # static bound on a level's segment: its own top-k plus the zero-score fillers the short levels borrow (all of which may
+    # come from one level); lets the scan kernel stage the segment's bit matrix in LDS when it fits
+    max_seg = min(n, k + sum(max(0, k - m) for m in ns))
+    mask = torch.empty((n, lib.ape_hip_nms_mask_words(n)), dtype=torch.int64, device=dev)
+    keep = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    _lib.check(lib.ape_hip_nms_mask(_p(boxes_b), _p(groups_b), n, float(iou_thr), _p(mask), _stream()), "ape_hip_nms_mask")
+    _lib.check(lib.ape_hip_nms_scan_segments(_p(mask), n, _p(seg), L, int(max_seg), None, _p(keep), _stream()), "ape_hip_nms_scan_segments")
+    out = torch.empty((int(num_queries),), dtype=torch.int64, device=dev)
+    rc = lib.ape_hip_proposal_quota(_p(cand_a), _p(lv_a), _p(pos_b), _p(keep), n, _p(alt), k_alt, starts_c, ns_c, L, int(num_queries),
+                                    _p(out), _stream())
+    _lib.check(rc, "ape_hip_proposal_quota")
+    return out
+
+
+def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
+    """fast_rcnn_inference_single_image (ape_deta/fast_rcnn.py:97-201) on class-agnostic boxes: logits [Q,K] fp32 (row-major
+    view), boxes [Q,4] cxcywh in [0,1], scale [4] device (w,h,w,h) -> dict(det_boxes [k,4], det_scores [k] (-1 = empty slot),
+    det_classes [k] int64, det_query [k] int64).  Four launches."""
+    _dev(logits, boxes, scale)
+    _rowmajor(logits, "logits")
+    Q, K = logits.shape
+    if logits.dtype != torch.float32:
+        raise TypeError("ape_amd.ops.detections: logits must be float32")
+    _f32c(boxes, "boxes", (Q, 4)), _f32c(scale, "scale", (4,))
+    dev = logits.device
+    lib = _lib.load()
+    xyxy = torch.empty((Q, 4), dtype=torch.float32, device=dev)
+    finite = torch.empty((Q,), dtype=torch.uint8, device=dev)
+    sorted_scores = torch.empty((K, Q), dtype=torch.float32, device=dev)
+    order = torch.empty((K, Q), dtype=torch.int32, device=dev)
+    valid = torch.empty((K, Q), dtype=torch.uint8, device=dev)
+    rc = lib.ape_hip_det_sort(_p(logits), _ld(logits), Q, K, _p(boxes), _p(scale), float(score_thresh), _p(xyxy), _p(finite),
+                              _p(sorted_scores), _p(order), _p(valid), _stream())
+    _lib.check(rc, "ape_hip_det_sort")
+    keep = nms_classes(xyxy, order, iou_thr, valid)
+    k = min(int(topk), K * Q)
+    det = dict(det_boxes=torch.empty((k, 4), dtype=torch.float32, device=dev), det_scores=torch.empty((k,), dtype=torch.float32, device=dev),
+               det_classes=torch.empty((k,), dtype=torch.int64, device=dev), det_query=torch.empty((k,), dtype=torch.int64, device=dev))
+    rc = lib.ape_hip_det_topk(_p(sorted_scores), _p(keep), _p(order), _p(xyxy), K, Q, k, _p(det["det_boxes"]), _p(det["det_scores"]),
+                              _p(det["det_classes"]), _p(det["det_query"]), _stream())
+    _lib.check(rc, "ape_hip_det_topk")
+    return det

@@ -348,6 +348,45 @@ int ape_hip_rle_to_string(const uint32_t* counts, int n, char* out, int cap);
 int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* table, int ldtab, const void* pos, int ldpos, int dt, float* out,
                          int ldo, int B, int L, int Lp, int W, int vocab, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data-dependent selections as fixed-shape device code -- csrc/topk.hip.  One 1024-thread workgroup per selection problem:
+ * radix select over order-preserving keys + stable compaction (ties: lowest index) + bitonic sort in LDS.
+ *
+ * Encoder proposals (ape/modeling/ape_deta/deformable_transformer_vl.py:503-533, 565-627); level l owns tokens
+ * level_start[l] .. +level_n[l] (HOST int arrays, L <= 5):
+ *   enc_finalize   : per token the (logit, box delta) pair of the larger logit of the two head copies (first on ties), + anchors
+ *                    -> enc_class [T], enc_coord [T,4] (unactivated), xyxy [T,4] = clamp(corners(sigmoid(enc_coord)), 0, 1)
+ *   proposal_topk  : cand [L*k]: per level the top k of sigmoid(logit) * level mask over ALL T tokens (ties: lowest index;
+ *                    a level with fewer than k tokens continues with the lowest-index tokens of the other levels, whose
+ *                    masked score is 0); alt [k_alt]: top k_alt of the raw logits over all tokens (the :600-606 fallback)
+ *   proposal_order : the n = L*k candidates by descending logit (stable) = "A order": cand_a, lv_a (token's level), pos_b =
+ *                    position in the level-major "B order"; boxes_b / groups_b / seg [L+1] are the NMS segments in B order
+ *                    (feed ape_hip_nms_mask + ape_hip_nms_scan_segments)
+ *   proposal_quota : keep_b = NMS survivors in B order -> out [nq] int64: per level the first nq / L survivors in A order,
+ *                    then the best of the rest; with fewer than nq survivors the first n_alt entries of alt take the
+ *                    candidates' place; zero padded
+ * Final detections (ape/modeling/ape_deta/fast_rcnn.py:97-201, deformable_detr_segm_vl.py:759-810):
+ *   det_sort       : logits [Q, ldl] (K classes), boxes [Q,4] cxcywh, scale [4] device (w,h,w,h) -> xyxy [Q,4] scaled + clipped
+ *                    (zero rows where box or scores are not finite), finite [Q]; per class the queries by descending sigmoid
+ *                    score (stable): sorted [K,Q], order [K,Q] int32, valid [K,Q] = score > thresh & finite.  Q <= 1024.
+ *   det_topk       : keep [K,Q] = class-wise NMS survivors in visiting order (ape_hip_nms_scan_classes) -> the k best
+ *                    (score, class, query, box); suppressed pairs rank as score -1 (ties: lowest (class, rank))
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_enc_finalize(const float* cls2, const float* d, const float* anchors, int T, float* enc_class, float* enc_coord,
+                         float* xyxy, void* stream);
+int ape_hip_proposal_topk(const float* logit, int T, const int* level_start, const int* level_n, int L, int k, int k_alt,
+                          int32_t* cand, int32_t* alt, void* stream);
+int ape_hip_proposal_order(const int32_t* cand, int n, const float* logit, const float* xyxy, const int* level_start,
+                           const int* level_n, int L, float* boxes_b, int32_t* groups_b, int32_t* seg, int32_t* cand_a,
+                           int32_t* lv_a, int32_t* pos_b, void* stream);
+int ape_hip_proposal_quota(const int32_t* cand_a, const int32_t* lv_a, const int32_t* pos_b, const uint8_t* keep_b, int n,
+                           const int32_t* alt, int n_alt, const int* level_start, const int* level_n, int L, int nq, int64_t* out,
+                           void* stream);
+int ape_hip_det_sort(const float* logits, int ldl, int Q, int K, const float* boxes, const float* scale, float thresh, float* xyxy,
+                     uint8_t* finite, float* sorted, int32_t* order, uint8_t* valid, void* stream);
+int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* order, const float* xyxy, int K, int Q, int k,
+                     float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

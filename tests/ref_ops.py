@@ -422,3 +422,92 @@ def rle_encode(masks, cap=4096, counts=None, nruns=None):
 def rle_to_string(counts):
     from oracle import imageio as O
     return O.rle_to_string([int(c) & 0xFFFFFFFF for c in (counts.tolist() if hasattr(counts, "tolist") else counts)])
+
+
+# ------------------------------------------------------------------------------------------------
+# data-dependent selections: tensor-level definitions (the sort / cumsum formulation the reference's code amounts to, with the
+# defined tie rule: equal scores -> lowest index)
+# ------------------------------------------------------------------------------------------------
+def _stable_topk(values, k):
+    return torch.sort(values, descending=True, stable=True)[1][:k]
+
+
+def enc_finalize(cls2, d, anchors):
+    pick = cls2[:, 1] > cls2[:, 0]
+    enc_class = torch.where(pick, cls2[:, 1], cls2[:, 0])
+    enc_coord = torch.where(pick[:, None], d[:, 4:], d[:, :4]) + anchors
+    cs = enc_coord.sigmoid()
+    xyxy = torch.stack([cs[:, 0] - 0.5 * cs[:, 2], cs[:, 1] - 0.5 * cs[:, 3], cs[:, 0] + 0.5 * cs[:, 2],
+                        cs[:, 1] + 0.5 * cs[:, 3]], -1).clamp(0, 1)
+    return enc_class, enc_coord, xyxy.contiguous()
+
+
+def select_proposals(logit, xyxy, level_shapes, pre_nms_topk, num_queries, iou_thr):
+    dev = logit.device
+    T, L = logit.numel(), len(level_shapes)
+    ns = [h * w for h, w in level_shapes]
+    starts = [sum(ns[:i]) for i in range(L)]
+    level_ids = torch.cat([torch.full((m,), i, dtype=torch.long) for i, m in enumerate(ns)]).to(dev)
+    k = min(pre_nms_topk, T)
+    nq = num_queries
+    prob = logit.sigmoid()
+    cands = []
+    for n_l, start in zip(ns, starts):
+        inl = start + _stable_topk(prob[start:start + n_l], min(k, n_l))
+        if n_l < k:
+            extra = torch.arange(k - n_l, device=dev)
+            extra = torch.where(extra >= start, extra + n_l, extra)
+            inl = torch.cat([inl, extra])
+        cands.append(inl)
+    cand = torch.cat(cands)
+    n = cand.numel()
+    sc, lv, bx = logit[cand], level_ids[cand], xyxy[cand]
+    o1 = torch.sort(sc, descending=True, stable=True)[1]
+    o2 = torch.sort(lv[o1], stable=True)[1]
+    order = o1[o2]
+    ar = torch.arange(L, device=dev)
+    counts = (lv[None, :] == ar[:, None]).sum(1)
+    seg = torch.cat([counts.new_zeros(1), counts.cumsum(0)]).to(torch.int32)
+    max_seg = min(n, k + sum(max(0, k - m) for m in ns))
+    keep_s = nms_segments(bx[order].float().contiguous(), lv[order].to(torch.int32).contiguous(), seg, max_seg, iou_thr)
+    keep1 = torch.zeros(n, dtype=torch.bool, device=dev)
+    keep1[o2] = keep_s.bool()
+    cand1, lv1 = cand[o1], lv[o1]
+    alt = _stable_topk(logit, min(nq, T))
+    pad = n - alt.numel()
+    cand_alt = torch.cat([alt, alt.new_zeros(pad)]) if pad > 0 else alt[:n]
+    valid_alt = torch.arange(n, device=dev) < alt.numel()
+    use_alt = keep1.sum() < nq
+    candx = torch.where(use_alt, cand_alt, cand1)
+    valid = torch.where(use_alt, valid_alt, keep1)
+    lvx = torch.where(use_alt, level_ids[cand_alt], lv1)
+    is_lvl = (lvx[None, :] == ar[:, None]) & valid[None, :]
+    sel = (is_lvl & (is_lvl.cumsum(1) <= nq // L)).any(0)
+    need = nq - sel.sum()
+    notsel = valid & ~sel
+    sel = sel | (notsel & (notsel.cumsum(0) <= need))
+    slot = torch.where(sel, sel.cumsum(0) - 1, torch.full_like(candx, nq))
+    out = torch.zeros(nq + 1, dtype=torch.long, device=dev)
+    out.scatter_(0, slot, candx)
+    return out[:nq]
+
+
+def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
+    Q, K = logits.shape
+    scores = logits.sigmoid()
+    cx, cy, bw, bh = boxes.unbind(-1)
+    xyxy = torch.stack([cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh], -1) * scale
+    finite = torch.isfinite(xyxy).all(1) & torch.isfinite(scores).all(1)
+    xyxy = torch.minimum(xyxy.clamp_min(0.0), scale)
+    xyxy = torch.where(finite[:, None], xyxy, torch.zeros_like(xyxy)).contiguous()
+    st = scores.t().contiguous()
+    sorted_scores, order = torch.sort(st, dim=1, descending=True, stable=True)
+    valid = (sorted_scores > score_thresh) & finite[order]
+    keep = nms_classes(xyxy, order.to(torch.int32).contiguous(), iou_thr, valid.to(torch.uint8).contiguous())
+    masked = torch.where(keep.bool(), sorted_scores, torch.full_like(sorted_scores, -1.0)).reshape(-1)
+    k = min(topk, masked.numel())
+    top_scores, flat = torch.sort(masked, descending=True, stable=True)
+    top_scores, flat = top_scores[:k], flat[:k]
+    cls = torch.div(flat, Q, rounding_mode="floor")
+    qidx = order.reshape(-1)[flat]
+    return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)

@@ -623,3 +623,74 @@ def test_geometry_kernel(ops, dt):
         e_use = (got[usable] - lp.float()[usable]).abs().max().item()
         print(f"geometry kernel {dt} {h}x{w}: lvl_pos max abs diff usable {e_use:.2e} all {e_all:.2e}")
         assert e_use <= (1e-6 if dt == torch.float32 else 8e-3), (h, w, e_use)
+
+
+# ------------------------------------------------------------------------------------------------
+# data-dependent selections (csrc/topk.hip) vs their sort / cumsum definitions: index outputs must be IDENTICAL
+# ------------------------------------------------------------------------------------------------
+def _qlogits(n, seed, lo=-8.0, hi=6.0, step=1 / 64):
+    """logits on a grid coarse enough that distinct logits have distinct float32 sigmoids (no ulp-level ambiguity between two
+    correct sigmoid implementations), with plenty of exact ties"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randint(int(lo / step), int(hi / step), (n,), generator=g).float() * step).to(DEV)
+
+
+def test_enc_finalize(ops):
+    T = 5000
+    g = torch.Generator(device="cpu").manual_seed(0)
+    cls2 = torch.randint(-20, 20, (T, 2), generator=g).float().div(4).to(DEV)            # ties between the two heads
+    d = rnd(T, 8, seed=1)
+    anchors = rnd(T, 4, seed=2, scale=2.0)
+    anchors[::7] = float("inf")
+    ec, eb, xy = ops.enc_finalize(cls2.contiguous(), d.contiguous(), anchors.contiguous())
+    rc, rb, rxy = ref_ops.enc_finalize(cls2, d, anchors)
+    assert torch.equal(ec, rc) and torch.equal(eb, rb)
+    assert (xy - rxy).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("shapes,k,nq,mode", [
+    ([(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)], 1000, 900, "random"),
+    ([(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)], 1000, 900, "ties"),
+    ([(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)], 1000, 900, "fallback"),
+    ([(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], 1000, 900, "random"),
+    ([(32, 32), (16, 16), (8, 8), (4, 4), (2, 2)], 1000, 300, "ties"),
+    ([(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], 1000, 100, "random"),
+    ([(40, 27), (20, 14), (10, 7)], 300, 90, "random"),
+])
+def test_select_proposals(ops, shapes, k, nq, mode):
+    T = sum(h * w for h, w in shapes)
+    logit = _qlogits(T, 3, step=1 / 64 if mode != "ties" else 1.0)
+    g = torch.Generator(device="cpu").manual_seed(4)
+    c = torch.rand(T, 2, generator=g)
+    wh = torch.rand(T, 2, generator=g) * (0.3 if mode != "fallback" else 0.0) + (0.02 if mode != "fallback" else 0.9)
+    if mode == "fallback":
+        c = c * 0.01 + 0.5                                   # near-identical boxes: NMS keeps a handful, the naive top-k takes over
+    xyxy = torch.cat([c - wh / 2, c + wh / 2], 1).clamp(0, 1).to(DEV).contiguous()
+    got = ops.select_proposals(logit, xyxy, shapes, k, nq, 0.9)
+    ref = ref_ops.select_proposals(logit, xyxy, shapes, k, nq, 0.9)
+    assert got.dtype == torch.int64 and got.shape == (nq,)
+    assert torch.equal(got.cpu(), ref.cpu()), f"{(got.cpu() != ref.cpu()).sum().item()} of {nq} proposals differ"
+
+
+@pytest.mark.parametrize("Q,K,topk", [(900, 80, 100), (900, 1203, 300), (900, 1, 1), (300, 7, 500), (1024, 3, 100)])
+def test_detections(ops, Q, K, topk):
+    g = torch.Generator(device="cpu").manual_seed(5)
+    logits = (torch.randint(-600, 200, (Q, K), generator=g).float() / 64).to(DEV)
+    if K > 2:
+        logits[:, 1] = float("-inf")                         # a class switched off (evaluation-dataset mode)
+    if Q > 10:
+        logits[5, 0] = float("nan")                          # a non-finite row is dropped entirely (fast_rcnn.py:132-137)
+    c = torch.rand(Q, 2, generator=g)
+    wh = torch.rand(Q, 2, generator=g) * 0.4 + 0.02
+    boxes = torch.cat([c, wh], 1).to(DEV).contiguous()
+    if Q > 10:
+        boxes[7, 2] = float("inf")
+    scale = torch.tensor([1024.0, 683.0, 1024.0, 683.0], device=DEV)
+    got = ops.detections(logits, boxes, scale, 0.0, 0.7, topk)
+    ref = ref_ops.detections(logits, boxes, scale, 0.0, 0.7, topk)
+    k = min(topk, Q * K)
+    assert got["det_scores"].shape == (k,)
+    assert torch.equal(got["det_query"].cpu(), ref["det_query"].cpu())
+    assert torch.equal(got["det_classes"].cpu(), ref["det_classes"].cpu())
+    assert (got["det_scores"] - ref["det_scores"]).abs().max().item() < 1e-6
+    assert (got["det_boxes"] - ref["det_boxes"]).abs().max().item() < 1e-3
