@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libape_hip.so")
 
 DT_F32 = 0
 DT_BF16 = 1
+DT_F16 = 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SWIGLU, ACT_SILU = 0, 1, 2, 3, 4
 MASK_NONE, MASK_ZERO_INPUT, MASK_ZERO_OUTPUT = 0, 1, 2
 
@@ -67,6 +68,8 @@ SIGNATURES = {
                                                c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ape_hip_msda_fused": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), c_void_p, c_int, c_void_p,
                                    c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ape_hip_msda_fused_h": (c_int, [c_void_p, c_int, c_int, POINTER(c_int64), POINTER(c_int64), c_void_p, c_int, c_void_p,
+                                     c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ape_hip_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                   c_int, c_float, c_int, c_void_p]),
     "ape_hip_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int, c_void_p, c_float, c_float, c_float,

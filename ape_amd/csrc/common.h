@@ -80,6 +80,20 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v
                                             pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }
 
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// round-to-nearest-even pair conversion (same rule as torch's float -> half cast)
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+template <> __device__ __forceinline__ void ld4<f16_t>(const f16_t* p, float v[4]) {
+  const uint2 t = *reinterpret_cast<const uint2*>(p);
+  const f16x2_t a = __builtin_bit_cast(f16x2_t, t.x), b = __builtin_bit_cast(f16x2_t, t.y);
+  v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
+}
+template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, const float v[4]) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+}
 template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float v[8]) {
   f16x8_t t;
 #pragma unroll

@@ -650,7 +650,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int RES /*0 none, 1 bf16 (2 = f32: compiles, spills, not instantiated)*/, bool OUT_F32>
+template <int RES /*0 none, 1 bf16 (2 = f32: compiles, spills, not instantiated)*/, bool OUT_F32, bool OUT_F16 = false /* 2-byte output is IEEE half */>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem_raw);                     // 4 stages x [128][64] bf16 (swz128 image)
@@ -817,6 +817,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
         if (OUT_F32) {
           *reinterpret_cast<float4*>(cp + jp * 32) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
           *reinterpret_cast<float4*>(cp + jp * 32 + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+        } else if (OUT_F16) {
+          *reinterpret_cast<uint4*>(cp + jp * 16) = make_uint4(pack2h(v[0][0], v[0][1]), pack2h(v[0][2], v[0][3]),
+                                                               pack2h(v[1][0], v[1][1]), pack2h(v[1][2], v[1][3]));
         } else {
           *reinterpret_cast<uint4*>(cp + jp * 16) = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]),
                                                                pack2bf(v[1][0], v[1][1]), pack2bf(v[1][2], v[1][3]));
@@ -839,6 +842,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
         float v[4];
         finish(std::integral_constant<int, 2>{}, acc[mi][j], b, rv, mi, v);
         if (OUT_F32) st4<float>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
+        else if (OUT_F16) st4<f16_t>(reinterpret_cast<f16_t*>(p.C) + (size_t)m * p.ldc + n, v);
         else st4<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, v);
       }
   };
@@ -898,6 +902,13 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(p.A && p.W && p.C, "ape_hip_gemm: null pointer");
   APE_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "ape_hip_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   APE_CHECK_ARG(p.in_dt == APE_DT_F32 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: bad in_dt %d", p.in_dt);
+  APE_CHECK_ARG(p.out_dt == APE_DT_F32 || p.out_dt == APE_DT_BF16 || p.out_dt == APE_DT_F16, "ape_hip_gemm: bad out_dt %d", p.out_dt);
+  // IEEE-half output exists for one kernel: the K = 256 register-resident GEMM without residual (the deformable attention's
+  // offset / logit projection over the encoder tokens, which is bound by the bytes it writes)
+  APE_CHECK_ARG(p.out_dt != APE_DT_F16 || (p.in_dt == APE_DT_BF16 && p.K == 256 && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
+                                           p.residual == nullptr && p.rowscale == nullptr && p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr &&
+                                           p.splitk <= 1 && p.ldc % 8 == 0 && ((uintptr_t)p.C) % 16 == 0 && p.tile64 != 3 && p.tile64 != 4),
+                "ape_hip_gemm: f16 output needs bf16 inputs, K == 256, M >= 2048, N %% 8 == 0, no residual / transpose / rope / split-K");
   APE_CHECK_ARG(p.act != APE_ACT_SWIGLU || (p.N % 4 == 0 && !p.trans_out), "ape_hip_gemm: swiglu needs N%%4==0, no transpose");
   APE_CHECK_ARG(!p.trans_out || (p.residual == nullptr && p.rope_cos == nullptr && p.rowmask == nullptr),
                 "ape_hip_gemm: transposed output supports bias/act only");
@@ -947,6 +958,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
       }
       p.tile64 = 0;
     }
+    APE_CHECK_ARG(v2_ok || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output needs 16-byte aligned output rows");
     if (v2_ok) {
       static bool attr_done = false;
       if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
@@ -963,6 +975,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
       const bool kres = !no_kres && !no_glds && p.K == 256 && p.rowscale == nullptr && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
                         p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr && p.splitk <= 1 && p.ldc % 8 == 0 &&
                         (p.residual == nullptr || (p.res_dt == APE_DT_BF16 && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
+      APE_CHECK_ARG(kres || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output is only produced by the K == 256 kernel (disabled by the environment?)");
       if (kres) {
         static bool kattr = false;
         if (!kattr) {
@@ -970,6 +983,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
           (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
           (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
           (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
           kattr = true;
         }
         const int mblk = ceil_div(p.M, KR_BM);
@@ -979,7 +993,8 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
         const dim3 grid(mblk, ysplit);
         const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
         const bool of32 = p.out_dt == APE_DT_F32;
-        if (!res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false>", (gemm_bf16_kres_kernel<0, false>), grid, KR_LDS);
+        if (p.out_dt == APE_DT_F16) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false, true>", (gemm_bf16_kres_kernel<0, false, true>), grid, KR_LDS);
+        else if (!res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false>", (gemm_bf16_kres_kernel<0, false>), grid, KR_LDS);
         else if (res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<1, false>", (gemm_bf16_kres_kernel<1, false>), grid, KR_LDS);
         else if (!res) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, true>", (gemm_bf16_kres_kernel<0, true>), grid, KR_LDS);
         else LAUNCH_GEMM("gemm_bf16_kres_kernel<1, true>", (gemm_bf16_kres_kernel<1, true>), grid, KR_LDS);

@@ -22,7 +22,8 @@ struct MsdaParams {
   const void* value; int ldv;
   const void* loc;      // plain: [Q, M, L, P, 2]
   const void* attn;     // plain: [Q, M, L, P]
-  const float* offw; int ldoffw;   // fused
+  const void* offw; int ldoffw;    // fused: fp32, or f16 with offw_f16 (the offset / logit GEMM writes half the bytes)
+  int offw_f16;
   const float* ref; int refdim;    // fused
   void* out; int ldout;
   int S, Q;             // per batch element
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void msda_kernel(const MsdaParams p) {
   constexpr int LP = L * MS_P;
   if (FUSED) {
     // logits + softmax over the L*P samples of this (query, head)
-    const float* lg = p.offw + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
+    const float* lg = reinterpret_cast<const float*>(p.offw) + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
     float w[LP];
     float mx = -INFINITY;
 #pragma unroll
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void msda_kernel(const MsdaParams p) {
 #pragma unroll
     for (int s = 0; s < LP; ++s) { w[s] = expf(w[s] - mx); sum += w[s]; }
     const float inv = 1.f / sum;
-    const float* of = p.offw + qg * p.ldoffw + h * LP * 2;
+    const float* of = reinterpret_cast<const float*>(p.offw) + qg * p.ldoffw + h * LP * 2;
     const float* rf = p.ref + qg * L * p.refdim;
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -204,7 +205,7 @@ __device__ __forceinline__ void group_fma(const CornerGroup<TV>& g, f32x2_t (&a2
   for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(a2[e]));   // ... and the FMAs may not sink below it
 }
 
-template <typename TV, typename TO, int L>
+template <typename TV, typename TO, int L, typename TW = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void msda_fused_quad_kernel(const MsdaParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -226,11 +227,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   constexpr int LP = L * MS_P;
 
   // ---- phase 1: this lane's samples (point `sub` of every level)
-  const float* lg = p.offw + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
+  const TW* lg = reinterpret_cast<const TW*>(p.offw) + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
   float wv[L];
   float mx = -INFINITY;
 #pragma unroll
-  for (int l = 0; l < L; ++l) { wv[l] = lg[l * MS_P + sub]; mx = fmaxf(mx, wv[l]); }
+  for (int l = 0; l < L; ++l) { wv[l] = ldf<TW>(lg + l * MS_P + sub); mx = fmaxf(mx, wv[l]); }
   mx = fmaxf(mx, quad_xor1(mx));
   mx = fmaxf(mx, quad_xor2(mx));
   float sum = 0.f;
@@ -239,14 +240,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   sum += quad_xor1(sum);
   sum += quad_xor2(sum);
   const float inv = 1.f / sum;
-  const float* of = p.offw + qg * p.ldoffw + h * LP * 2 + sub * 2;
+  const TW* of = reinterpret_cast<const TW*>(p.offw) + qg * p.ldoffw + h * LP * 2 + sub * 2;
   const float* rf = p.ref + qg * L * p.refdim;
   float cw[L][4];
   int ci[L][4];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
     const int H = p.H[l], W = p.W[l];
-    const float2 o = *reinterpret_cast<const float2*>(of + l * 8);
+    float2 o;
+    if (sizeof(TW) == 4) {
+      o = *reinterpret_cast<const float2*>(of + l * 8);
+    } else {
+      typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+      const h2_t t = *reinterpret_cast<const h2_t*>(of + l * 8);
+      o = make_float2((float)t[0], (float)t[1]);
+    }
     const float rx = rf[l * p.refdim], ry = rf[l * p.refdim + 1];
     float lx, ly;
     if (p.refdim == 2) {                       // loc = ref + off / (W, H)            (multi_scale_deform_attn.py:298-303)
@@ -318,6 +326,16 @@ template <typename TV, typename TO, bool FUSED>
 static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
   const dim3 grid(ceil_div(p.Q, 8), B), block(256);
   if constexpr (FUSED) {
+    if (p.offw_f16) {
+      switch (L) {
+        case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1, f16_t>), grid, block, 0, s, p); return 0;
+        case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2, f16_t>), grid, block, 0, s, p); return 0;
+        case 3: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 3, f16_t>), grid, block, 0, s, p); return 0;
+        case 4: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 4, f16_t>), grid, block, 0, s, p); return 0;
+        case 5: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 5, f16_t>), grid, block, 0, s, p); return 0;
+        default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
+      }
+    }
     switch (L) {
       case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1>), grid, block, 0, s, p); return 0;
       case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2>), grid, block, 0, s, p); return 0;
@@ -376,9 +394,9 @@ extern "C" int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const 
   return 0;
 }
 
-extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
-                                  const int64_t* level_start_index, const float* offw, int ldoffw, const float* ref,
-                                  int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream) {
+static int msda_fused_launch(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                             const void* offw, int ldoffw, int offw_f16, const float* ref, int refdim, void* out, int ldout, int out_dt,
+                             int B, int S, int Q, int L, void* stream) {
   APE_CHECK_ARG(value && spatial_shapes && level_start_index && offw && ref && out, "msda_fused: null pointer");
   APE_CHECK_ARG(refdim == 2 || refdim == 4, "msda_fused: reference points must have 2 or 4 coordinates, got %d", refdim);
   APE_CHECK_ARG(B > 0 && S > 0 && Q > 0, "msda_fused: bad sizes");
@@ -387,7 +405,7 @@ extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const in
                 "msda_fused: alignment (value/out 16 B, ld %% 8; offw 16 B, ld %% 4)");
   MsdaParams p;
   memset(&p, 0, sizeof(p));
-  p.value = value; p.ldv = ldv; p.offw = offw; p.ldoffw = ldoffw; p.ref = ref; p.refdim = refdim;
+  p.value = value; p.ldv = ldv; p.offw = offw; p.ldoffw = ldoffw; p.offw_f16 = offw_f16; p.ref = ref; p.refdim = refdim;
   p.out = out; p.ldout = ldout; p.S = S; p.Q = Q;
   if (fill_levels(p, spatial_shapes, level_start_index, L, S)) return -1;
   int rc;
@@ -399,4 +417,20 @@ extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const in
   if (rc) return rc;
   APE_CHECK_LAUNCH("ape_hip_msda_fused");
   return 0;
+}
+
+extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
+                                  const int64_t* level_start_index, const float* offw, int ldoffw, const float* ref,
+                                  int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream) {
+  return msda_fused_launch(value, ldv, v_dt, spatial_shapes, level_start_index, offw, ldoffw, 0, ref, refdim, out, ldout, out_dt, B, S, Q, L,
+                           stream);
+}
+
+// offsets | logits stored as IEEE half (the K = 256 GEMM that produces them is bound by the bytes it writes)
+extern "C" int ape_hip_msda_fused_h(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
+                                    const int64_t* level_start_index, const void* offw_f16, int ldoffw, const float* ref,
+                                    int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream) {
+  APE_CHECK_ARG(v_dt == APE_DT_BF16, "msda_fused_h: bf16 values (the production mode)");
+  return msda_fused_launch(value, ldv, v_dt, spatial_shapes, level_start_index, offw_f16, ldoffw, 1, ref, refdim, out, ldout, out_dt, B, S, Q,
+                           L, stream);
 }

@@ -5,6 +5,8 @@ constructor kwargs, parameter names and forward signature), function `multi_scal
 (:84-124) and the operator `torch.ops.ape.ms_deform_attn_forward` (ape/layers/csrc/vision.cpp:76-79), all backed by
 csrc/msda.hip through the C-ABI.  `pytorch_attn` is accepted and ignored: there is one path, the HIP one.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -78,7 +80,11 @@ class MultiScaleDeformableAttention(nn.Module):
         P = self.packed(dt)
         if value is None:
             value = ops.gemm(value_src, P["wval"], P["bval"], rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT)
-        offw = ops.gemm(query_pos_sum, P["woffw"], P["boffw"], out_dtype=torch.float32)
+        # offsets | logits: fp32 in validation mode and for the decoder's 900 queries; IEEE half for the encoder's 87 k tokens in
+        # production mode -- that GEMM is bound by the bytes it writes (168 MB per layer in fp32) and the sampler reads them
+        # back; half keeps 11 significant bits (offsets are a few pixels, logits feed a 20-way softmax)
+        half = dt == torch.bfloat16 and query_pos_sum.shape[0] >= 2048 and os.environ.get("APE_MSDA_F32_OFFSETS") != "1"
+        offw = ops.gemm(query_pos_sum, P["woffw"], P["boffw"], out_dtype=torch.float16 if half else torch.float32)
         samp = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=dt)
         return ops.gemm(samp, P["wout"], P["bout"], residual=identity, out_dtype=out_dtype or dt)
 

@@ -119,7 +119,8 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     args.bias = _f32vec(bias, "bias").data_ptr() if bias is not None else None
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldw, args.ldc = _ld(a), _ld(w), _ld(out)
-    args.in_dt, args.out_dt = _dt(a), _dt(out)
+    # IEEE-half output: one kernel produces it (K = 256, >= 2048 rows, no residual) -- the launcher checks
+    args.in_dt, args.out_dt = _dt(a), (_lib.DT_F16 if out.dtype == torch.float16 else _dt(out))
     if residual is not None:
         _rowmajor(residual, "residual")
         args.residual, args.ldr, args.res_dt = residual.data_ptr(), _ld(residual), _dt(residual)
@@ -303,13 +304,13 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, out_dtype=None, out=None):
     """Fused softmax + sampling-location + bilinear gather (multi_scale_deform_attn.py:278-348).
 
-    value [batch*S, >=256] (row-major view), offw [batch*Q, 8*L*4*3] fp32 (offsets then logits),
+    value [batch*S, >=256] (row-major view), offw [batch*Q, 8*L*4*3] fp32 or (bf16 values only) fp16 (offsets then logits),
     ref [batch*Q, L, 2|4] fp32 -> [batch*Q, 256].
     """
     _dev(value, offw, ref, out)
     _rowmajor(value, "value"), _rowmajor(offw, "offw")
-    if offw.dtype != torch.float32 or ref.dtype != torch.float32 or not ref.is_contiguous():
-        raise TypeError("ape_amd.ops.msda_fused: offw / ref must be float32 (ref contiguous)")
+    if offw.dtype not in (torch.float32, torch.float16) or ref.dtype != torch.float32 or not ref.is_contiguous():
+        raise TypeError("ape_amd.ops.msda_fused: offw must be float32 / float16, ref contiguous float32")
     shp, st, L = _levels(spatial_shapes, level_start_index)
     S = value.shape[0] // batch
     Q = offw.shape[0] // batch
@@ -317,8 +318,9 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
         raise ValueError("ape_amd.ops.msda_fused: offw/ref shape mismatch")
     if out is None:
         out = torch.empty((batch * Q, 256), dtype=out_dtype or value.dtype, device=value.device)
-    rc = _lib.load().ape_hip_msda_fused(_p(value), _ld(value), _dt(value), shp, st, _p(offw), _ld(offw), _p(ref),
-                                       ref.shape[-1], _p(out), _ld(out), _dt(out), batch, S, Q, L, _stream())
+    fn = _lib.load().ape_hip_msda_fused_h if offw.dtype == torch.float16 else _lib.load().ape_hip_msda_fused
+    rc = fn(_p(value), _ld(value), _dt(value), shp, st, _p(offw), _ld(offw), _p(ref), ref.shape[-1], _p(out), _ld(out), _dt(out),
+            batch, S, Q, L, _stream())
     _lib.check(rc, "ape_hip_msda_fused")
     return out
 

@@ -168,6 +168,11 @@ int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const int64_t* sp
 int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
                        const int64_t* level_start_index, const float* offw, int ldoffw, const float* ref,
                        int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream);
+/* the same with the offsets | logits stored as IEEE half (offw_f16 [B*Q, ldoffw] halves): the K = 256 GEMM that produces them
+ * (ape_hip_gemm with out_dt = APE_DT_F16) is bound by the bytes it writes, and this kernel by the bytes it reads; bf16 values */
+int ape_hip_msda_fused_h(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
+                       const int64_t* level_start_index, const void* offw_f16, int ldoffw, const float* ref,
+                       int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Scaled-dot-product attention (non causal, no mask): O = softmax(scale * Q K^T) V

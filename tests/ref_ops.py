@@ -176,7 +176,7 @@ def msda_locations(offw, ref, spatial_shapes):
 def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, out_dtype=None, out=None):
     S = value.shape[0] // batch
     Q = offw.shape[0] // batch
-    loc, aw = msda_locations(offw, ref.reshape(batch * Q, -1, ref.shape[-1]), spatial_shapes)
+    loc, aw = msda_locations(offw.float(), ref.reshape(batch * Q, -1, ref.shape[-1]), spatial_shapes)
     v = value[:, :256].float().reshape(batch, S, 8, 32)
     o = ms_deform_attn_core(v, spatial_shapes, loc.reshape(batch, Q, *loc.shape[1:]), aw.reshape(batch, Q, *aw.shape[1:]))
     o = o.reshape(batch * Q, 256)

@@ -203,6 +203,40 @@ def test_software_pipelined_runtime(B):
         assert inst.pred_masks.shape == m.shape and (inst.pred_masks != m).float().mean().item() < 1e-3
 
 
+def test_runtime_rle_mask_format_and_predictor_pipeline():
+    """mask_format="rle": the runtime's device-side COCO RLE == the bitmask output encoded by the oracle; the predictor's
+    device-side input pipeline (upload uint8, resize + BGR flip + float CHW in one kernel) == the reference's host pipeline"""
+    import numpy as np
+    from oracle import imageio as IO
+    from ape_amd import evaluation
+    from ape_amd.engine import DefaultPredictor
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_padded", torch.float32)
+    plain = GraphedForward(model.model_vision)
+    rle = GraphedForward(model.model_vision, mask_format="rle", rle_cap=512)
+    h, w = image.shape[-2:]
+    for fh, fw in [(h, w), (2 * h + 3, w + 17)]:
+        a, _ = plain(image, text, fh, fw)
+        b, _ = rle(image, text, fh, fw)
+        assert len(a) == len(b) > 0 and b.has("pred_masks_rle") and not b.has("pred_masks")
+        assert torch.equal(a.pred_classes, b.pred_classes)
+        for i in range(len(a)):
+            r = b.pred_masks_rle[i]
+            ref = IO.rle_encode(a.pred_masks[i].numpy())
+            assert r["size"] == [fh, fw] and r["counts"] == IO.rle_to_string(ref), i
+        js = evaluation.instances_to_coco_json(b, 7)
+        js2 = evaluation.instances_to_coco_json(a, 7)                       # host bitmasks -> uploaded -> encoded on the device
+        assert [d["segmentation"] for d in js] == [d["segmentation"] for d in js2]
+        assert js[0]["bbox"][2] >= 0 and js[0]["image_id"] == 7
+    rng = np.random.default_rng(3)
+    pred = DefaultPredictor(model=model, short_edge_length=h, max_size=max(h, w), input_format="RGB")
+    bgr = rng.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    got = pred.preprocess(bgr)
+    ref = IO.predictor_input(bgr, h, max(h, w), "RGB")
+    assert got.is_cuda and np.array_equal(got.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("pipeline", [False, True])
 def test_any_size_runtime(pipeline):
     """any_size=True: ONE size-agnostic graph (image canvas + StaticGeometry buffers + device frame vector) serves a stream
