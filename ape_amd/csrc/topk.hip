@@ -449,6 +449,11 @@ extern "C" int ape_hip_proposal_order(const int32_t* cand, int n, const float* l
   if (fill_levels(lv, level_start, level_n, L)) return -1;
   APE_CHECK_ARG(cand && logit && xyxy && boxes_b && groups_b && seg && cand_a && lv_a && pos_b && n > 0 && n <= PO_PAD,
                 "ape_hip_proposal_order: 1 <= n <= 8192 candidates");
+  static bool attr_done = false;
+  if (!attr_done) {   // 64 KiB of dynamic LDS next to the kernel's static arrays needs the opt-in attribute
+    (void)hipFuncSetAttribute((const void*)proposal_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    attr_done = true;
+  }
   hipLaunchKernelGGL(proposal_order_kernel, dim3(1), dim3(TK_THREADS), PO_PAD * sizeof(u64), (hipStream_t)stream, cand, n, logit, xyxy, lv,
                      boxes_b, groups_b, seg, cand_a, lv_a, pos_b);
   APE_CHECK_LAUNCH("proposal_order_kernel");
