@@ -164,7 +164,7 @@ __device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float
 #define EPI_ACT_RELU 1
 #define EPI_ACT_SWIGLU 2
 
-__host__ __device__ __forceinline__ bool epi_fast_ok(const GemmParams& p) {
+__device__ __forceinline__ bool epi_fast_ok(const GemmParams& p) {
   if (p.alpha != 1.f || p.rowmask != nullptr || p.clamp > 0.f) return false;
   if (!(p.act == APE_ACT_NONE || p.act == APE_ACT_RELU || p.act == APE_ACT_SWIGLU)) return false;
   if (p.bias != nullptr && !(p.vec_ok & (2 | 16))) return false;
@@ -246,108 +246,6 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
         ld8<bf16_t>(rp + e * 8, r);
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[e * 8 + q] += r[q];
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// The same epilogue split into LOAD and APPLY, for kernels that walk several row tiles per lane (gemm_p8.hip).  epi_row_fast
-// issues its loads where it needs them; unrolled over 8 row tiles that became, per row tile, a chain of dependent
-// load -> s_waitcnt vmcnt(0) -> use groups (row scale, column vector, bias, RoPE tables, residual: up to five exposed L2 / HBM
-// latencies per row tile, and the loads of the next row tile cannot be hoisted above this row tile's stores because the
-// compiler must assume they alias).  Here the row-invariant vectors (bias[n], colvec[n]) are loaded once per lane, and everything
-// a row tile needs from memory is one batch of loads (`epi_row_load`) that the caller issues one row tile AHEAD of the stores
-// of the current one: the epilogue exposes one latency instead of ~8 x (1..5).  Arithmetic and its order are epi_row_fast's.
-// ------------------------------------------------------------------------------------------
-template <int W, bool ROPE, bool NORM, bool RES>
-struct EpiRowAux {
-  float c[ROPE ? W : 1], sn[ROPE ? W : 1];
-  uint4 rr[RES ? W / 4 : 1];      // residual row segment, raw: W fp32 values or (first W / 8 entries) W bf16 values
-  float rs, sh, brow;
-};
-
-// BROW: the bias is indexed by the row (transposed problems).  RES_F32: the residual is fp32 (else bf16).  Both are uniform per
-// launch and are template arguments so that the row loop is straight-line code: a load inside a (even uniform) branch makes the
-// compiler's wait-count bookkeeping fall back to vmcnt(0) at the next use, which serialises the prefetch again.
-template <int W, bool ROPE, bool NORM, bool RES, bool BROW, bool RES_F32>
-__device__ __forceinline__ void epi_row_load(const GemmParams& p, int m, int nb, EpiRowAux<W, ROPE, NORM, RES>& a) {
-  if constexpr (NORM) { a.rs = p.rowscale[m]; a.sh = p.rowshift[m]; }
-  if constexpr (BROW) a.brow = p.bias[m];
-  if constexpr (ROPE) {
-    // columns >= rope_cols are not rotated (apply selects); their table reads stay inside the table
-    const int hd = p.rope_hd;
-    const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;
-    const size_t trow = (size_t)(m & rmask) * hd + (nb & (hd - 1));
-    ldrow_f32<W>(p.rope_cos + trow, a.c);
-    ldrow_f32<W>(p.rope_sin + trow, a.sn);
-  }
-  if constexpr (RES) {
-    const size_t roff = (size_t)m * p.ldr + nb;
-    if constexpr (RES_F32) {
-      const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
-#pragma unroll
-      for (int e = 0; e < W / 4; ++e) a.rr[e] = *reinterpret_cast<const uint4*>(rp + e * 4);
-    } else {
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + roff;
-#pragma unroll
-      for (int e = 0; e < W / 8; ++e) a.rr[e] = *reinterpret_cast<const uint4*>(rp + e * 8);
-    }
-  }
-}
-
-template <int W, bool ROPE, bool NORM, bool RES, bool BROW, bool RES_F32, int ACT>
-__device__ __forceinline__ void epi_row_apply(const GemmParams& p, int nb, bool has_bias_n, const EpiRowAux<W, ROPE, NORM, RES>& a,
-                                              const float (&bias_n)[W], const float (&cvec)[W], float (&v)[W]) {
-  if constexpr (NORM) {
-#pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = fmaf(v[e], a.rs, a.sh * cvec[e]);
-  }
-  if constexpr (BROW) {
-#pragma unroll
-    for (int e = 0; e < W; ++e) v[e] += a.brow;
-  } else if (has_bias_n) {
-#pragma unroll
-    for (int e = 0; e < W; ++e) v[e] += bias_n[e];
-  }
-  if constexpr (ROPE) {
-    const bool rot = nb < p.rope_cols;
-#pragma unroll
-    for (int e = 0; e < W; e += 2) {          // rotate_half pairs (2i, 2i+1) -> (-x[2i+1], x[2i])
-      const float x0 = v[e], x1 = v[e + 1];
-      const float r0 = x0 * a.c[e] - x1 * a.sn[e];
-      const float r1 = x1 * a.c[e + 1] + x0 * a.sn[e + 1];
-      v[e] = rot ? r0 : x0;
-      v[e + 1] = rot ? r1 : x1;
-    }
-  }
-  if (ACT == EPI_ACT_RELU) {
-#pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = fmaxf(v[e], 0.f);
-  }
-  if (ACT == EPI_ACT_SWIGLU) {                   // interleaved (gate, up) pairs -> W/2 outputs in v[0 .. W/2)
-#pragma unroll
-    for (int e = 0; e < W / 2; ++e) {
-      const float g = v[2 * e], u = v[2 * e + 1];
-      v[e] = (g / (1.f + __expf(-g))) * u;
-    }
-    return;
-  }
-  if constexpr (RES) {
-    if constexpr (RES_F32) {
-#pragma unroll
-      for (int e = 0; e < W / 4; ++e) {
-        v[4 * e] += __uint_as_float(a.rr[e].x); v[4 * e + 1] += __uint_as_float(a.rr[e].y);
-        v[4 * e + 2] += __uint_as_float(a.rr[e].z); v[4 * e + 3] += __uint_as_float(a.rr[e].w);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < W / 8; ++e) {
-        const uint4 t = a.rr[e];
-        v[8 * e] += __uint_as_float(t.x << 16); v[8 * e + 1] += __uint_as_float(t.x & 0xffff0000u);
-        v[8 * e + 2] += __uint_as_float(t.y << 16); v[8 * e + 3] += __uint_as_float(t.y & 0xffff0000u);
-        v[8 * e + 4] += __uint_as_float(t.z << 16); v[8 * e + 5] += __uint_as_float(t.z & 0xffff0000u);
-        v[8 * e + 6] += __uint_as_float(t.w << 16); v[8 * e + 7] += __uint_as_float(t.w & 0xffff0000u);
       }
     }
   }

@@ -48,21 +48,7 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// EPI: the epilogue specialisation, chosen per launch by the launcher (one kernel per specialisation: compiled into ONE kernel
-// behind a uniform branch, the register allocation of the prefetching epilogues spilled).  0 = generic (bounds-checked quads, any
-// combination); 1 RoPE; 2 folded LayerNorm + residual; 3 folded LayerNorm; 4 SwiGLU; 5 ReLU + residual; 6 ReLU;
-// 7 residual; 8 bias only.  A wave whose column slab is partial takes the generic path in every specialisation.
-#define P8_EPI_GENERIC 0
-#define P8_EPI_ROPE 1
-#define P8_EPI_NORM_RES 2
-#define P8_EPI_NORM 3
-#define P8_EPI_SWIGLU 4
-#define P8_EPI_RELU_RES 5
-#define P8_EPI_RELU 6
-#define P8_EPI_RES 7
-#define P8_EPI_PLAIN 8
-
-template <int BN, bool STAGGER, int EPI>
+template <int BN, bool STAGGER>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
@@ -243,52 +229,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   // ---- epilogue from registers: lane (frow, fq) owns rows tile_i * 16 + frow, TN * 4 consecutive columns
   constexpr int W = TN * 4;
   const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
-  // wave-uniform: the wave's whole column slab is inside N (a partial slab takes the generic, bounds-checked path); everything
-  // else the fast epilogues need (epi_fast_ok, 16-byte output rows) was checked by the launcher when it picked EPI
-  const bool fast = EPI != P8_EPI_GENERIC && n0 + wc * WN + WN <= p.N;
-  // one specialisation per launch (wave-uniform).  Row-invariant vectors are loaded once; the loads of row tile i + 1 are
-  // issued BEFORE row tile i is finished and stored (see gemm_epi.h: the compiler cannot hoist them above the stores itself),
-  // so the eight row tiles expose one memory latency instead of eight chains of dependent loads.
-  auto run2 = [&](auto rope_t, auto norm_t, auto res_t, auto act_t, auto brow_t, auto rf32_t) __attribute__((always_inline)) {
-    constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value, RES = decltype(res_t)::value;
-    constexpr bool BROW = decltype(brow_t)::value, RF32 = decltype(rf32_t)::value;
+  // wave-uniform: the wave's whole column slab is inside N (a partial slab takes the generic, bounds-checked path)
+  const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
+  // one specialisation per launch (wave-uniform): the unrolled body stays short
+  auto run = [&](auto rope_t, auto norm_t, auto act_t) __attribute__((always_inline)) {
+    constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value;
     constexpr int ACT = decltype(act_t)::value;
-    float bias_n[W], cvec[W];
-#pragma unroll
-    for (int e = 0; e < W; ++e) { bias_n[e] = 0.f; cvec[e] = 0.f; }
-    const bool has_bias_n = !BROW && p.bias != nullptr;
-    if (has_bias_n) ldrow_f32<W>(p.bias + nb, bias_n);
-    if (NORM) ldrow_f32<W>(p.colvec + nb, cvec);
-    EpiRowAux<W, ROPE, NORM, RES> aux[2];
-    const int mbase = m0 + wr * 128 + frow;
-    epi_row_load<W, ROPE, NORM, RES, BROW, RF32>(p, min(mbase, p.M - 1), nb, aux[0]);
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
-      if (i + 1 < 8) epi_row_load<W, ROPE, NORM, RES, BROW, RF32>(p, min(mbase + (i + 1) * 16, p.M - 1), nb, aux[(i + 1) & 1]);
-      const int m = mbase + i * 16;
-      float o[W];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[4 * j + r] = acc[i][j][r];
-      epi_row_apply<W, ROPE, NORM, RES, BROW, RF32, ACT>(p, nb, has_bias_n, aux[i & 1], bias_n, cvec, o);
+      const int m = m0 + wr * 128 + i * 16 + frow;
       if (m < p.M) {
+        float o[W];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[4 * j + r] = acc[i][j][r];
+        epi_row_fast<W, ROPE, NORM, ACT>(p, m, nb, o);
         if (ACT == EPI_ACT_SWIGLU) store_row<W / 2>(p, m, nb >> 1, o);
         else store_row<W>(p, m, nb, o);
       }
-    }
-  };
-  // uniform launch properties that are not part of EPI: bias by row (transposed problems; bias then always present), fp32 vs
-  // bf16 residual -- decided once, outside the row loop
-  auto run = [&](auto rope_t, auto norm_t, auto res_t, auto act_t) __attribute__((always_inline)) {
-    using TT = std::true_type; using FF = std::false_type;
-    constexpr bool RES = decltype(res_t)::value;
-    const bool brow = p.bias != nullptr && (p.vec_ok & 16);
-    if constexpr (RES) {
-      if (p.res_dt == APE_DT_F32) { if (brow) run2(rope_t, norm_t, res_t, act_t, TT{}, TT{}); else run2(rope_t, norm_t, res_t, act_t, FF{}, TT{}); }
-      else { if (brow) run2(rope_t, norm_t, res_t, act_t, TT{}, FF{}); else run2(rope_t, norm_t, res_t, act_t, FF{}, FF{}); }
-    } else {
-      if (brow) run2(rope_t, norm_t, res_t, act_t, TT{}, FF{}); else run2(rope_t, norm_t, res_t, act_t, FF{}, FF{});
     }
   };
   using T = std::true_type; using F = std::false_type;
@@ -305,17 +264,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
         }
       }
     }
+  } else if (p.rope_cos != nullptr) {
+    run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
+  } else if (p.rowscale != nullptr) {
+    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{});
+  } else if (p.act == APE_ACT_SWIGLU) {
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{});
+  } else if (p.act == APE_ACT_RELU) {
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{});
   } else {
-    using NONE_T = std::integral_constant<int, EPI_ACT_NONE>;
-    using RELU_T = std::integral_constant<int, EPI_ACT_RELU>;
-    if constexpr (EPI == P8_EPI_ROPE) run(T{}, F{}, F{}, NONE_T{});
-    else if constexpr (EPI == P8_EPI_NORM_RES) run(F{}, T{}, T{}, NONE_T{});
-    else if constexpr (EPI == P8_EPI_NORM) run(F{}, T{}, F{}, NONE_T{});
-    else if constexpr (EPI == P8_EPI_SWIGLU) run(F{}, F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{});
-    else if constexpr (EPI == P8_EPI_RELU_RES) run(F{}, F{}, T{}, RELU_T{});
-    else if constexpr (EPI == P8_EPI_RELU) run(F{}, F{}, F{}, RELU_T{});
-    else if constexpr (EPI == P8_EPI_RES) run(F{}, F{}, T{}, NONE_T{});
-    else if constexpr (EPI == P8_EPI_PLAIN) run(F{}, F{}, F{}, NONE_T{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
   }
 }
 
@@ -342,44 +300,21 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     p.trans_out = 0;
     p.vec_ok = (p.vec_ok & ~2) | P8_BIAS_BY_ROW;
   }
-  // epilogue specialisation (uniform per launch; the conditions the fast epilogues rely on are checked here)
-  int epi = P8_EPI_GENERIC;
-  if (epi_fast_ok(p) && !(p.rope_cos != nullptr && p.residual != nullptr) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0) {
-    const bool res = p.residual != nullptr;
-    if (p.rope_cos != nullptr) epi = P8_EPI_ROPE;
-    else if (p.rowscale != nullptr) epi = res ? P8_EPI_NORM_RES : P8_EPI_NORM;
-    else if (p.act == APE_ACT_SWIGLU) epi = P8_EPI_SWIGLU;
-    else if (p.act == APE_ACT_RELU) epi = res ? P8_EPI_RELU_RES : P8_EPI_RELU;
-    else epi = res ? P8_EPI_RES : P8_EPI_PLAIN;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    attr_done = true;
   }
-  if (!stagger) epi = P8_EPI_GENERIC;            // the unstaggered schedule exists for A/B probes only (generic epilogue)
   const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
-  const size_t lds = bn == 256 ? 131072 : 98304;
-#define P8_CASE(BN_, ST_, E_)                                                                                              \
-  case E_: {                                                                                                              \
-    static bool done = false;                                                                                             \
-    if (!done) {                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<BN_, ST_, E_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      done = true;                                                                                                        \
-    }                                                                                                                     \
-    hipLaunchKernelGGL((gemm_bf16_p8_kernel<BN_, ST_, E_>), dim3(tiles), dim3(512), lds, s, p);                           \
-    break;                                                                                                                \
-  }
-#define P8_SWITCH(BN_)                                                                     \
-  switch (epi) {                                                                           \
-    P8_CASE(BN_, true, P8_EPI_GENERIC) P8_CASE(BN_, true, P8_EPI_ROPE) P8_CASE(BN_, true, P8_EPI_NORM_RES)   \
-    P8_CASE(BN_, true, P8_EPI_NORM) P8_CASE(BN_, true, P8_EPI_SWIGLU) P8_CASE(BN_, true, P8_EPI_RELU_RES)    \
-    P8_CASE(BN_, true, P8_EPI_RELU) P8_CASE(BN_, true, P8_EPI_RES) P8_CASE(BN_, true, P8_EPI_PLAIN)          \
-  }
-  // the reported symbol groups the epilogue specialisations of one tile shape (bench.py sums them under one name)
   if (bn == 256) {
-    if (stagger) { P8_SWITCH(256) return "gemm_bf16_p8_kernel<256, true>"; }
-    switch (epi) { P8_CASE(256, false, P8_EPI_GENERIC) }
+    if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true>), dim3(tiles), dim3(512), 131072, s, p); return "gemm_bf16_p8_kernel<256, true>"; }
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, false>), dim3(tiles), dim3(512), 131072, s, p);
     return "gemm_bf16_p8_kernel<256, false>";
   }
-  if (stagger) { P8_SWITCH(128) return "gemm_bf16_p8_kernel<128, true>"; }
-  switch (epi) { P8_CASE(128, false, P8_EPI_GENERIC) }
+  if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, true>), dim3(tiles), dim3(512), 98304, s, p); return "gemm_bf16_p8_kernel<128, true>"; }
+  hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, false>), dim3(tiles), dim3(512), 98304, s, p);
   return "gemm_bf16_p8_kernel<128, false>";
-#undef P8_SWITCH
-#undef P8_CASE
 }

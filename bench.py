@@ -87,15 +87,25 @@ class GemmMeter:
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
 
+    @staticmethod
+    def family(name):
+        """the eight-wave tile kernel is compiled once per epilogue (third template argument, csrc/gemm_p8.hip): the roofline
+        object is about the tile kernel as a whole = the sum over its epilogue specialisations"""
+        import re
+        return re.sub(r"^(gemm_bf16_p8_kernel<\d+, \w+), \d+>$", r"\1>", name)
+
     def summary(self):
-        """per kernel symbol: (launches, seconds, flops), sorted by time"""
+        """per kernel family: (launches, seconds, flops), sorted by time; and per exact symbol (as rocprofv3 lists them)"""
         torch.cuda.synchronize()
-        groups = {}
+        groups, symbols = {}, {}
         for name, s, e, fl in self.records:
-            g = groups.setdefault(name, [0, 0.0, 0.0])
-            g[0] += 1
-            g[1] += s.elapsed_time(e) * 1e-3
-            g[2] += fl
+            dt = s.elapsed_time(e) * 1e-3
+            for table, key in ((groups, self.family(name)), (symbols, name)):
+                g = table.setdefault(key, [0, 0.0, 0.0])
+                g[0] += 1
+                g[1] += dt
+                g[2] += fl
+        self.symbols = symbols
         return sorted(groups.items(), key=lambda kv: -kv[1][1])
 
 
@@ -298,6 +308,10 @@ def main():
                          "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n / reps,
                          "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
                          "flops_per_launch": dom_fl / max(dom_n, 1),
+                         # the family's exact symbols as rocprofv3 --kernel-trace lists them (one per epilogue specialisation)
+                         "symbols": {k: {"launches_per_image": v[0] / reps, "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 2),
+                                         "tflops": round(v[2] / v[1] / 1e12, 1)}
+                                     for k, v in sorted(meter.symbols.items(), key=lambda kv: -kv[1][1]) if GemmMeter.family(k) == dom_name},
                          "all_gemm_kernels": {"ms_per_image": 1e3 * all_t / reps, "tflops": all_fl / all_t / 1e12,
                                               "flops_per_image": all_fl / reps,
                                               "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups}}},
