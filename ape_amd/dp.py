@@ -6,7 +6,9 @@ ape/data/build.py:79,127), so the forward has NO collective on its data path.  T
     classes, 2.4 MB for LVIS-1203) -- the reference instead recomputes / caches the text tower on every rank
     (clip_wrapper_eva02.py:88-128), and
   * an all-gather of fixed-size detection records [k, 6] = (x1, y1, x2, y2, score, class) per step -- the reference
-    gathers pickled Python lists over a gloo group at the end (lvis_evaluation.py:103-104).
+    gathers pickled Python lists over a gloo group at the end (lvis_evaluation.py:103-104) -- and, with
+    `gather_masks=True` on a runtime in `mask_format="rle"`, of the masks as COCO run lengths ([k, cap] int32 + [k] run
+    counts per image: 1.6 MB at k = 100, cap = 4096, instead of 105 MB of bitmaps).
 One process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
 import torch
@@ -19,9 +21,11 @@ def shard_indices(n_items, rank, world):
 
 
 class DataParallelRunner:
-    def __init__(self, forward_fn, records_per_image, device, group=None):
+    def __init__(self, forward_fn, records_per_image, device, group=None, gather_masks=False):
         """forward_fn(image, text) -> (host instances, device record tensor [records_per_image, 6])"""
         self.forward_fn = forward_fn
+        self.gather_masks = gather_masks
+        self._gather_runs = None
         self.k = records_per_image
         self.device = device
         self.group = group
@@ -37,6 +41,28 @@ class DataParallelRunner:
         if self.world > 1:
             dist.broadcast(text, src=0, group=self.group)
         return text
+
+    def text_bank_from_names(self, model_language, names, dim=1024, cache=True):
+        """rank 0 runs the text tower on the class names (`model_language.forward_text`, e.g. ape_amd.modeling.text.EVA02CLIP)
+        and every rank receives the [len(names), dim] bank -- the reference runs the tower on every rank
+        (deformable_detr_segm_vl.py:258-260)"""
+        feats = None
+        if self.rank == 0:
+            feats = model_language.forward_text(list(names), cache=cache)["last_hidden_state_eot"].float()
+            if tuple(feats.shape) != (len(names), dim):
+                raise ValueError(f"text tower returned {tuple(feats.shape)}, expected {(len(names), dim)}")
+        return self.broadcast_text_bank(feats, len(names), dim)
+
+    def _all_gather_runs(self, runs):
+        """all ranks' (run lengths, run counts) of one step: ([world, ...], [world, ...])"""
+        counts, nruns = runs
+        if self.world == 1:
+            return counts[None], nruns[None]
+        if self._gather_runs is None or self._gather_runs[0][0].shape != counts.shape:
+            self._gather_runs = ([torch.empty_like(counts) for _ in range(self.world)], [torch.empty_like(nruns) for _ in range(self.world)])
+        dist.all_gather(self._gather_runs[0], counts.contiguous(), group=self.group)
+        dist.all_gather(self._gather_runs[1], nruns.contiguous(), group=self.group)
+        return torch.stack(self._gather_runs[0]), torch.stack(self._gather_runs[1])
 
     def _all_gather(self, rec):
         if self.world == 1:
@@ -58,6 +84,8 @@ class DataParallelRunner:
         ticket = self.forward_fn.submit(image, text, height, width, prompt)
         if getattr(ticket, "rec6", None) is not None:      # detections already enqueued (non-pipelined runtime): gather now,
             ticket.records = self._all_gather(ticket.rec6)  # stream-ordered behind the forward, no host wait
+            if self.gather_masks and getattr(ticket, "runs", None) is not None:
+                ticket.mask_runs = self._all_gather_runs(ticket.runs)
         return ticket
 
     def result(self, ticket):
@@ -67,4 +95,6 @@ class DataParallelRunner:
         inst, rec = self.forward_fn.result(ticket)
         if getattr(ticket, "records", None) is None:
             ticket.records = self._all_gather(rec)
+        if self.gather_masks and getattr(ticket, "mask_runs", None) is None and getattr(ticket, "runs", None) is not None:
+            ticket.mask_runs = self._all_gather_runs(ticket.runs)       # every rank's masks as run lengths: ticket.mask_runs
         return inst, ticket.records

@@ -50,11 +50,13 @@ _RETIRED = []
 
 class _Ticket:
     """handle of a submitted step (weak-referenceable, unlike SimpleNamespace)"""
-    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "__weakref__")
+    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "runs", "mask_runs", "__weakref__")
 
     def __init__(self, entry, single, frames):
         self.entry, self.single, self.frames = entry, single, frames      # frames: [(height, width)] of the output masks
         self.slot, self.ready, self.rec6, self.records = None, False, None, None
+        self.runs, self.mask_runs = None, None        # mask_format="rle": (device run lengths [B,k,cap], run counts [B,k]); all ranks'
+
 
 
 class GraphedForward:
@@ -355,6 +357,8 @@ class GraphedForward:
             s.has_masks = has_masks
             completes.slot, completes.ready = s, True
             completes.rec6 = s.d_rec[:, :, :6] if self.B > 1 else s.d_rec[0, :, :6]
+            if has_masks and s.d_runs is not None:
+                completes.runs = (s.d_runs, s.d_nruns)
         if images is not None and self.pipeline and self.any_size:
             # now the static geometry / frame may take the NEW images' constants (stream-ordered behind the replay)
             mv = self.mv

@@ -47,20 +47,44 @@ def _worker(rank, world, port, ret):
     class Pipelined:
         def submit(self, image, text, height=None, width=None, prompt="name"):
             from types import SimpleNamespace
-            return SimpleNamespace(rec6=fwd(image, text)[1])
+            rec = fwd(image, text)[1]
+            # stand-in for the runtime's device RLE buffers (mask_format="rle"): [k, cap] run lengths + [k] run counts
+            runs = (rec[:, :4].round().to(torch.int32).repeat(1, 2).contiguous(), rec[:, 5].to(torch.int32).contiguous())
+            return SimpleNamespace(rec6=rec, runs=runs)
 
         def result(self, ticket):
             return None, ticket.rec6
 
-    prunner = DataParallelRunner(Pipelined(), mv.test_topk_per_image, torch.device("cpu"))
-    piped, pending = [], None
+    prunner = DataParallelRunner(Pipelined(), mv.test_topk_per_image, torch.device("cpu"), gather_masks=True)
+    piped, pending, tickets = [], None, []
     for i in mine:
         t = prunner.submit(images[i], text)
+        tickets.append(t)
         if pending is not None:
             piped.append(prunner.result(pending)[1])
         pending = t
     piped.append(prunner.result(pending)[1])
     same = all(torch.equal(a, b) for a, b in zip(piped, gathered)) and len(piped) == len(gathered)
+    # the masks' run lengths of every rank arrive with the records (rank r's entry == what rank r produced for that step)
+    for t, allrec in zip(tickets, gathered):
+        counts, nruns = t.mask_runs
+        same &= counts.shape[0] == world and torch.equal(counts[rank], t.runs[0]) and torch.equal(nruns[rank], t.runs[1])
+        for r in range(world):
+            same &= torch.equal(counts[r][:, :4], allrec[r][:, :4].round().to(torch.int32))
+
+    # text bank from class names: only rank 0 owns a text tower
+    class Tower:
+        calls = 0
+
+        def forward_text(self, names, cache=False):
+            Tower.calls += 1
+            g = torch.Generator().manual_seed(len(names))
+            return {"last_hidden_state_eot": torch.randn(len(names), 1024, generator=g)}
+
+    named = runner.text_bank_from_names(Tower() if rank == 0 else None, ["cat", "dog", "traffic light"])
+    same &= tuple(named.shape) == (3, 1024) and (Tower.calls == (1 if rank == 0 else 0))
+    ret[f"named_sum_{rank}"] = float(named.sum())
+    ret[f"same_{rank}"] = bool(same)
     if rank == 0:
         # single-process ground truth for every image
         want = [fwd(img, text)[1] for img in images]
@@ -82,8 +106,9 @@ def test_dp_two_ranks_gloo():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert ret["ok"]
+    assert ret["ok"] and ret["same_0"] and ret["same_1"]
     assert abs(ret["text_sum"] - ret["text_sum_1"]) < 1e-6   # the broadcast reached rank 1
+    assert abs(ret["named_sum_0"] - ret["named_sum_1"]) < 1e-6 and ret["named_sum_0"] != 0.0
 
 
 def test_shard_indices():
