@@ -31,6 +31,10 @@ SIZES = {
     # APE-Ti (BASELINE config 1): configs/common/backbone/vitt_eva02.py:10-41 -- the EVA-02 MIM ViT-Ti of vit_eva02.py
     "Ti": dict(img_size=1024, embed_dim=192, depth=12, num_heads=3, window_size=14, pretrain_img_size=224, enc_layers=6,
                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02"),
+    # APE-L_A / L_B / L_C: the EVA-02 MIM ViT-L of vit_eva02.py (configs/common/backbone/vitl_eva02.py:10-41: 16 x 16 windows on the
+    # 64 x 64 grid, every sixth block global, separate q/k/v projections, SwiGLU with its sub-LayerNorm)
+    "L_A": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=16, pretrain_img_size=224, enc_layers=6,
+                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02", subln=True, global_every=6),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
 }
@@ -44,9 +48,9 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
         net = vit_eva02.ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
                             drop_path_rate=0.8, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
                             norm_layer=partial(nn.LayerNorm, eps=1e-6),
-                            window_block_indexes=[i for i in range(c.depth) if i % 3 != 2], residual_block_indexes=[],
-                            use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True, subln=False,
-                            swiglu=True, naiveswiglu=False)
+                            window_block_indexes=[i for i in range(c.depth) if i % getattr(c, "global_every", 3) != getattr(c, "global_every", 3) - 1],
+                            residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
+                            subln=getattr(c, "subln", False), swiglu=not getattr(c, "subln", False), naiveswiglu=getattr(c, "subln", False))
     else:
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
                   drop_path_rate=0.4, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,

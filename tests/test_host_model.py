@@ -241,6 +241,34 @@ def test_ape_ti_backbone_matches_reference_golden(fake_ops):
     print(f"APE-Ti backbone vs reference run: max relerr {e:.2e}")
 
 
+def _eva02_subln_case(device, dtype):
+    """the APE-L_A/B/C backbone configuration of vit_eva02.ViT at reduced size + the reference run's output"""
+    import os
+    from functools import partial
+    import torch.nn as nn
+    from ape_amd.modeling.backbone import vit_eva02
+    from oracle import weights
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_eva02_subln.pt"), weights_only=False)
+    net = vit_eva02.ViT(norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_path_rate=0.0, **gold["cfg"])
+    own = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert own == dict((k, v) for k, v in gold["spec"]), sorted(set(own) ^ set(dict(gold["spec"])))[:6]      # checkpoint-key contract
+    net.load_state_dict(weights.make_state_dict(gold["spec"], gold["wseed"]), strict=False)
+    net.compute_dtype = dtype
+    image = torch.randint(0, 256, (3, 256, 256), generator=torch.Generator().manual_seed(gold["iseed"])).float()
+    return net.to(device), image.to(device), gold
+
+
+def test_eva02_subln_backbone_matches_reference_golden(fake_ops):
+    """the EVA-02 MIM ViT as APE-L_A/B/C configure it (vitl_eva02.py:10-41: separate q/k/v projections, SwiGLU with
+    its sub-LayerNorm, windows that tile the grid, every sixth block global) vs the reference's own ViT, fp32"""
+    net, image, gold = _eva02_subln_case("cpu", torch.float32)
+    feat = net.forward_tokens(image, (120.0, 120.0, 120.0), (60.0, 60.0, 60.0))                   # [256, 128] raster order
+    ref = gold["last_feat"].reshape(128, -1).t()
+    e = U.relerr(feat, ref)
+    print(f"EVA-02 (sub-LN / naive SwiGLU) backbone vs reference run: {e:.2e}")
+    assert e < 1e-5
+
+
 def test_fp16_model_runs_through_the_module_edge(fake_ops):
     """the reference evaluates with model.to(torch.float16) (tools/train_net.py:642): parameters and inputs arrive as fp16,
     the HIP path stores bf16 / computes fp32 behind an explicit cast at the module edge, results come back like the

@@ -203,6 +203,19 @@ def test_software_pipelined_runtime(B):
         assert inst.pred_masks.shape == m.shape and (inst.pred_masks != m).float().mean().item() < 1e-3
 
 
+def test_eva02_subln_backbone_on_gpu():
+    """the APE-L_A/B/C backbone configuration (vit_eva02.ViT with sub-LN / naive SwiGLU) on the HIP kernels vs the reference
+    run: fp32 kernels <= 1e-3 (north_star's tolerance), bf16 reported and bounded"""
+    from test_host_model import _eva02_subln_case
+
+    for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        net, image, gold = _eva02_subln_case("cuda", dt)
+        feat = net.forward_tokens(image, (120.0, 120.0, 120.0), (60.0, 60.0, 60.0))
+        e = U.relerr(feat.float().cpu(), gold["last_feat"].reshape(128, -1).t())
+        print(f"[eva02 sub-LN backbone {dt}] last_feat vs reference run: {e:.2e}")
+        assert e < tol
+
+
 def test_runtime_rle_mask_format_and_predictor_pipeline():
     """mask_format="rle": the runtime's device-side COCO RLE == the bitmask output encoded by the oracle; the predictor's
     device-side input pipeline (upload uint8, resize + BGR flip + float CHW in one kernel) == the reference's host pipeline"""
