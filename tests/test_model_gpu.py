@@ -390,11 +390,12 @@ def test_L_D_fp32_matches_reference(case):
 # same pipeline differ by 5.8e-2 / 8.4e-2 (T2 above), and between builds that differ only in where bf16-level rounding falls the
 # T3 maxima moved between 2.7e-2 and 5.5e-2 (logits), 4.1e-2 and 8.3e-2 (boxes) (profiles/r02_parity_L_D.log,
 # profiles/r02_p8_epilogue_experiment_tests.log) while detections matched (83 %) and mask-sign mismatch (1.1e-2) stayed put.  The
-# head maxima are therefore bounded by the T2 scatter, and the STABLE statistic -- rms error over all 900 x K logits / 900 x 4
+# head maxima are therefore bounded just above the largest value seen (and well inside the T2 scatter), and the STABLE statistic -- rms error over all 900 x K logits / 900 x 4
 # box coordinates -- is asserted tightly (LD_BF16_T3_RMS = 2 x measured).
 LD_BF16_T2 = {"p2": 2e-2, "memory": 3.5e-2, "enc_class": 1.7e-2, "pred_logits": 1.3e-1, "pred_boxes": 1.7e-1}
-LD_BF16_T3 = {"p2": 1.2e-2, "memory": 1.4e-2, "pred_logits": 1.3e-1, "pred_boxes": 1.7e-1}
-LD_BF16_T3_RMS = {"pred_logits": 2e-2, "pred_boxes": 3e-2}
+# rms measured (profiles/r02_parity_rms.log): pred_logits 3.7e-3, pred_boxes 1.09e-2 for both vocabularies
+LD_BF16_T3 = {"p2": 1e-2, "memory": 1.4e-2, "pred_logits": 7e-2, "pred_boxes": 1e-1}
+LD_BF16_T3_RMS = {"pred_logits": 7.5e-3, "pred_boxes": 2.2e-2}
 
 
 @pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203"])
