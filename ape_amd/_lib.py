@@ -106,7 +106,9 @@ SIGNATURES = {
     "ape_hip_box_refine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_bilinear_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_enc_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "ape_hip_proposal_topk": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_topk_workspace_words": (c_int, [c_int]),
+    "ape_hip_proposal_topk": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
     "ape_hip_proposal_order": (c_int, [c_void_p, c_int, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ape_hip_proposal_quota": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_int),
@@ -114,7 +116,7 @@ SIGNATURES = {
     "ape_hip_det_sort": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "ape_hip_det_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p]),
+                                 c_void_p, c_void_p]),
     "ape_hip_resize_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int]),
     "ape_hip_resize_tile_rows": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "ape_hip_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

@@ -105,14 +105,15 @@ __device__ __forceinline__ void radix_select(KeyFn key, int n, int k, uint32_t* 
   rem = r;
 }
 
-// ---- top-k of key(0..n-1) into comp[0..1023] (sorted descending; entries >= min(k, n) are zero): composite =
-//      key << 32 | (0xffffffff - index), so equal keys come out in ascending index order
-template <typename KeyFn>
-__device__ __forceinline__ void block_topk(KeyFn key, int n, int k, u64* comp, uint32_t* hist, uint32_t* sh, uint32_t* wcnt) {
+// ---- top-k of key(0..n-1) into comp[0..1023] (sorted descending; entries >= min(k, n) are zero).  composite(i) =
+//      key << 32 | (0xffffffff - index): equal keys come out in ascending index order.  Streaming form: key(i) is evaluated once
+//      per pass, so the source must be cheap to re-read (LDS) -- the register-resident form below is the one for global memory.
+template <typename KeyFn, typename CompFn>
+__device__ __forceinline__ void block_topk(KeyFn key, CompFn composite, int n, int k, u64* comp, uint32_t* hist, uint32_t* sh, uint32_t* wcnt) {
   comp[threadIdx.x] = 0ull;
   __syncthreads();
   if (n <= k) {
-    for (int i = threadIdx.x; i < n; i += TK_THREADS) comp[i] = ((u64)key(i) << 32) | (u64)(0xffffffffu - (uint32_t)i);
+    for (int i = threadIdx.x; i < n; i += TK_THREADS) comp[i] = composite(i);
     __syncthreads();
   } else {
     uint32_t thr, rem;
@@ -135,10 +136,10 @@ __device__ __forceinline__ void block_topk(KeyFn key, int n, int k, u64* comp, u
         if (w < wave) { wg += cg; we += ce; }
         tg += cg; te += ce;
       }
-      if (gt) comp[base_gt + wg + (uint32_t)__popcll(bg & lt)] = ((u64)kk << 32) | (u64)(0xffffffffu - (uint32_t)i);
+      if (gt) comp[base_gt + wg + (uint32_t)__popcll(bg & lt)] = composite(i);
       if (eq) {
         const uint32_t rank = base_eq + we + (uint32_t)__popcll(be & lt);
-        if (rank < rem) comp[ngt + rank] = ((u64)kk << 32) | (u64)(0xffffffffu - (uint32_t)i);
+        if (rank < rem) comp[ngt + rank] = composite(i);
       }
       base_gt += tg;
       base_eq += te;
@@ -146,6 +147,104 @@ __device__ __forceinline__ void block_topk(KeyFn key, int n, int k, u64* comp, u
     }
   }
   bitonic_desc<1024>(comp);
+}
+
+// ---- the same for PER * 1024 keys held in REGISTERS: thread t owns elements e = j * 1024 + t (j < PER; coalesced loads, all
+//      PER of them in flight at once -- a single workgroup that re-reads global memory once per pass pays a full memory latency
+//      per element and pass: 784 us for 87 k tokens, measured), e < n valid.  gbase = index of element 0 in the composites.
+template <int PER>
+__device__ __forceinline__ void block_topk_regs(const uint32_t (&kk)[PER], int n, int k, uint32_t gbase, u64* comp, uint32_t* hist,
+                                                uint32_t* sh, uint32_t* wcnt) {
+  comp[threadIdx.x] = 0ull;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (n <= k) {                                    // n <= k <= 1024: only j = 0 holds elements
+    if ((int)threadIdx.x < n) comp[threadIdx.x] = ((u64)kk[0] << 32) | (u64)(0xffffffffu - (gbase + threadIdx.x));
+    __syncthreads();
+  } else {
+    uint32_t prefix = 0, r = (uint32_t)k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+      for (int b = threadIdx.x; b < 256; b += TK_THREADS) hist[b] = 0;
+      __syncthreads();
+      const uint32_t himask = shift == 24 ? 0u : (0xffffffffu << (shift + 8));
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int e = j * TK_THREADS + threadIdx.x;
+        bool live = e < n && (kk[j] & himask) == prefix;
+        const uint32_t bin = (kk[j] >> shift) & 255u;
+        u64 todo = __ballot(live);
+        while (todo) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t lb = (uint32_t)__builtin_amdgcn_readlane((int)bin, leader);
+          const u64 same = __ballot(live && bin == lb);
+          if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+          todo &= ~same;
+          if (live && bin == lb) live = false;
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t cum = 0;
+        int b = 255;
+        for (; b > 0; --b) {
+          if (cum + hist[b] >= r) break;
+          cum += hist[b];
+        }
+        sh[0] = prefix | ((uint32_t)b << shift);
+        sh[1] = r - cum;
+      }
+      __syncthreads();
+      prefix = sh[0];
+      r = sh[1];
+      __syncthreads();
+    }
+    const uint32_t thr = prefix, rem = r, ngt = (uint32_t)k - rem;
+    uint32_t base_gt = 0, base_eq = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = j * TK_THREADS + threadIdx.x;
+      const bool gt = e < n && kk[j] > thr, eq = e < n && kk[j] == thr;
+      const u64 bg = __ballot(gt), be = __ballot(eq);
+      const u64 lt = (1ull << lane) - 1ull;
+      if (lane == 0) { wcnt[wave] = (uint32_t)__popcll(bg); wcnt[16 + wave] = (uint32_t)__popcll(be); }
+      __syncthreads();
+      uint32_t wg = 0, we = 0, tg = 0, te = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const uint32_t cg = wcnt[w], ce = wcnt[16 + w];
+        if (w < wave) { wg += cg; we += ce; }
+        tg += cg; te += ce;
+      }
+      const u64 c = ((u64)kk[j] << 32) | (u64)(0xffffffffu - (gbase + (uint32_t)e));
+      if (gt) comp[base_gt + wg + (uint32_t)__popcll(bg & lt)] = c;
+      if (eq) {
+        const uint32_t rank = base_eq + we + (uint32_t)__popcll(be & lt);
+        if (rank < rem) comp[ngt + rank] = c;
+      }
+      base_gt += tg;
+      base_eq += te;
+      __syncthreads();
+    }
+  }
+  bitonic_desc<1024>(comp);
+}
+
+// Two-stage top-k over a large array: stage 1 = one workgroup per chunk of PER * 1024 elements (register resident) writes its
+// sorted top-k composites to ws[chunk * 1024 ..]; stage 2 = one workgroup per problem gathers (chunks x k) composites into LDS
+// and selects among them (the global top-k is a subset of the union of the chunks' top-k; equal keys keep ascending index
+// order because chunks are index ranges in ascending order and each chunk's list is sorted by (key desc, index asc)).
+#define TK_STAGE2_MAX 12288        // composites stage 2 holds in LDS (96 KiB)
+#define TK_MAX_JOBS 96
+struct TkJobs {
+  int njobs, nseg;
+  int seg_first[8], seg_jobs[8], seg_k[8], seg_n[8], seg_mode[8];     // mode 0: key = x, 1: key = sigmoid(x)
+  int start[TK_MAX_JOBS], n[TK_MAX_JOBS], seg[TK_MAX_JOBS];
+};
+
+__device__ __forceinline__ void stage2_gather(const u64* __restrict__ ws, int first_job, int njobs, int k, u64* lds) {
+  const int m = njobs * k;
+  for (int i = threadIdx.x; i < m; i += TK_THREADS) lds[i] = ws[(size_t)(first_job + i / k) * 1024 + (i % k)];
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------- encoder proposals
@@ -169,27 +268,46 @@ __global__ __launch_bounds__(256) void enc_finalize_kernel(const float* __restri
   *reinterpret_cast<float4*>(xyxy + 4 * (size_t)t) = b;
 }
 
-// workgroup l < L: level l's candidates cand[l*k .. +k); workgroup L: the fallback list alt[0 .. k_alt)
-__global__ __launch_bounds__(TK_THREADS) void proposal_topk_kernel(const float* __restrict__ logit, int T, TkLevels lv, int k, int k_alt,
-                                                                   int32_t* __restrict__ cand, int32_t* __restrict__ alt) {
+// stage 1: one workgroup per chunk of a level (key = sigmoid(logit)) or of the whole token range (fallback list, key = logit)
+template <int PER>
+__global__ __launch_bounds__(TK_THREADS) void topk_stage1_kernel(const float* __restrict__ x, TkJobs jobs, u64* __restrict__ ws) {
+  __shared__ u64 comp[1024];
+  __shared__ uint32_t hist[256], sh[2], wcnt[32];
+  const int job = blockIdx.x, seg = jobs.seg[job], start = jobs.start[job], n = jobs.n[job];
+  const bool sig = jobs.seg_mode[seg] != 0;
+  uint32_t kk[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = j * TK_THREADS + threadIdx.x;
+    const float v = e < n ? x[start + e] : 0.f;
+    kk[j] = e < n ? ordkey(sig ? sigmoid_f(v) : v) : 0u;
+  }
+  block_topk_regs<PER>(kk, n, jobs.seg_k[seg], (uint32_t)start, comp, hist, sh, wcnt);
+  ws[(size_t)job * 1024 + threadIdx.x] = comp[threadIdx.x];
+}
+
+// stage 2: workgroup l < L: level l's candidates cand[l*k .. +k); workgroup L: the fallback list alt[0 .. k_alt)
+__global__ __launch_bounds__(TK_THREADS) void proposal_topk2_kernel(const u64* __restrict__ ws, TkJobs jobs, TkLevels lv, int k, int k_alt,
+                                                                    int32_t* __restrict__ cand, int32_t* __restrict__ alt) {
+  extern __shared__ u64 lds[];
   __shared__ u64 comp[1024];
   __shared__ uint32_t hist[256], sh[2], wcnt[32];
   const int l = blockIdx.x;
+  const int kk = jobs.seg_k[l], m = jobs.seg_jobs[l] * kk;
+  stage2_gather(ws, jobs.seg_first[l], jobs.seg_jobs[l], kk, lds);
+  auto key = [&](int i) { return (uint32_t)(lds[i] >> 32); };
+  auto composite = [&](int i) { return lds[i]; };
+  block_topk(key, composite, m, kk, comp, hist, sh, wcnt);
   if (l == lv.L) {
-    auto key = [&](int i) { return ordkey(logit[i]); };
-    block_topk(key, T, k_alt, comp, hist, sh, wcnt);
     for (int r = threadIdx.x; r < k_alt; r += TK_THREADS) alt[r] = (int32_t)(0xffffffffu - (uint32_t)(comp[r] & 0xffffffffull));
     return;
   }
   const int start = lv.start[l], n = lv.n[l];
-  const float* x = logit + start;
-  auto key = [&](int i) { return ordkey(sigmoid_f(x[i])); };
-  block_topk(key, n, k, comp, hist, sh, wcnt);
   const int own = n < k ? n : k;
   for (int r = threadIdx.x; r < k; r += TK_THREADS) {
     int idx;
     if (r < own) {
-      idx = start + (int)(0xffffffffu - (uint32_t)(comp[r] & 0xffffffffull));
+      idx = (int)(0xffffffffu - (uint32_t)(comp[r] & 0xffffffffull));      // composites carry the token index
     } else {                       // torch.topk over sigmoid * level_mask: the zero scores of OTHER levels, lowest index first
       const int e = r - n;
       idx = e >= start ? e + n : e;
@@ -395,15 +513,36 @@ __global__ __launch_bounds__(TK_THREADS) void class_sort_kernel(const float* __r
   }
 }
 
-// one workgroup: top-k of the NMS survivors over all (class, rank) pairs; suppressed pairs score -1 (fast_rcnn.py:192-201)
-__global__ __launch_bounds__(TK_THREADS) void det_topk_kernel(const float* __restrict__ sorted, const uint8_t* __restrict__ keep,
-                                                              const int32_t* __restrict__ order, const float* __restrict__ xyxy, int n, int Q,
-                                                              int k, float* __restrict__ det_boxes, float* __restrict__ det_scores,
-                                                              long long* __restrict__ det_classes, long long* __restrict__ det_query) {
+// top-k of the NMS survivors over all (class, rank) pairs; suppressed pairs score -1 (fast_rcnn.py:192-201).  Stage 1: one
+// workgroup per PER * 1024 pairs; stage 2: one workgroup over the chunks' lists
+template <int PER>
+__global__ __launch_bounds__(TK_THREADS) void det_topk1_kernel(const float* __restrict__ sorted, const uint8_t* __restrict__ keep, int total,
+                                                               int k, u64* __restrict__ ws) {
   __shared__ u64 comp[1024];
   __shared__ uint32_t hist[256], sh[2], wcnt[32];
-  auto key = [&](int i) { return ordkey(keep[i] ? sorted[i] : -1.f); };
-  block_topk(key, n, k, comp, hist, sh, wcnt);
+  const int start = blockIdx.x * (PER * TK_THREADS);
+  const int n = min(PER * TK_THREADS, total - start);
+  uint32_t kk[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = j * TK_THREADS + threadIdx.x;
+    kk[j] = e < n ? ordkey(keep[start + e] ? sorted[start + e] : -1.f) : 0u;
+  }
+  block_topk_regs<PER>(kk, n, k, (uint32_t)start, comp, hist, sh, wcnt);
+  ws[(size_t)blockIdx.x * 1024 + threadIdx.x] = comp[threadIdx.x];
+}
+
+__global__ __launch_bounds__(TK_THREADS) void det_topk2_kernel(const u64* __restrict__ ws, int nchunks, const int32_t* __restrict__ order,
+                                                               const float* __restrict__ xyxy, int Q, int k, float* __restrict__ det_boxes,
+                                                               float* __restrict__ det_scores, long long* __restrict__ det_classes,
+                                                               long long* __restrict__ det_query) {
+  extern __shared__ u64 lds[];
+  __shared__ u64 comp[1024];
+  __shared__ uint32_t hist[256], sh[2], wcnt[32];
+  stage2_gather(ws, 0, nchunks, k, lds);
+  auto key = [&](int i) { return (uint32_t)(lds[i] >> 32); };
+  auto composite = [&](int i) { return lds[i]; };
+  block_topk(key, composite, nchunks * k, k, comp, hist, sh, wcnt);
   for (int r = threadIdx.x; r < k; r += TK_THREADS) {
     const int flat = (int)(0xffffffffu - (uint32_t)(comp[r] & 0xffffffffull));
     const int qi = order[flat];
@@ -431,14 +570,72 @@ extern "C" int ape_hip_enc_finalize(const float* cls2, const float* d, const flo
   return 0;
 }
 
+// elements per stage-1 workgroup: the smallest of 8 / 32 / 64 thousand that keeps (chunks x k) of every problem inside stage 2's LDS
+static int topk_per(const int* seg_n, const int* seg_k, int nseg) {
+  const int pers[3] = {8, 32, 64};
+  for (int pi = 0; pi < 3; ++pi) {
+    bool ok = true;
+    int jobs = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const int c = ceil_div(seg_n[s], pers[pi] * TK_THREADS);
+      ok = ok && (long long)c * seg_k[s] <= TK_STAGE2_MAX;
+      jobs += c;
+    }
+    if (ok && jobs <= TK_MAX_JOBS) return pers[pi];
+  }
+  return 0;
+}
+
+static void set_stage2_attr() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)proposal_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    (void)hipFuncSetAttribute((const void*)det_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    done = true;
+  }
+}
+
+// uint64 words of workspace the two-stage selections need: 1024 per stage-1 workgroup
+extern "C" int ape_hip_topk_workspace_words(int n_total) {
+  // proposals: <= TK_MAX_JOBS workgroups; detections: one per 8 k pairs at most
+  const int det = ceil_div(n_total > 0 ? n_total : 1, 8 * TK_THREADS);
+  return 1024 * (det > TK_MAX_JOBS ? det : TK_MAX_JOBS);
+}
+
 extern "C" int ape_hip_proposal_topk(const float* logit, int T, const int* level_start, const int* level_n, int L, int k, int k_alt,
-                                     int32_t* cand, int32_t* alt, void* stream) {
+                                     uint64_t* workspace, int32_t* cand, int32_t* alt, void* stream) {
   TkLevels lv;
   if (fill_levels(lv, level_start, level_n, L)) return -1;
-  APE_CHECK_ARG(logit && cand && alt && T > 0 && k >= 1 && k <= 1024 && k_alt >= 1 && k_alt <= 1024 && k <= T && k_alt <= T,
+  APE_CHECK_ARG(logit && workspace && cand && alt && T > 0 && k >= 1 && k <= 1024 && k_alt >= 1 && k_alt <= 1024 && k <= T && k_alt <= T,
                 "ape_hip_proposal_topk: 1 <= k, k_alt <= min(1024, T)");
-  hipLaunchKernelGGL(proposal_topk_kernel, dim3(L + 1), dim3(TK_THREADS), 0, (hipStream_t)stream, logit, T, lv, k, k_alt, cand, alt);
-  APE_CHECK_LAUNCH("proposal_topk_kernel");
+  int seg_n[8], seg_k[8];
+  for (int l = 0; l < L; ++l) { seg_n[l] = level_n[l]; seg_k[l] = k; }
+  seg_n[L] = T; seg_k[L] = k_alt;
+  const int per = topk_per(seg_n, seg_k, L + 1);
+  APE_CHECK_ARG(per > 0, "ape_hip_proposal_topk: %d tokens do not fit the two-stage selection", T);
+  TkJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  jobs.nseg = L + 1;
+  const int chunk = per * TK_THREADS;
+  for (int s = 0; s <= L; ++s) {
+    const int base = s < L ? level_start[s] : 0;
+    jobs.seg_first[s] = jobs.njobs; jobs.seg_k[s] = seg_k[s]; jobs.seg_n[s] = seg_n[s]; jobs.seg_mode[s] = s < L ? 1 : 0;
+    for (int c0 = 0; c0 < seg_n[s]; c0 += chunk) {
+      jobs.start[jobs.njobs] = base + c0; jobs.n[jobs.njobs] = seg_n[s] - c0 < chunk ? seg_n[s] - c0 : chunk; jobs.seg[jobs.njobs] = s;
+      ++jobs.njobs;
+    }
+    jobs.seg_jobs[s] = jobs.njobs - jobs.seg_first[s];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  u64* ws = reinterpret_cast<u64*>(workspace);
+  if (per == 8) hipLaunchKernelGGL(topk_stage1_kernel<8>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  else if (per == 32) hipLaunchKernelGGL(topk_stage1_kernel<32>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  else hipLaunchKernelGGL(topk_stage1_kernel<64>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  set_stage2_attr();
+  int mmax = 0;
+  for (int s = 0; s <= L; ++s) mmax = mmax > jobs.seg_jobs[s] * jobs.seg_k[s] ? mmax : jobs.seg_jobs[s] * jobs.seg_k[s];
+  hipLaunchKernelGGL(proposal_topk2_kernel, dim3(L + 1), dim3(TK_THREADS), (size_t)mmax * sizeof(u64), st, ws, jobs, lv, k, k_alt, cand, alt);
+  APE_CHECK_LAUNCH("proposal_topk");
   return 0;
 }
 
@@ -485,11 +682,22 @@ extern "C" int ape_hip_det_sort(const float* logits, int ldl, int Q, int K, cons
 }
 
 extern "C" int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* order, const float* xyxy, int K, int Q, int k,
-                                float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream) {
-  APE_CHECK_ARG(sorted && keep && order && xyxy && det_boxes && det_scores && det_classes && det_query, "ape_hip_det_topk: null pointer");
+                                uint64_t* workspace, float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query,
+                                void* stream) {
+  APE_CHECK_ARG(sorted && keep && order && xyxy && workspace && det_boxes && det_scores && det_classes && det_query, "ape_hip_det_topk: null pointer");
   APE_CHECK_ARG(K > 0 && Q > 0 && (long long)K * Q < 0x7fffffffLL && k >= 1 && k <= 1024 && k <= K * Q, "ape_hip_det_topk: 1 <= k <= min(1024, K*Q)");
-  hipLaunchKernelGGL(det_topk_kernel, dim3(1), dim3(TK_THREADS), 0, (hipStream_t)stream, sorted, keep, order, xyxy, K * Q, Q, k, det_boxes,
-                     det_scores, (long long*)det_classes, (long long*)det_query);
-  APE_CHECK_LAUNCH("det_topk_kernel");
+  const int total = K * Q;
+  const int per = topk_per(&total, &k, 1);
+  APE_CHECK_ARG(per > 0, "ape_hip_det_topk: %d (class, query) pairs with k = %d do not fit the two-stage selection", total, k);
+  const int nchunks = ceil_div(total, per * TK_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  u64* ws = reinterpret_cast<u64*>(workspace);
+  if (per == 8) hipLaunchKernelGGL(det_topk1_kernel<8>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  else if (per == 32) hipLaunchKernelGGL(det_topk1_kernel<32>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  else hipLaunchKernelGGL(det_topk1_kernel<64>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  set_stage2_attr();
+  hipLaunchKernelGGL(det_topk2_kernel, dim3(1), dim3(TK_THREADS), (size_t)nchunks * k * sizeof(u64), st, ws, nchunks, order, xyxy, Q, k,
+                     det_boxes, det_scores, (long long*)det_classes, (long long*)det_query);
+  APE_CHECK_LAUNCH("det_topk");
   return 0;
 }

@@ -836,7 +836,7 @@ def enc_finalize(cls2, d, anchors):
 def select_proposals(logit, xyxy, level_shapes, pre_nms_topk, num_queries, iou_thr):
     """two-stage proposal selection (deformable_transformer_vl.py:565-627): per-level top-k of sigmoid(logit) (ties: lowest
     index), per-level NMS, per-level quota + fill-up, "naive top-k" fallback -> topk_proposals [num_queries] int64.
-    logit [T] fp32, xyxy [T,4] fp32 in [0,1]; five launches, no host synchronisation."""
+    logit [T] fp32, xyxy [T,4] fp32 in [0,1]; seven launches, no host synchronisation."""
     _dev(logit, xyxy)
     T = logit.numel()
     _f32c(logit, "logit", (T,)), _f32c(xyxy, "xyxy", (T, 4))
@@ -849,7 +849,8 @@ def select_proposals(logit, xyxy, level_shapes, pre_nms_topk, num_queries, iou_t
     lib = _lib.load()
     cand = torch.empty((n,), dtype=torch.int32, device=dev)
     alt = torch.empty((k_alt,), dtype=torch.int32, device=dev)
-    _lib.check(lib.ape_hip_proposal_topk(_p(logit), T, starts_c, ns_c, L, k, k_alt, _p(cand), _p(alt), _stream()), "ape_hip_proposal_topk")
+    ws = torch.empty((lib.ape_hip_topk_workspace_words(T),), dtype=torch.int64, device=dev)
+    _lib.check(lib.ape_hip_proposal_topk(_p(logit), T, starts_c, ns_c, L, k, k_alt, _p(ws), _p(cand), _p(alt), _stream()), "ape_hip_proposal_topk")
     boxes_b = torch.empty((n, 4), dtype=torch.float32, device=dev)
     ints = torch.empty((4 * n + L + 1,), dtype=torch.int32, device=dev)
     groups_b, cand_a, lv_a, pos_b, seg = ints[:n], ints[n:2 * n], ints[2 * n:3 * n], ints[3 * n:4 * n], ints[4 * n:]
@@ -894,7 +895,8 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
     k = min(int(topk), K * Q)
     det = dict(det_boxes=torch.empty((k, 4), dtype=torch.float32, device=dev), det_scores=torch.empty((k,), dtype=torch.float32, device=dev),
                det_classes=torch.empty((k,), dtype=torch.int64, device=dev), det_query=torch.empty((k,), dtype=torch.int64, device=dev))
-    rc = lib.ape_hip_det_topk(_p(sorted_scores), _p(keep), _p(order), _p(xyxy), K, Q, k, _p(det["det_boxes"]), _p(det["det_scores"]),
+    ws = torch.empty((lib.ape_hip_topk_workspace_words(K * Q),), dtype=torch.int64, device=dev)
+    rc = lib.ape_hip_det_topk(_p(sorted_scores), _p(keep), _p(order), _p(xyxy), K, Q, k, _p(ws), _p(det["det_boxes"]), _p(det["det_scores"]),
                               _p(det["det_classes"]), _p(det["det_query"]), _stream())
     _lib.check(rc, "ape_hip_det_topk")
     return det

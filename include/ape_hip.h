@@ -354,8 +354,9 @@ int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* table, int 
                          int ldo, int B, int L, int Lp, int W, int vocab, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Data-dependent selections as fixed-shape device code -- csrc/topk.hip.  One 1024-thread workgroup per selection problem:
- * radix select over order-preserving keys + stable compaction (ties: lowest index) + bitonic sort in LDS.
+ * Data-dependent selections as fixed-shape device code -- csrc/topk.hip.  Radix select over order-preserving keys + stable
+ * compaction (ties: lowest index) + bitonic sort in LDS by 1024-thread workgroups; large arrays in two stages (one workgroup per
+ * register-resident chunk, then one workgroup per problem over the chunks' lists; `workspace`: ape_hip_topk_workspace_words).
  *
  * Encoder proposals (ape/modeling/ape_deta/deformable_transformer_vl.py:503-533, 565-627); level l owns tokens
  * level_start[l] .. +level_n[l] (HOST int arrays, L <= 5):
@@ -379,8 +380,9 @@ int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* table, int 
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_enc_finalize(const float* cls2, const float* d, const float* anchors, int T, float* enc_class, float* enc_coord,
                          float* xyxy, void* stream);
+int ape_hip_topk_workspace_words(int n_total); /* uint64 words of `workspace` for proposal_topk (any T) / det_topk (n_total = K*Q) */
 int ape_hip_proposal_topk(const float* logit, int T, const int* level_start, const int* level_n, int L, int k, int k_alt,
-                          int32_t* cand, int32_t* alt, void* stream);
+                          uint64_t* workspace, int32_t* cand, int32_t* alt, void* stream);
 int ape_hip_proposal_order(const int32_t* cand, int n, const float* logit, const float* xyxy, const int* level_start,
                            const int* level_n, int L, float* boxes_b, int32_t* groups_b, int32_t* seg, int32_t* cand_a,
                            int32_t* lv_a, int32_t* pos_b, void* stream);
@@ -390,7 +392,7 @@ int ape_hip_proposal_quota(const int32_t* cand_a, const int32_t* lv_a, const int
 int ape_hip_det_sort(const float* logits, int ldl, int Q, int K, const float* boxes, const float* scale, float thresh, float* xyxy,
                      uint8_t* finite, float* sorted, int32_t* order, uint8_t* valid, void* stream);
 int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* order, const float* xyxy, int K, int Q, int k,
-                     float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
+                     uint64_t* workspace, float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
 
 #ifdef __cplusplus
 }
