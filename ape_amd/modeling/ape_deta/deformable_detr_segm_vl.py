@@ -321,8 +321,10 @@ class DeformableDETRSegmVL(nn.Module):
 
     # ------------------------------------------------------------------ the hot path, one image
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
-                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None, geo=None):
+                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None, geo=None, encoder_done=None):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
+        encoder_done: optional torch.cuda.Event recorded on the current stream as soon as the encoder memory exists (the runtime
+        orders the next step's ViT behind it, runtime.GraphedForward late_vit).
         instance: run the detection branch; semantic: metadata dict (entity, thing_classes, stuff_classes) to run the
         semantic branch; detector_columns: ("first", n) | ("ids", LongTensor) restriction of the detector's classes;
         vit_feat: this image's rows of a batched ViT pass (backbone.net.forward_tokens on a list of images);
@@ -371,6 +373,8 @@ class DeformableDETRSegmVL(nn.Module):
             return ops.gemm(y, P["maskc"], None)                                                      # [H0*W0, 256]
 
         def after_encoder(memory):
+            if encoder_done is not None:
+                encoder_done.record()
             if want_masks or semantic is not None or panoptic:
                 mask_job.append(ops.fork(lambda: mask_features(memory)))
 

@@ -79,6 +79,8 @@ class GraphedForward:
         if mask_format not in ("bitmask", "rle"):
             raise ValueError("GraphedForward: mask_format is 'bitmask' or 'rle'")
         self.mask_format, self.rle_cap = mask_format, int(rle_cap)
+        # pipelined steps: start the ViT branch behind the tails' encoders (see _run_entry); APE_PIPE_LATE_VIT=0|1 overrides
+        self.late_vit = os.environ.get("APE_PIPE_LATE_VIT", "0") == "1"
         self._graphs = {}
         self._copy_stream = None
 
@@ -94,12 +96,13 @@ class GraphedForward:
             pass
 
     # ------------------------------------------------------------------ device work of one image
-    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None, geo=None, frame=None):
+    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None, geo=None, frame=None, encoder_done=None):
         """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame).
         frame (any_size): device vector [8] = (sx, sy, sx, sy, width, height, width, height) of the output frame."""
         mv = self.mv
         h, w = image.shape[-2:]
-        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo)
+        out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo,
+                                encoder_done=encoder_done)
         if frame is None:
             boxes = out["det_boxes"].clone()
             boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
@@ -118,10 +121,10 @@ class GraphedForward:
         masks128 = out.get("det_masks128")
         return rec[order].contiguous(), (masks128[order].contiguous() if masks128 is not None else None), boxes[order].contiguous()
 
-    def _tail(self, e, b, vit_feat):
+    def _tail(self, e, b, vit_feat, encoder_done=None):
         height, width = e.size
         return self._device_part(e.images[b], e.text, height, width, e.prompt, vit_feat,
-                                 e.sgeo[b] if self.any_size else None, e.frame[b] if self.any_size else None)
+                                 e.sgeo[b] if self.any_size else None, e.frame[b] if self.any_size else None, encoder_done)
 
     def _run_entry(self, e):
         """the device work of one step of entry `e` on its static buffers: (ViT of the images) + B tails"""
@@ -141,10 +144,28 @@ class GraphedForward:
             # ViT of the NEW images || tails of the features the previous replay left in e.feat.  Branches do not fork again
             # (nested fork/join inside image branches made hipStreamEndCapture crash on this ROCm).
             with ops.inline_forks():
-                vjob = ops.fork(lambda: net.forward_tokens(e.images if B > 1 else e.images[0], mv._mean, mv._std), force=True)
                 feats = [e.feat[b * n_tok:(b + 1) * n_tok] for b in range(B)]
-                jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
-                outs = [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
+                if self.late_vit:
+                    # ViT of the new images ordered BEHIND the encoders of the tails: the tails' GEMM-bound first half (FPN,
+                    # encoder) then has the chip to itself, and the GEMM-bound ViT overlaps their latency-bound second half
+                    # (selection, decoder, heads, NMS, masks) instead of both heavy phases fighting for the CUs first and
+                    # the light chains running alone at the end.  Every tail on a side stream, so the ViT branch depends on
+                    # nothing but the encoder events.
+                    done = [torch.cuda.Event() for _ in range(B)]
+                    jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b], done[b]), force=True) for b in range(B)]
+
+                    def vit():
+                        cur = torch.cuda.current_stream()
+                        for ev in done:
+                            cur.wait_event(ev)
+                        return net.forward_tokens(e.images if B > 1 else e.images[0], mv._mean, mv._std)
+
+                    vjob = ops.fork(vit, force=True)
+                    outs = [j.join() for j in jobs]
+                else:
+                    vjob = ops.fork(lambda: net.forward_tokens(e.images if B > 1 else e.images[0], mv._mean, mv._std), force=True)
+                    jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
+                    outs = [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
                 e.feat.copy_(vjob.join())             # behind every tail: the next replay reads the new features
             return outs
         if B == 1:
