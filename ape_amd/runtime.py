@@ -50,11 +50,12 @@ _RETIRED = []
 
 class _Ticket:
     """handle of a submitted step (weak-referenceable, unlike SimpleNamespace)"""
-    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "runs", "mask_runs", "__weakref__")
+    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "runs", "mask_runs", "sem_labels", "__weakref__")
 
     def __init__(self, entry, single, frames):
         self.entry, self.single, self.frames = entry, single, frames      # frames: [(height, width)] of the output masks
         self.slot, self.ready, self.rec6, self.records = None, False, None, None
+        self.sem_labels = None                        # GraphedForward(semantic=...): per-image label maps [fh, fw] int16 (host)
         self.runs, self.mask_runs = None, None        # mask_format="rle": (device run lengths [B,k,cap], run counts [B,k]); all ranks'
 
 
@@ -63,7 +64,7 @@ class GraphedForward:
     SLOTS = 2
 
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
-                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096):
+                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096, semantic=None):
         self.mv = model_vision
         self.batch_vit = batch_vit
         self.pipeline = bool(pipeline)
@@ -79,6 +80,13 @@ class GraphedForward:
         if mask_format not in ("bitmask", "rle"):
             raise ValueError("GraphedForward: mask_format is 'bitmask' or 'rle'")
         self.mask_format, self.rle_cap = mask_format, int(rle_cap)
+        # semantic branch inside the captured step (deformable_detr_segm_vl.py:628-666 + sem_seg_postprocess :875-918): `semantic`
+        # = the dataset's metadata dict (thing_classes / stuff_classes / entity, as model.forward builds it).  The [K', H, W] score
+        # volume stays on the device (1.3 GB per 1536^2 image with 134 classes); what leaves is its per-pixel argmax -- the
+        # label map every semantic evaluator reduces the scores to -- as int16 [H, W] (`ticket.sem_labels`).  Per-size graphs only.
+        self.semantic = semantic
+        if semantic is not None and self.any_size:
+            raise NotImplementedError("GraphedForward: the semantic branch needs per-size graphs (any_size=False)")
         # pipelined steps: start the ViT branch behind the tails' encoders (see _run_entry); APE_PIPE_LATE_VIT=0|1 overrides
         self.late_vit = os.environ.get("APE_PIPE_LATE_VIT", "0") == "1"
         self._graphs = {}
@@ -102,7 +110,17 @@ class GraphedForward:
         mv = self.mv
         h, w = image.shape[-2:]
         out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo,
-                                encoder_done=encoder_done)
+                                encoder_done=encoder_done, semantic=self.semantic)
+        labels = None
+        if self.semantic is not None:
+            import math
+            from . import ops
+            r = ops.bilinear_resize(out["sem_seg"], height, width)                           # sem_seg_postprocess (:916)
+            meta = self.semantic
+            if (mv.eval_dataset_id >= 0 and meta.get("entity") == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
+                    and mv.stuff_prob_thing > 0):                                            # (:654-663)
+                r[0] = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
+            labels = r.argmax(0).to(torch.int16).contiguous()                                # [height, width]
         if frame is None:
             boxes = out["det_boxes"].clone()
             boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
@@ -119,7 +137,7 @@ class GraphedForward:
         # ~1 MB per mask with a boolean index (a 105 MB host copy per image whenever one detection is dropped)
         order = torch.sort((~keep).to(torch.int8), stable=True)[1]
         masks128 = out.get("det_masks128")
-        return rec[order].contiguous(), (masks128[order].contiguous() if masks128 is not None else None), boxes[order].contiguous()
+        return rec[order].contiguous(), (masks128[order].contiguous() if masks128 is not None else None), boxes[order].contiguous(), labels
 
     def _tail(self, e, b, vit_feat, encoder_done=None):
         height, width = e.size
@@ -269,6 +287,8 @@ class GraphedForward:
             s.d_nruns = torch.zeros((B, k), dtype=torch.int32, device=dev) if rle else None
             s.h_runs = torch.empty((B, k, self.rle_cap), dtype=torch.int32, pin_memory=True) if rle else None
             s.h_nruns = torch.zeros((B, k), dtype=torch.int32, pin_memory=True) if rle else None
+            s.d_sem = torch.empty((B, e.maxpix), dtype=torch.int16, device=dev) if self.semantic is not None else None
+            s.h_sem = torch.empty((B, e.maxpix), dtype=torch.int16, pin_memory=True) if self.semantic is not None else None
             s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
             s.busy = False
             e.slots.append(s)
@@ -355,8 +375,10 @@ class GraphedForward:
             cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
             has_masks = s.d_masks is not None and outs[0][1] is not None
             k = e.k
-            for b, (rec, masks128, boxes) in enumerate(outs):
+            for b, (rec, masks128, boxes, labels) in enumerate(outs):
                 s.d_rec[b].copy_(rec, non_blocking=True)
+                if labels is not None:
+                    s.d_sem[b, : labels.numel()].copy_(labels.reshape(-1), non_blocking=True)
                 if has_masks:
                     fh, fw = completes.frames[b]
                     pasted = ops.paste_bits(masks128, boxes, fh, fw, out=s.d_masks[b, : k * fh * fw].view(k, fh, fw))   # detector_postprocess (:869-871)
@@ -366,6 +388,8 @@ class GraphedForward:
             with torch.cuda.stream(self._copy_stream):
                 self._copy_stream.wait_event(s.computed)
                 s.h_rec.copy_(s.d_rec, non_blocking=True)
+                if s.d_sem is not None:
+                    s.h_sem.copy_(s.d_sem, non_blocking=True)
                 if has_masks and s.d_runs is not None:
                     s.h_runs.copy_(s.d_runs, non_blocking=True)
                     s.h_nruns.copy_(s.d_nruns, non_blocking=True)
@@ -425,6 +449,8 @@ class GraphedForward:
                 masks = s.h_masks[b, : k * fh * fw].view(k, fh, fw)[:n].view(torch.bool)   # zero-copy
             insts.append(make_instances((fh, fw), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(), masks,
                                         query_index=hr[:n, 6].long(), **extra))
+        if s.h_sem is not None:       # label maps (views of the slot's pinned buffer, valid like pred_masks)
+            ticket.sem_labels = [s.h_sem[b, : fh * fw].view(fh, fw) for b, (fh, fw) in enumerate(ticket.frames)]
         if ticket.single:
             return insts[0], ticket.rec6
         return insts, ticket.rec6

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--stream", choices=["square", "coco"], default="square",
                     help="square: S x S images (BASELINE config 2); coco: the synthetic COCO-shaped stream of config 4 -- 1000 sizes, "
                          "long side S, short side U[480, S] (seed 5), served by ONE size-agnostic graph (GraphedForward any_size)")
+    ap.add_argument("--semantic", action="store_true",
+                    help="BASELINE config 5 flavour: semantic branch on (80 thing + 54 stuff classes incl. the leading 'things' class; the "
+                         "text bank has 133 rows), captured with the step; label maps (per-pixel argmax) leave the device")
     ap.add_argument("--no-batch-vit", action="store_true", help="one ViT pass per image instead of one per step")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="no software pipeline over steps (ViT of step i+1 || tails of step i inside one graph)")
@@ -214,8 +217,15 @@ def main():
     from ape_amd.dp import DataParallelRunner
 
     B = args.images_per_step
+    sem_meta = None
+    if args.semantic:
+        things, stuff = [f"thing{i}" for i in range(80)], ["things"] + [f"stuff{i}" for i in range(53)]
+        mv.semantic_on = True
+        mv.set_metadata(0, name="bench_thing_stuff", thing_classes=things, stuff_classes=stuff)
+        sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+        args.classes = len(things) + len(stuff) - 1
     graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
-                             pipeline=not args.no_pipeline, any_size=args.stream == "coco")
+                             pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta)
     dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev)
     # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
@@ -284,7 +294,7 @@ def main():
             batch = [images[(i * B + b) % len(images)].contiguous() for b in range(B)]
             x = mv.backbone.net.forward_tokens(batch if B > 1 else batch[0], mv._mean, mv._std)
             for b in range(B):
-                out = mv.forward_single(batch[b], text, vit_feat=x[b * n_tok:(b + 1) * n_tok])
+                out = mv.forward_single(batch[b], text, vit_feat=x[b * n_tok:(b + 1) * n_tok], semantic=sem_meta)
                 hh, ww = batch[b].shape[-2:]
                 mv.postprocess_instance(out, (hh, ww), hh, ww)
 
@@ -309,7 +319,8 @@ def main():
             "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
                                    f"{B} images, everything after it one batch-1 forward per image ({B} parallel branches of one "
                                    f"hipGraph); {args.classes} classes (name prompt), masks on, top-{mv.test_topk_per_image} detections "
-                                   "per image incl. their full-resolution masks on the host; seeded synthetic weights",
+                                   "per image incl. their full-resolution masks on the host; seeded synthetic weights"
+                                   + ("; semantic branch on (54 stuff columns), label maps on the host" if args.semantic else ""),
                        "parallelism": f"dp{world}", "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B,
                        "batched_vit": not args.no_batch_vit, "stream": args.stream,
                        "software_pipeline": (not args.no_pipeline) and "ViT of step i+1 overlaps the tails of step i; the last step is flushed inside the timed region"},

@@ -141,6 +141,36 @@ def test_semantic_branch_on_gpu():
     M.check_semantic(model, orc, image_c, text_c, gold, "cuda")
 
 
+def test_semantic_branch_in_graph_runtime():
+    """GraphedForward(semantic=meta): the semantic branch captured with the step; the label map (per-pixel argmax of the
+    [K', H, W] scores) equals the argmax of model.forward()'s sem_seg, plain and software-pipelined"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_semantic", torch.float32)
+    mv = model.model_vision
+    meta = gold["semantic_meta"]
+    mv.semantic_on = True
+    mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
+    H, W = gold["out_hw"]
+    res = model([{"image": image_c, "height": H, "width": W, "text_features": text_c}])[0]
+    ref = res["sem_seg"].argmax(0).cpu()
+    sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    for kw in (dict(), dict(images_per_step=2, pipeline=True)):
+        run = GraphedForward(mv, semantic=sem_meta, **kw)
+        B = kw.get("images_per_step", 1)
+        tickets = [run.submit([image] * B if B > 1 else image, text, H, W) for _ in range(2)]      # second submit replays the graph
+        for t in tickets:
+            inst, _ = run.result(t)
+            for lab in t.sem_labels:
+                assert lab.shape == (H, W) and lab.dtype == torch.int16
+                agree = (lab.long() == ref).float().mean().item()
+                assert agree > 0.999, (kw, agree)
+        first = inst[0] if B > 1 else inst
+        frac = U.match_detections(first.pred_boxes, first.scores, first.pred_classes, res["instances"].pred_boxes, res["instances"].scores,
+                                  res["instances"].pred_classes)
+        assert frac >= 0.99
+
+
 def test_parallel_images_in_one_graph():
     """images_per_step = 2: two batch-1 forwards as parallel branches of one hipGraph give the same detections and masks
     as two sequential single-image replays"""
