@@ -1,0 +1,212 @@
+// ffn_fused.hip -- EXPERIMENTAL (opt-in: APE_FFN_FUSED=1; written at the end of round 2 without GPU time left to validate it;
+// the layout design is validated at index level by tests/test_ffn_fused_layout.py, the kernel by
+// tests/test_ops_gpu.py::test_ffn_fused under APE_TEST_EXPERIMENTAL=1).
+//
+// Encoder FFN of the deformable transformer (detrex FFN, ape/modeling/ape_deta/deformable_transformer_vl.py:45-54) in ONE kernel:
+//     y = x + relu(x W1^T + b1) W2^T + b2         x [M, 256] bf16, W1 [HID, 256], W2 [256, HID], HID = 2048, M = 87 296
+// The two-GEMM form writes the [M, HID] hidden activations (357 MB per layer) and reads them back: FFN1 is bound by that write
+// (182 us), FFN2 by reading it (135 us).  Here the hidden tile never leaves the registers -- the flash-attention pattern of
+// attention.hip with relu() in the place of softmax:
+//   * a workgroup = 4 waves = 128 token rows; a wave keeps its 32 rows of x as 2 x 8 MFMA B-operand fragments (64 VGPRs, loaded
+//     once) and its 32 x 256 output tile as 16 x 2 accumulators (128 VGPRs);
+//   * loop over the hidden dimension in chunks of 64: W1[chunk, :] (32 KB) and W2[:, chunk] (32 KB) stream HBM/L2 -> LDS with
+//     global_load_lds (two stages; the next chunk lands while this one is consumed);
+//   * first MFMA  H^T[hidden][token] = W1c . x^T : after bias + ReLU, a lane's accumulator registers (token lane & 15, hidden
+//     4 g .. 4 g + 3 of each 16-row tile, g = lane >> 4) ARE the B operand of the second MFMA  Y^T[channel][token] += W2c . H^T
+//     under a permuted k order (e < 4 -> hidden (2kk) 16 + 4g + e, e >= 4 -> (2kk + 1) 16 + 4g + e - 4), which is applied
+//     identically to the W2 fragment reads (two 8-byte halves) -- no LDS round trip, no cross-lane traffic for H; H is rounded to
+//     bf16 exactly where the two-GEMM form rounds it;
+//   * the W2 rows are permuted on their way into LDS (row ot*16 + m holds channel (m >> 2) * 64 + ot * 4 + (m & 3)) so that a lane
+//     ends up with 64 CONSECUTIVE output channels of its token: bias, residual and the bf16 store work on 16-byte pieces.
+//   * LDS images: W1 rows are 512 B with the 16-byte chunk XOR-ed by (row & 31), W2 rows 128 B with chunk ^ ((row >> 1) & 7); the
+//     XOR is applied to the LDS-DMA source address (its destination is lane-linear) and to the fragment read address.
+// Per layer: 183 GFLOP on the MFMA pipe, 44.7 MB read + 44.7 MB written instead of 2 x 357 MB more.
+#include "common.h"
+#include "../../include/ape_hip.h"
+
+typedef __attribute__((address_space(3))) void ff_lds_void_t;
+typedef const __attribute__((address_space(1))) void ff_gbl_void_t;
+
+#define FF_K 256
+#define FF_HC 64
+#define FF_N 256
+#define FF_BM 128
+#define FF_STAGE 65536   // W1 chunk (32 KB) + W2 chunk (32 KB)
+
+struct FfnParams {
+  const bf16_t* X; int ldx;
+  const bf16_t* W1; int ldw1;
+  const float* b1;
+  const bf16_t* W2; int ldw2;
+  const float* b2;
+  const bf16_t* R; int ldr;      // residual (may be NULL)
+  bf16_t* Y; int ldy;
+  int M, HID;
+};
+
+__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * FF_STAGE);
+  float* sb2 = sb1 + p.HID;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fm = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * FF_BM + wave * 32;
+
+  for (int i = tid; i < p.HID; i += 256) sb1[i] = p.b1[i];
+  for (int i = tid; i < FF_N; i += 256) sb2[i] = p.b2[i];
+
+  // ---- x fragments: B operand of the first MFMA (token = rt*16 + fm, k = ks*32 + 8g .. +8)
+  bf16x8_t xf[2][8];
+  int tok[2];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    tok[rt] = row0 + rt * 16 + fm;
+    const bf16_t* xp = p.X + (size_t)(tok[rt] < p.M ? tok[rt] : p.M - 1) * p.ldx + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xf[rt][ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(xp + ks * 32));
+  }
+
+  // ---- LDS-DMA sources: wave w issues instructions i = 8w .. 8w+7 of each image (64 lanes x 16 B = 1 KB each)
+  uint32_t w1off[8], w2off[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = wave * 8 + j;
+    {
+      const int rho = 2 * i + (lane >> 5), qp = lane & 31;
+      const int q = qp ^ (rho & 31);
+      w1off[j] = (uint32_t)rho * (uint32_t)p.ldw1 + (uint32_t)q * 8u;            // + chunk * 64 * ldw1
+    }
+    {
+      const int rho = 8 * i + (lane >> 3), qp = lane & 7;
+      const int q = qp ^ ((rho >> 1) & 7);
+      const int ot = rho >> 4, m = rho & 15;
+      const int ch = (m >> 2) * 64 + ot * 4 + (m & 3);
+      w2off[j] = (uint32_t)ch * (uint32_t)p.ldw2 + (uint32_t)q * 8u;             // + chunk * 64
+    }
+  }
+  auto issue = [&](int c, int s) __attribute__((always_inline)) {
+    unsigned char* d1 = smem + s * FF_STAGE + wave * 8192;
+    unsigned char* d2 = smem + s * FF_STAGE + 32768 + wave * 8192;
+    const bf16_t* s1 = p.W1 + (size_t)c * FF_HC * p.ldw1;
+    const bf16_t* s2 = p.W2 + (size_t)c * FF_HC;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __builtin_amdgcn_global_load_lds((ff_gbl_void_t*)(s1 + w1off[j]), (ff_lds_void_t*)(d1 + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((ff_gbl_void_t*)(s2 + w2off[j]), (ff_lds_void_t*)(d2 + j * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4_t yacc[16][2];
+#pragma unroll
+  for (int ot = 0; ot < 16; ++ot)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) yacc[ot][rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nc = p.HID / FF_HC;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int c = 0; c < nc; ++c) {
+    const int s = c & 1;
+    if (c + 1 < nc) issue(c + 1, s ^ 1);          // the other stage was released by the barrier that ended chunk c - 1
+    const unsigned char* i1 = smem + s * FF_STAGE;
+    const unsigned char* i2 = i1 + 32768;
+
+    // ---- H^T = W1c . x^T : 4 hidden tiles x 2 token tiles, 8 k steps
+    f32x4_t hacc[4][2];
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) {
+      hacc[ht][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      hacc[ht][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int rho = ht * 16 + fm;
+      const unsigned char* rowp = i1 + rho * 512;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(rowp + (((ks * 4 + g) ^ (rho & 31)) << 4)));
+        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[0][ks], hacc[ht][0], 0, 0, 0);
+        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[1][ks], hacc[ht][1], 0, 0, 0);
+      }
+      // bias + ReLU: lane holds hidden c*64 + ht*16 + 4g .. +3 of token rt*16 + fm
+      const float4 b = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        hacc[ht][rt][0] = fmaxf(hacc[ht][rt][0] + b.x, 0.f);
+        hacc[ht][rt][1] = fmaxf(hacc[ht][rt][1] + b.y, 0.f);
+        hacc[ht][rt][2] = fmaxf(hacc[ht][rt][2] + b.z, 0.f);
+        hacc[ht][rt][3] = fmaxf(hacc[ht][rt][3] + b.w, 0.f);
+      }
+    }
+    // ---- Y^T += W2c . H^T : the activations are the B operand (k step kk = hidden tiles 2kk, 2kk + 1, permuted inside the step)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t hb[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const uint4 u = make_uint4(pack2bf(hacc[2 * kk][rt][0], hacc[2 * kk][rt][1]), pack2bf(hacc[2 * kk][rt][2], hacc[2 * kk][rt][3]),
+                                   pack2bf(hacc[2 * kk + 1][rt][0], hacc[2 * kk + 1][rt][1]),
+                                   pack2bf(hacc[2 * kk + 1][rt][2], hacc[2 * kk + 1][rt][3]));
+        hb[rt] = __builtin_bit_cast(bf16x8_t, u);
+      }
+#pragma unroll
+      for (int ot = 0; ot < 16; ++ot) {
+        const int rho = ot * 16 + fm;
+        const int sw = (rho >> 1) & 7;
+        const unsigned char* rowp = i2 + rho * 128 + (g & 1) * 8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + (g >> 1)) ^ sw) << 4));
+        const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + 2 + (g >> 1)) ^ sw) << 4));
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        yacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[0], yacc[ot][0], 0, 0, 0);
+        yacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[1], yacc[ot][1], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (for this wave's share; the barrier covers the others)
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns channels g*64 .. g*64 + 63 of tokens tok[0], tok[1]; 16-byte pieces (ot pair 2q, 2q+1 = 8 channels)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    if (tok[rt] >= p.M) continue;
+    bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 64;
+    const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tok[rt] * p.ldr + g * 64 : nullptr;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 ba = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8);
+      const float4 bb = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8 + 4);
+      float v[8] = {yacc[2 * q][rt][0] + ba.x, yacc[2 * q][rt][1] + ba.y, yacc[2 * q][rt][2] + ba.z, yacc[2 * q][rt][3] + ba.w,
+                    yacc[2 * q + 1][rt][0] + bb.x, yacc[2 * q + 1][rt][1] + bb.y, yacc[2 * q + 1][rt][2] + bb.z, yacc[2 * q + 1][rt][3] + bb.w};
+      if (rp != nullptr) {
+        float r[8];
+        ld8<bf16_t>(rp + q * 8, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      st8<bf16_t>(yp + q * 8, v);
+    }
+  }
+}
+
+extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
+                                 const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, void* stream) {
+  APE_CHECK_ARG(X && W1 && b1 && W2 && b2 && Y && M > 0, "ape_hip_ffn_fused: null pointer / empty problem");
+  APE_CHECK_ARG(K == FF_K && N == FF_N && HID % FF_HC == 0 && HID >= FF_HC && HID <= 4096,
+                "ape_hip_ffn_fused: the kernel is built for 256 -> HID -> 256 with HID %% 64 == 0, HID <= 4096 (got %d -> %d -> %d)", K, HID, N);
+  APE_CHECK_ARG(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
+                "ape_hip_ffn_fused: leading dimensions must be multiples of 8");
+  APE_CHECK_ARG(((uintptr_t)X) % 16 == 0 && ((uintptr_t)W1) % 16 == 0 && ((uintptr_t)W2) % 16 == 0 && ((uintptr_t)Y) % 16 == 0 &&
+                    ((uintptr_t)residual) % 16 == 0 && ((uintptr_t)b1) % 16 == 0 && ((uintptr_t)b2) % 16 == 0,
+                "ape_hip_ffn_fused: 16-byte aligned pointers");
+  APE_CHECK_ARG((size_t)HID * ldw1 * 2 < (1ull << 32) && (size_t)FF_N * ldw2 * 2 < (1ull << 32), "ape_hip_ffn_fused: weights too large for 32-bit offsets");
+  FfnParams p;
+  p.X = (const bf16_t*)X; p.ldx = ldx; p.W1 = (const bf16_t*)W1; p.ldw1 = ldw1; p.b1 = b1; p.W2 = (const bf16_t*)W2; p.ldw2 = ldw2; p.b2 = b2;
+  p.R = (const bf16_t*)residual; p.ldr = ldr; p.Y = (bf16_t*)Y; p.ldy = ldy; p.M = M; p.HID = HID;
+  const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(ffn_fused_kernel, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
+  APE_CHECK_LAUNCH("ffn_fused_kernel");
+  return 0;
+}

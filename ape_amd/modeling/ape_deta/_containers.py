@@ -3,6 +3,8 @@ norms, FFN.layers = Sequential(Sequential(Linear, ReLU, Dropout), Linear, Dropou
 inside detrex MultiheadAttention.attn, ChannelMapper.convs[i].{conv,norm}) so checkpoints of the reference load
 unchanged.  They hold weights and packing logic only -- the arithmetic is in the HIP kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -29,6 +31,10 @@ class FFN(nn.Module):
     def forward_tokens(self, x, dt, out_dtype=None):
         """x + Linear(ReLU(Linear(x)))  (detrex FFN with add_identity)"""
         P = self.packed(dt)
+        if (os.environ.get("APE_FFN_FUSED") == "1" and dt == torch.bfloat16 and (out_dtype or dt) == torch.bfloat16 and x.shape[0] >= 2048
+                and x.shape[1] == 256 and P["w2"].shape[0] == 256 and P["w1"].shape[0] % 64 == 0 and P["w1"].shape[0] <= 4096):
+            # EXPERIMENTAL: one kernel, the hidden activations stay in registers (csrc/ffn_fused.hip); off by default until validated
+            return ops.ffn_fused(x, P["w1"], P["b1"], P["w2"], P["b2"], residual=x)
         h = ops.gemm(x, P["w1"], P["b1"], act=ops.ACT_RELU)
         return ops.gemm(h, P["w2"], P["b2"], residual=x, out_dtype=out_dtype or dt)
 

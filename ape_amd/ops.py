@@ -900,3 +900,27 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
                               _p(det["det_classes"]), _p(det["det_query"]), _stream())
     _lib.check(rc, "ape_hip_det_topk")
     return det
+
+
+def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None):
+    """EXPERIMENTAL (csrc/ffn_fused.hip): residual + relu(x w1^T + b1) w2^T + b2 in one kernel; x [M, 256] bf16, w1 [HID, 256],
+    w2 [256, HID] bf16, biases fp32 -> [M, 256] bf16.  The hidden activations never reach HBM."""
+    _dev(x, w1, w2, b1, b2, residual, out)
+    for t, name in ((x, "x"), (w1, "w1"), (w2, "w2")):
+        _rowmajor(t, name)
+        if t.dtype != torch.bfloat16:
+            raise TypeError(f"ape_amd.ops.ffn_fused: {name} must be bfloat16")
+    M, K = x.shape
+    HID, N = w1.shape[0], w2.shape[0]
+    if w1.shape[1] != K or w2.shape[1] != HID:
+        raise ValueError("ape_amd.ops.ffn_fused: weight shapes do not chain")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        _rowmajor(residual, "residual")
+        if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, N):
+            raise TypeError("ape_amd.ops.ffn_fused: residual must be bfloat16 [M, N]")
+    rc = _lib.load().ape_hip_ffn_fused(_p(x), _ld(x), _p(w1), _ld(w1), _p(_f32vec(b1, "b1")), _p(w2), _ld(w2), _p(_f32vec(b2, "b2")),
+                                      _p(residual), _ld(residual) if residual is not None else 0, _p(out), _ld(out), M, K, HID, N, _stream())
+    _lib.check(rc, "ape_hip_ffn_fused")
+    return out

@@ -394,6 +394,15 @@ int ape_hip_det_sort(const float* logits, int ldl, int Q, int K, const float* bo
 int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* order, const float* xyxy, int K, int Q, int k,
                      uint64_t* workspace, float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * EXPERIMENTAL (not on the default path; opt-in with APE_FFN_FUSED=1): the encoder FFN in one kernel,
+ * y = x + relu(x W1^T + b1) W2^T + b2 (detrex FFN, ape/modeling/ape_deta/deformable_transformer_vl.py:45-54), bf16 in / out,
+ * K = N = 256, HID %% 64 == 0 (<= 4096).  The hidden activations stay in registers as the B operand of the second MFMA
+ * (csrc/ffn_fused.hip); residual may be NULL.
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
+                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -511,3 +511,16 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
     cls = torch.div(flat, Q, rounding_mode="floor")
     qidx = order.reshape(-1)[flat]
     return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)
+
+
+def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None):
+    """the two-GEMM form at the kernel's rounding points: H rounded to bf16, fp32 accumulation, one rounding of the output"""
+    h = torch.relu(x.float() @ w1.float().t() + b1.float()).to(torch.bfloat16)
+    y = h.float() @ w2.float().t() + b2.float()
+    if residual is not None:
+        y = y + residual.float()
+    y = y.to(torch.bfloat16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
