@@ -7,6 +7,8 @@ import torch
 
 try:                                                     # full environment: the real thing
     from detectron2.structures import Boxes, Instances   # noqa: F401
+    if not (hasattr(Instances, "set") and hasattr(Instances, "has") and hasattr(Boxes, "nonempty")):
+        raise ImportError("a partial detectron2 stand-in is registered (test shims): use the local containers")
 except ImportError:
 
     class Boxes:

@@ -91,6 +91,36 @@ def test_forward_text_cache_and_chunks(fake_ops):
     assert m.encode_text(g["texts"][:3])["last_hidden_state_eot"].shape == (3, cfg["embed_dim"])
 
 
+def test_text_prompt_end_to_end_host_logic(fake_ops):
+    """strings in, detections out: `text_prompt` -> tokenizer -> text tower (`model_language.forward_text`) -> detector, the way
+    demo/demo_lazy.py --text-prompt drives the reference (deformable_detr_segm_vl.py:204-259); the tower is the registered
+    sub-module `model_vision.model_language` like in the reference's checkpoints (ape_deta.py:32-33)"""
+    from ape_amd.modeling.build import build_ape, init_synthetic
+    from ape_amd.modeling.text import EVA02CLIP
+
+    g = _gold()
+    cfg = dict(g["tiny"]["cfg"], embed_dim=1024)                       # the detector's language width
+    lookup = {t: g["tokens"][i] for i, t in enumerate(g["texts"])}
+    tower = EVA02CLIP(text_cfg={k: cfg[k] for k in ("width", "heads", "layers", "context_length", "vocab_size")}, embed_dim=1024,
+                      tokenizer=lambda texts, context_length=77: torch.stack([lookup[t] for t in texts]))
+    sd = {"text." + k: v for k, v in T.make_state_dict(cfg, 2).items()}
+    sd["logit_scale"] = tower.net.logit_scale.detach().clone()
+    tower.net.load_state_dict(sd)
+    model = init_synthetic(build_ape("tiny", model_language=tower), seed=0)
+    tower.net.load_state_dict(sd)                                      # init_synthetic re-seeds every parameter of the model
+    keys = [k for k in model.state_dict() if "model_language" in k]
+    assert "model_vision.model_language.net.text.token_embedding.weight" in keys and len(keys) == len(sd)
+    model.model_vision.set_compute_dtype(torch.float32)
+    image = torch.randint(0, 256, (3, 200, 256), generator=torch.Generator().manual_seed(4)).float()
+    names = g["texts"][:6]                                             # single-word / two-word class names -> prompt "name" or "phrase"
+    only_single = [n for n in names if " " not in n]
+    out = model([{"image": image, "height": 200, "width": 256, "prompt": "text", "text_prompt": ",".join(only_single)}])[0]["instances"]
+    want = T.text_tower(T.make_state_dict(cfg, 2), cfg, torch.stack([lookup[t] for t in only_single]))[0]
+    ref = model([{"image": image, "height": 200, "width": 256, "text_features": want}])[0]["instances"]
+    assert len(out) == len(ref) > 0 and torch.equal(out.pred_classes, ref.pred_classes)
+    assert torch.allclose(out.scores, ref.scores, atol=1e-4) and int(out.pred_classes.max()) < len(only_single)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_causal_attention_and_embedding_kernels():
