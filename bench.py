@@ -313,7 +313,7 @@ def main():
         all_t, all_fl = sum(g[1][1] for g in groups), sum(g[1][2] for g in groups)
         achieved = dom_fl / dom_t / 1e12
         result = {
-            "metric": "images/sec @1024^2 APE-L_D fwd", "value": world * args.steps * B / elapsed, "unit": "images/sec",
+            "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": world * args.steps * B / elapsed, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
