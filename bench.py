@@ -40,8 +40,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARC
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)       # 100 two-image steps = a timed region of ~2.2 s
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", default="L_D_coco", help="L_D_coco = APE-L_D with the COCO config's top-100 (BASELINE config 2); L_D = top-300")
     ap.add_argument("--classes", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
