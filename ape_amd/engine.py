@@ -32,8 +32,8 @@ class DefaultPredictor:
         self.cfg = cfg
         self.aug = None
         if model is None:
-            from detectron2.checkpoint import DetectionCheckpointer      # full environment only
-            from detectron2.config import instantiate
+            from detectron2.config import instantiate                    # full environment only (LazyConfig)
+            from .checkpoint import DetectionCheckpointer                # ape/engine/defaults.py:9,199
             model = instantiate(cfg.model)
             model.to(cfg.train.device)
             DetectionCheckpointer(model).load(cfg.train.init_checkpoint)

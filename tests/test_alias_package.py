@@ -21,6 +21,7 @@ TARGETS = [
     ("ape.modeling.backbone.vit_eva02", ["SimpleFeaturePyramid", "ViT"]),
     ("ape.engine.defaults", ["DefaultPredictor"]),
     ("ape.modeling.text", ["EVA02CLIP"]),
+    ("ape.checkpoint", ["DetectionCheckpointer"]),
 ]
 
 SCRIPT = r"""
