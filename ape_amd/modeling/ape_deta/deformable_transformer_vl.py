@@ -135,6 +135,7 @@ class DeformableDetrTransformerVL(nn.Module):
         self.assign_first_stage = assign_first_stage
         self.pre_nms_topk, self.nms_thresh_enc = pre_nms_topk, nms_thresh_enc
         self.proposal_ambiguous = proposal_ambiguous
+        self.compute_dtype = torch.bfloat16          # set by DeformableDETRSegmVL.set_compute_dtype; read by the reference-signature forward()
         self.embed_dim = self.encoder.embed_dim
         self.level_embeds = nn.Parameter(torch.Tensor(self.num_feature_levels, self.embed_dim))
         self.enc_output = nn.Linear(self.embed_dim, self.embed_dim)
@@ -226,3 +227,31 @@ class DeformableDetrTransformerVL(nn.Module):
         inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt)
         return dict(inter_states=inter, init_reference=reference, inter_references=inter_ref, enc_class=enc_class,
                     enc_coord_unact=enc_coord, memory=memory, query_l=l_out, topk_proposals=topk)
+
+    def forward(self, multi_level_feats, multi_level_masks, multi_level_pos_embeds, query_embed=None, query_l=None, attention_mask_l=None,
+                multi_level_masks_prompt=None, **kwargs):
+        """reference signature (deformable_transformer_vl.py:422-689), two-stage form: NCHW feature levels, their padding masks
+        [B, H_l, W_l] and position embeddings [B, C, H_l, W_l], the language tokens query_l [B, L, l_dim] ->
+        (inter_states [layers, B, Q, C], init_reference [B, Q, 4], inter_references [layers, B, Q, 4], enc_outputs_class
+        [B, T, 1], enc_outputs_coord_unact [B, T, 4], anchors [B, T, 4] (sigmoid space), memory [B, T, C], query_l [B, L, l_dim]).
+        Batch elements run one after the other through `forward_tokens` (the reference evaluates batch 1)."""
+        if not self.as_two_stage or query_embed is not None:
+            raise NotImplementedError("ape_amd: the two-stage transformer of the APE configs (as_two_stage=True, no query_embed)")
+        if attention_mask_l is not None or multi_level_masks_prompt is not None:
+            raise NotImplementedError("ape_amd: language masks (un-reduced text tokens) and mask prompts are not implemented")
+        dt = getattr(self, "compute_dtype", torch.bfloat16)
+        B = multi_level_feats[0].shape[0]
+        rows = []
+        for b in range(B):
+            masks = [m[b].bool() for m in multi_level_masks]
+            pos = [p[b].flatten(1).t() for p in multi_level_pos_embeds]
+            geo = G.geometry_from_masks(masks, pos)
+            src = torch.cat([f[b].flatten(1).t() for f in multi_level_feats]).to(dt).contiguous()
+            tr = self.forward_tokens(src, geo, query_l[b].float().contiguous(), dt)
+            rows.append((torch.stack(tr["inter_states"]), tr["init_reference"], torch.stack(tr["inter_references"]),
+                         tr["enc_class"][:, None], tr["enc_coord_unact"], geo.proposals.sigmoid(), tr["memory"], tr["query_l"]))
+        odt = multi_level_feats[0].dtype
+        cat = lambda i, dim: torch.stack([r[i] for r in rows], dim)                      # noqa: E731
+        return (cat(0, 1).to(odt), cat(1, 0).to(odt), cat(2, 1).to(odt), cat(3, 0).to(odt), cat(4, 0).to(odt), cat(5, 0).to(odt),
+                cat(6, 0).to(odt), cat(7, 0).to(query_l.dtype))
+

@@ -148,6 +148,54 @@ def build_geometry(square, image_size, level_shapes, device, pos_cfg):
     return g
 
 
+def geometry_from_masks(level_masks, level_pos):
+    """the same constants from the padding masks / position embeddings a CALLER supplies, level by level -- the inputs of the
+    reference-signature `DeformableDetrTransformerVL.forward` (deformable_transformer_vl.py:422-477, 321-410).
+    level_masks: [H_l, W_l] bool (True = padding); level_pos: [H_l * W_l, C] token-major position embeddings."""
+    device = level_masks[0].device
+    g = LevelGeometry()
+    g.image_size = None
+    g.shapes = [(int(m.shape[0]), int(m.shape[1])) for m in level_masks]
+    g.starts = [0]
+    for a, b in g.shapes[:-1]:
+        g.starts.append(g.starts[-1] + a * b)
+    g.T = sum(a * b for a, b in g.shapes)
+    g.mask = torch.cat([m.reshape(-1).bool() for m in level_masks])
+    g.mask_u8 = g.mask.to(torch.uint8).contiguous()
+    g.pos = torch.cat([p.float() for p in level_pos]).contiguous()
+    vrs, refs, props, lids = [], [], [], []
+    for lvl, m in enumerate(level_masks):
+        H, W = m.shape
+        valid_H, valid_W = torch.sum(~m[:, 0]).float(), torch.sum(~m[0, :]).float()
+        vrs.append(torch.stack([valid_W / W, valid_H / H]))
+        lids.append(torch.full((H * W,), lvl, dtype=torch.long, device=device))
+    g.valid_ratios = torch.stack(vrs)
+    g.level_ids = torch.cat(lids)
+    for lvl, m in enumerate(level_masks):
+        H, W = m.shape
+        vr = g.valid_ratios[lvl]
+        ry, rx = torch.meshgrid(torch.linspace(0.5, H - 0.5, H, dtype=torch.float32, device=device),
+                                torch.linspace(0.5, W - 0.5, W, dtype=torch.float32, device=device), indexing="ij")
+        refs.append(torch.stack((rx.reshape(-1) / (vr[0] * W), ry.reshape(-1) / (vr[1] * H)), -1))
+        valid_H, valid_W = torch.sum(~m[:, 0]), torch.sum(~m[0, :])
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H, dtype=torch.float32, device=device),
+                                torch.linspace(0, W - 1, W, dtype=torch.float32, device=device), indexing="ij")
+        grid = (torch.cat([gx.unsqueeze(-1), gy.unsqueeze(-1)], -1) + 0.5) / torch.stack([valid_W, valid_H]).view(1, 1, 2)
+        wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        props.append(torch.cat((grid, wh), -1).view(-1, 4))
+    ref = torch.cat(refs)
+    g.enc_ref = (ref[:, None, :] * g.valid_ratios[None]).contiguous()
+    prop = torch.cat(props)
+    valid = ((prop > 0.01) & (prop < 0.99)).all(-1, keepdim=True)
+    prop = torch.log(prop / (1 - prop))
+    g.proposals = prop.masked_fill(g.mask.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf")).contiguous()
+    g.invalid_u8 = (g.mask | ~valid[:, 0]).to(torch.uint8).contiguous()
+    g.box_scale = None
+    g.vr4 = torch.cat([g.valid_ratios, g.valid_ratios], -1).contiguous()
+    g.arange_T = torch.arange(g.T, device=device)
+    return g
+
+
 def proposal_pos_embed(coords_unact, num_pos_feats=128, temperature=10000):
     """deformable_transformer_vl.py:412-420 for [Q,4] unactivated coords -> [Q, 512] fp32"""
     scale = 2 * math.pi

@@ -76,7 +76,8 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         hook(enc.layers[i], f"enc{i}_out")
     hooks.append(mv.transformer.register_forward_hook(lambda m, i, o: S.update({
         "inter_states": o[0], "init_reference": o[1], "inter_references": o[2], "enc_class": o[3],
-        "enc_coord_unact": o[4], "memory": o[6], "query_l": o[7]})))
+        "enc_coord_unact": o[4], "anchors": o[5], "memory": o[6], "query_l": o[7]})))
+    hooks.append(mv.transformer.register_forward_pre_hook(lambda m, a: S.__setitem__("transformer_inputs", a)))
     hooks.append(mv.transformer.decoder.register_forward_pre_hook(
         lambda m, a, kw: S.update({"query_init": kw["query"], "query_pos": kw["query_pos"]}), with_kwargs=True))
     hook(mv.transformer.enc_output_norm, "output_memory")

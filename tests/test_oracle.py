@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle_util as U
-from oracle import ape_oracle, weights
+from oracle import ape_oracle, refshim, weights
 from oracle.configs import CONFIGS
 
 FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order)
@@ -142,3 +142,33 @@ def test_oracle_vit_eva02_backbone_matches_reference_golden():
     U.check_fingerprint(feat, gold["stages"]["last_feat"], FP32_TOL, "last_feat")
     for k, v in orc.fpn(feat).items():
         U.check_fingerprint(v, gold["stages"][k], FP32_TOL, k)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="needs /root/reference")
+def test_transformer_reference_signature_matches_live_reference(fake_ops):
+    """`DeformableDetrTransformerVL.forward(multi_level_feats, masks, pos_embeds, query_embed, query_l, attention_mask_l,
+    masks_prompt)` -> the reference's 8-tuple (deformable_transformer_vl.py:422-689).  The reference model is run on a padded
+    image, the transformer's own inputs are captured by a hook and handed to the HIP-path module (ops = their definitions)."""
+    from ape_amd.modeling.build import build_ape
+    from oracle import run_reference as RR, weights
+
+    gold = U.load_golden("tiny_padded")
+    cfg_name, wseed, image, text = U.case_inputs(gold)
+    S, _, spec, _ = RR.run_reference(cfg_name, wseed, image, text)
+    model = build_ape(cfg_name)
+    model.load_state_dict(weights.make_state_dict(spec, wseed), strict=False)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.float32)
+    assert mv.transformer.compute_dtype == torch.float32
+    with torch.no_grad():
+        out = mv.transformer(*S["transformer_inputs"])
+    names = ["inter_states", "init_reference", "inter_references", "enc_class", "enc_coord_unact", "anchors", "memory", "query_l"]
+    assert len(out) == 8
+    for name, got in zip(names, out):
+        ref = S[name]
+        assert tuple(got.shape) == tuple(ref.shape), (name, got.shape, ref.shape)
+        fin = torch.isfinite(ref)
+        assert torch.equal(fin, torch.isfinite(got)), name                  # +inf anchors of padded / out-of-range tokens
+        e = U.relerr(got[fin], ref[fin])
+        print(f"transformer.forward {name}: {e:.2e}")
+        assert e < 1e-3, (name, e)
