@@ -12,3 +12,7 @@ everything else of the reference's `ape` package (data, evaluation, text towers,
 import ape_amd as _impl
 
 __version__ = _impl.__version__
+
+from . import _overlay as _ov  # noqa: E402
+
+_ov.extend(__path__)           # ape.data, ape.evaluation, ape.utils, ape.model_zoo, ... of a reference checkout stay importable

@@ -56,3 +56,39 @@ def test_default_predictor_resize_rule():
     assert shortest_edge_size(640, 480, 1024, 1024) == (1024, 768)
     assert shortest_edge_size(1000, 1000, 1024, 1024) == (1024, 1024)
     assert shortest_edge_size(427, 640, 1024, 1024) == (683, 1024)
+
+
+OVERLAY = r"""
+import os, sys
+sys.path.insert(0, %r)
+os.environ["APE_REFERENCE"] = %r
+import ape, ape.layers, ape.modeling.ape_deta as A, ape.modeling.text as T
+# hot path: still the HIP-backed classes
+assert A.DeformableDETRSegmVL.__module__.startswith("ape_amd.") and ape.layers.VisionLanguageAlign.__module__.startswith("ape_amd.")
+assert T.EVA02CLIP.__module__.startswith("ape_amd.")
+# not provided here: the reference's own files, found through the extended package paths
+import ape.modeling.text.utils as tu
+assert tu.__file__.startswith(%r) and hasattr(tu, "reduce_language_feature")
+from ape.layers import ZeroShotFC            # lazy name re-exported by the reference's __init__ (ape/layers/__init__.py:8)
+assert ZeroShotFC.__module__ == "ape.layers.zero_shot_fc"
+try:
+    A.DeformableCriterion                    # needs detectron2 / detrex: resolves only in a full environment
+    print("criterion resolved")
+except ImportError as e:
+    print("criterion needs the full environment:", type(e).__name__)
+try:
+    A.NoSuchName
+    raise SystemExit("missing names must raise AttributeError")
+except AttributeError:
+    pass
+print("overlay ok")
+"""
+
+
+def test_overlay_on_a_reference_checkout():
+    ref = os.environ.get("APE_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "ape")):
+        import pytest
+        pytest.skip("needs a reference checkout")
+    out = subprocess.run([sys.executable, "-c", OVERLAY % (ROOT, ref, os.path.join(ref, "ape"))], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "overlay ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
