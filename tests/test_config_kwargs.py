@@ -1,0 +1,90 @@
+"""Drop-in contract at the LazyConfig level: every keyword the reference's APE-L_D / APE-Ti configuration chain passes
+to a hot-path class -- `L(Class)(kw=...)` calls and later `model.model_vision[.transformer[.encoder|.decoder]].<kw> = ...`
+assignments -- is accepted by the HIP-backed class of the same name.  Static (AST) check of the reference's config files; needs
+the reference checkout."""
+import ast
+import inspect
+import os
+import re
+
+import pytest
+
+REF = os.environ.get("APE_REFERENCE", "/root/reference")
+CFG = os.path.join(REF, "configs")
+CHAINS = {
+    "L_D": ["COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py",
+            "LVIS_InstanceSegmentation/ape_deta/ape_deta_vitl_eva02_lsj1024_cp_24ep.py",
+            "LVISCOCOCOCOSTUFF_O365_OID_VGR_SA1B_REFCOCO_GQA_PhraseCut_Flickr30k/ape_deta/ape_deta_vitl_eva02_clip_vlf_lsj1024_cp_16x4_1080k.py",
+            "common/backbone/vitl_eva02_clip.py"],
+    "Ti": ["COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py",
+           "LVISCOCOCOCOSTUFF_O365_OID_VGR_SA1B_REFCOCO_GQA_PhraseCut_Flickr30k/ape_deta/ape_deta_vitt_eva02_vlf_lsj1024_cp_16x4_1080k.py",
+           "common/backbone/vitt_eva02.py"],
+    "L_A": ["common/backbone/vitl_eva02.py"],
+}
+# config class name -> (our class, attribute path whose later assignments also count)
+pytestmark = pytest.mark.skipif(not os.path.isdir(CFG), reason="needs the reference checkout")
+
+
+def _collect(files):
+    calls, assigns = {}, {}
+    for rel in files:
+        path = os.path.join(CFG, rel)
+        if not os.path.isfile(path):
+            continue
+        src = open(path).read()
+        for node in ast.walk(ast.parse(src)):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Call) and getattr(node.func.func, "id", "") == "L" and node.func.args:
+                tgt = node.func.args[0]
+                name = getattr(tgt, "id", None) or getattr(tgt, "attr", None)
+                if name:
+                    calls.setdefault(name, set()).update(k.arg for k in node.keywords if k.arg)
+        for m in re.finditer(r"^model\.model_vision((?:\.\w+)*)\.(\w+)\s*=", src, flags=re.M):
+            assigns.setdefault(m.group(1), set()).add(m.group(2))
+    return calls, assigns
+
+
+def _accepts(cls):
+    sig = inspect.signature(cls.__init__)
+    if any(p.kind == p.VAR_KEYWORD for p in sig.parameters.values()):
+        return None
+    return set(sig.parameters) - {"self"}
+
+
+@pytest.mark.parametrize("chain", ["L_D", "Ti", "L_A"])
+def test_every_config_keyword_is_accepted(chain):
+    from ape_amd.layers import VisionLanguageFusion
+    from ape_amd.modeling.ape_deta import (DeformableDETRSegmVL, DeformableDetrTransformerDecoderVL, DeformableDetrTransformerEncoderVL,
+                                           DeformableDetrTransformerVL)
+    from ape_amd.modeling.backbone import vit_eva02, vit_eva_clip
+    from ape_amd.modeling.text import EVA02CLIP
+
+    calls, assigns = _collect(CHAINS[chain])
+    vit_mod = vit_eva_clip if chain == "L_D" else vit_eva02
+    table = [
+        (("DeformableDETRSegm", "DeformableDETRSegmVL"), "", DeformableDETRSegmVL),
+        (("DeformableDetrTransformer", "DeformableDetrTransformerVL"), ".transformer", DeformableDetrTransformerVL),
+        (("DeformableDetrTransformerEncoder", "DeformableDetrTransformerEncoderVL"), ".transformer.encoder", DeformableDetrTransformerEncoderVL),
+        (("DeformableDetrTransformerDecoder", "DeformableDetrTransformerDecoderVL"), ".transformer.decoder", DeformableDetrTransformerDecoderVL),
+        (("VisionLanguageFusion",), None, VisionLanguageFusion),
+        (("ViT",), None, vit_mod.ViT),
+        (("SimpleFeaturePyramid",), None, vit_mod.SimpleFeaturePyramid),
+        (("EVA02CLIP",), None, EVA02CLIP),
+    ]
+    checked = 0
+    for names, path, cls in table:
+        want = set()
+        for n in names:
+            want |= calls.get(n, set())
+        if path is not None:
+            want |= assigns.get(path, set())
+        want -= {"_target_"}
+        # sub-configs replaced wholesale by later configs are not keywords of the class itself
+        if cls is DeformableDETRSegmVL:
+            want -= {"transformer", "backbone", "neck"} - set(inspect.signature(cls.__init__).parameters)
+        ok = _accepts(cls)
+        if ok is None or not want:
+            continue
+        missing = sorted(want - ok)
+        assert not missing, f"{chain}: {cls.__name__} does not accept {missing}"
+        checked += len(want)
+    assert checked >= (8 if chain == "L_A" else 40), checked
