@@ -88,3 +88,24 @@ def test_every_config_keyword_is_accepted(chain):
         assert not missing, f"{chain}: {cls.__name__} does not accept {missing}"
         checked += len(want)
     assert checked >= (8 if chain == "L_A" else 40), checked
+
+
+def test_overrides_of_every_vit_ape_config_are_accepted():
+    """all configs/**/ape_deta/*vit[lt]_eva02*.py (APE-Ti, APE-L_A..D, every dataset mix): each `model.model_vision[.transformer
+    [.encoder|.decoder]].<kw> = ...` override names a constructor keyword of the HIP-backed class"""
+    import glob
+    from ape_amd.modeling.ape_deta import (DeformableDETRSegmVL, DeformableDetrTransformerDecoderVL, DeformableDetrTransformerEncoderVL,
+                                           DeformableDetrTransformerVL)
+    acc = {"": DeformableDETRSegmVL, ".transformer": DeformableDetrTransformerVL, ".transformer.encoder": DeformableDetrTransformerEncoderVL,
+           ".transformer.decoder": DeformableDetrTransformerDecoderVL}
+    ok = {k: set(inspect.signature(c.__init__).parameters) for k, c in acc.items()}
+    files = glob.glob(os.path.join(CFG, "**", "ape_deta", "*vit[lt]_eva02*.py"), recursive=True)
+    assert len(files) > 50
+    bad, n = {}, 0
+    for f in files:
+        for m in re.finditer(r"^model\.model_vision((?:\.\w+)*)\.(\w+)\s*=", open(f).read(), flags=re.M):
+            if m.group(1) in ok:
+                n += 1
+                if m.group(2) not in ok[m.group(1)]:
+                    bad.setdefault((m.group(1), m.group(2)), []).append(os.path.basename(f))
+    assert not bad and n > 500, (bad, n)
