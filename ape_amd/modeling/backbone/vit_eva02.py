@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...packing import attach_cache, f32, pack_matrix, round_up
+from ...stagetap import tap
 from .vit_eva_clip import Backbone, PatchEmbed, SimpleFeaturePyramid, VisionRotaryEmbeddingFast  # noqa: F401
 
 __all__ = ["ViT", "SimpleFeaturePyramid"]
@@ -219,7 +220,7 @@ class ViT(Backbone):
             return d
         return self._pack.get(self, dt, build)
 
-    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), stages=None):
         """image [3,h,w] fp32 (h,w <= img_size) -> last feature [N, E] in the compute dtype, RASTER token order"""
         dt = self.compute_dtype
         P = self.packed(dt)
@@ -228,16 +229,19 @@ class ViT(Backbone):
         if isinstance(image, (list, tuple)):
             return torch.cat([self.forward_tokens(im, mean, std) for im in image], 0)
         patches = ops.patchify(image, P["ident"], hw, hw, mean, std, out_dtype=dt)
-        x = ops.gemm(patches, P["wpe"], P["bpe"], residual=P["pos"], out_dtype=torch.float32)
+        x = tap(stages, "vit_embed", ops.gemm(patches, P["wpe"], P["bpe"], residual=P["pos"], out_dtype=torch.float32))
         xn_buf = torch.zeros((n + 1, self.embed_dim), dtype=dt, device=x.device)
         rows = n if P["win"] is None else max(n, P["win"]["nwin"] * P["win"]["stride"])
-        vt_buf = torch.zeros((self.embed_dim, round_up(rows, 64)), dtype=dt, device=x.device)
+        # the attention kernel reads V^T in 64-column tiles from every window's first column: the last window's last tile ends
+        # at (nwin - 1) * stride + round_up(ntok, 64) <= round_up(rows, 64) + 64 (ops.attention checks the bound)
+        vt_buf = torch.zeros((self.embed_dim, round_up(rows, 64) + 64), dtype=dt, device=x.device)
         for i, blk in enumerate(self.blocks):
             last = i == len(self.blocks) - 1
             if blk.window_size > 0:
                 x = blk.forward_tokens(x, dt, P["rope_win"], P["win"], xn_buf, vt_buf, last)
             else:
                 x = blk.forward_tokens(x, dt, P["rope_glb"], None, xn_buf, vt_buf, last)
+            x = tap(stages, f"vit_blk{i}", x)
         return x
 
     def forward(self, x):

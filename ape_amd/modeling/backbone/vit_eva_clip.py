@@ -23,6 +23,7 @@ import torch.nn.functional as F
 
 from ... import ops
 from ...packing import attach_cache, f32, pack_matrix, round_up
+from ...stagetap import tap
 
 __all__ = ["ViT", "SimpleFeaturePyramid"]
 
@@ -240,8 +241,9 @@ class ViT(Backbone):
             )
         return self._pack.get(self, dt, build)
 
-    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0)):
+    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), stages=None):
         """image [3,h,w] fp32 (h,w <= img_size) -> last feature [N, E] in the compute dtype, WINDOW-MAJOR token order.
+        stages: optional dict / StageTap (stagetap.py) recording "vit_embed" and every block's output "vit_blk<i>".
         A list of B images (sizes may differ) runs as ONE pass over [B * N, E]: every linear sees B x 4096 rows (the big-tile
         GEMM kernels need that many to fill 256 CUs), windows / global attention stay per image.  Rows are independent in
         every op of the ViT, so each image's result is bit-identical to its own single-image pass."""
@@ -261,12 +263,13 @@ class ViT(Backbone):
             if ("pos", B) not in P:
                 P[("pos", B)] = P["pos"].repeat(B, 1).contiguous()
             pos = P[("pos", B)]
-        x = ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32)
+        x = tap(stages, "vit_embed", ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32))
         nwin = (hw // self.window_size) ** 2 * B
         vt_buf = torch.zeros((self.embed_dim, round_up(B * n, 64)), dtype=dt, device=x.device)
         for i, blk in enumerate(self.blocks):
             rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
             x = blk.forward_tokens(x, dt, rope, nwin, self.window_size ** 2, vt_buf, last=(i == len(self.blocks) - 1), images=B)
+            x = tap(stages, f"vit_blk{i}", x)
         return x
 
     def forward(self, x):
@@ -389,13 +392,18 @@ class SimpleFeaturePyramid(Backbone):
         cols = ops.im2col3x3(y, perm, H, W)
         return ops.layernorm(ops.gemm(cols, c3[0], None), c3[1], c3[2], c3[3], out_dtype=dt)
 
-    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), vit_feat=None):
+    def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), vit_feat=None, stages=None):
         """-> dict name -> ([H*W, C] raster token-major map in the compute dtype, (H, W)).  vit_feat: this image's rows of a
         batched ViT pass (ViT.forward_tokens on a list) -- the pyramid then starts from them."""
         dt = self.compute_dtype
         P = self.packed(dt)
         hw = P["hw"]
-        x = vit_feat if vit_feat is not None else self.net.forward_tokens(image, mean, std)          # [hw*hw, E] window-major
+        if vit_feat is not None:
+            x = vit_feat
+        elif stages is not None:
+            x = self.net.forward_tokens(image, mean, std, stages=stages)
+        else:
+            x = self.net.forward_tokens(image, mean, std)                                             # [hw*hw, E] window-major
         out = {}
         # The four scales only share the ViT output: stride 8 / 16 / 32 run as parallel graph branches next to the heavy
         # stride-4 chain (their kernels are small launches that leave most of the chip idle).

@@ -133,7 +133,8 @@ class TextTransformer(nn.Module):
         L = ctx if all_positions else min(ctx, round_up(int(eot.max()) + 1, 8))
         Lp = round_up(L, 8)
         x = ops.embed_tokens(tok, P["emb"], P["pos"], L, Lp)         # [B * Lp, W] fp32
-        vt_buf = torch.zeros((self.width, round_up(B * Lp, 64)), dtype=dt, device=x.device)
+        # V^T is read in 64-column tiles from each text's first column: (B - 1) * Lp + round_up(L, 64) <= round_up(B * Lp, 64) + 64
+        vt_buf = torch.zeros((self.width, round_up(B * Lp, 64) + 64), dtype=dt, device=x.device)
         for blk in self.transformer.resblocks:
             x = blk.forward_tokens(x, dt, B, L, Lp, vt_buf)
         rows = (torch.arange(B, device=x.device) * Lp + eot).to(torch.int32)

@@ -327,13 +327,19 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
 
 def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False):
     """softmax(scale * q k^T) v per (window, head); causal: keys after the query are masked (CLIP text tower).  q,k: [rows, >=heads*head_dim] views; vt: V transposed
-    [heads*head_dim, >= round_up(rows, 64)] (finite padding); returns [rows, heads*head_dim].  Window b owns rows
-    b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride)."""
+    [heads*head_dim, >= (batch-1)*stride + round_up(n, 64)] (finite padding; checked); returns [rows, heads*head_dim].  Window
+    b owns rows b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride)."""
     _dev(q, k, vt, out)
     _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(vt, "vt")
     if not (q.dtype == k.dtype == vt.dtype):
         raise TypeError("ape_amd.ops.attention: q/k/vt must share a dtype")
     stride = n if stride is None else int(stride)
+    # the kernels read V^T in 64-column tiles starting at each window's first column (keys beyond n get weight 0, but the
+    # columns must exist and be finite): the last window's last tile ends at (batch - 1) * stride + round_up(n, 64)
+    need = (batch - 1) * stride + (n + 63) // 64 * 64
+    if vt.shape[1] < need or q.shape[0] < (batch - 1) * stride + n:
+        raise ValueError(f"ape_amd.ops.attention: vt has {vt.shape[1]} columns, the tiled reads need {need} "
+                         f"((batch - 1) * stride + round_up(n, 64)); q has {q.shape[0]} rows")
     if out is None:
         out = (torch.empty if stride == n else torch.zeros)((batch * stride, heads * head_dim), dtype=q.dtype, device=q.device)
     fn = _lib.load().ape_hip_attention_causal if causal else _lib.load().ape_hip_attention_strided

@@ -180,13 +180,15 @@ int ape_hip_msda_fused_h(const void* value, int ldv, int v_dt, const int64_t* sp
  * 1024 tokens or 4096 global) and nn.MultiheadAttention's core in the decoder self-attention
  * (detrex MultiheadAttention, deformable_transformer_vl.py:141-146; 8 heads x 32, 900 queries).
  *   Q,K: [B*N, ld] with head h at columns h*HD..; Vt: [H*HD, ldvt] = V transposed (token index
- *   b*N + key along the contiguous axis; must be readable and finite up to the next multiple of 64
- *   keys); O: [B*N, ldo].  HD in {32, 64}.
+ *   b*N + key along the contiguous axis).  The bf16 kernels read Vt in 64-column tiles from each batch item's first column:
+ *   every row of Vt must be readable and FINITE for columns 0 .. (B-1)*bstride + round_up(N, 64) - 1 (bstride = N here);
+ *   O: [B*N, ldo].  HD in {32, 64}.
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_attention(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                       int B, int N, int H, int HD, float scale, int dt, void* stream);
 /* same, with `bstride` >= N rows between consecutive batch items (windows): batch item b owns rows b*bstride .. b*bstride+N-1
- * of Q / K / O and columns b*bstride .. of Vt.  For the zero-padded 14 x 14 windows of ape/modeling/backbone/vit_eva02.py:437-458
+ * of Q / K / O and columns b*bstride .. of Vt (column bound above: with a stride that is not a multiple of 64 the last batch
+ * item's last tile ends up to 63 columns past B*bstride -- size Vt accordingly).  For the zero-padded 14 x 14 windows of ape/modeling/backbone/vit_eva02.py:437-458
  * (196 tokens per window, stored at a stride of 200 so that every window starts 16-byte aligned in Vt). */
 int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                               int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream);

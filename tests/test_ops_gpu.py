@@ -308,6 +308,18 @@ def test_ms_deform_attn_forward_operator(ops, dtype):
         assert torch.equal(got2, got)
 
 
+def poisoned_vt(E, batch, stride, n, dtype, seed):
+    """V^T [E, (batch-1)*stride + round_up(n, 64)] -- exactly the columns ops.attention may read -- as a view into a wider
+    allocation whose remaining columns are NaN: a kernel that reads past the documented bound turns its output into NaN."""
+    rows = batch * stride
+    need = (batch - 1) * stride + (n + 63) // 64 * 64
+    big = torch.full((E, need + 64), float("nan"), dtype=dtype, device=DEV)
+    vt = big[:, :need]
+    vt.zero_()
+    vt[:, : min(rows, need)] = rnd(E, rows, dtype=dtype, seed=seed)[:, : min(rows, need)]
+    return vt
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("B,N,H,HD", [(4, 1024, 16, 64), (1, 4096, 16, 64), (1, 900, 8, 32), (2, 200, 3, 64), (1, 77, 2, 32)])
 def test_attention(ops, dtype, B, N, H, HD):
@@ -316,9 +328,7 @@ def test_attention(ops, dtype, B, N, H, HD):
     E = H * HD
     qk = rnd(B * N, 2 * E + 64, dtype=dtype, seed=1)
     q, k = qk[:, :E], qk[:, E:2 * E]
-    npad = (B * N + 63) // 64 * 64
-    vt = torch.zeros(E, npad, dtype=dtype, device=DEV)
-    vt[:, : B * N] = rnd(E, B * N, dtype=dtype, seed=2)
+    vt = poisoned_vt(E, B, N, N, dtype, 2)
     scale = HD ** -0.5
     got = ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
     want = ref_ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=scale)
@@ -343,12 +353,13 @@ def test_attention_strided_windows(ops, dtype):
     E = H * HD
     qk = rnd(B * S, 2 * E, dtype=dtype, seed=1)
     q, k = qk[:, :E], qk[:, E:]
-    npad = (B * S + 63) // 64 * 64
-    vt = torch.zeros(E, npad, dtype=dtype, device=DEV)
-    vt[:, : B * S] = rnd(E, B * S, dtype=dtype, seed=2)
+    vt = poisoned_vt(E, B, S, N, dtype, 2)
+    with pytest.raises(ValueError):          # one column short of the documented bound is refused, not over-read
+        ops.attention(q, k, vt[:, :-1], batch=B, n=N, heads=H, head_dim=HD, scale=HD ** -0.5, stride=S)
     got = ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=HD ** -0.5, stride=S)
     want = ref_ops.attention(q, k, vt, batch=B, n=N, heads=H, head_dim=HD, scale=HD ** -0.5, stride=S)
     rows = (torch.arange(B * S) % S < N).to(DEV)
+    assert torch.isfinite(got[rows].float()).all()
     e = relerr(got[rows], want[rows])
     print(f"attention strided {dtype}: {e:.3e}")
     assert e < (1e-2 if dtype == torch.bfloat16 else 2e-5)

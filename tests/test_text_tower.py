@@ -129,15 +129,20 @@ def test_causal_attention_and_embedding_kernels():
 
     gen = torch.Generator().manual_seed(0)
     for dt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 8e-3)):
-        for (B, n, stride, H) in [(5, 77, 80, 2), (3, 16, 16, 20), (40, 24, 24, 4), (2, 200, 200, 3)]:
+        for (B, n, stride, H) in [(5, 77, 80, 2), (3, 16, 16, 20), (40, 24, 24, 4), (2, 200, 200, 3), (80, 8, 8, 2)]:
             E = H * 64
             rows = B * stride
             q, k = (torch.randn(rows, E, generator=gen).to(dt).cuda() for _ in range(2))
-            vt = torch.zeros(E, (rows + 63) // 64 * 64, dtype=dt, device="cuda")
-            vt[:, :rows] = torch.randn(E, rows, generator=gen).to(dt).cuda()
+            # exactly the columns the kernel may read, inside a NaN-poisoned allocation (stride 8..80 is not a multiple of 64)
+            need = (B - 1) * stride + (n + 63) // 64 * 64
+            big = torch.full((E, need + 64), float("nan"), dtype=dt, device="cuda")
+            vt = big[:, :need]
+            vt.zero_()
+            vt[:, :min(rows, need)] = torch.randn(E, rows, generator=gen).to(dt).cuda()[:, :min(rows, need)]
             got = ops.attention(q, k, vt, batch=B, n=n, heads=H, head_dim=64, scale=0.125, stride=stride, causal=True)
             ref = ref_ops.attention(q, k, vt, batch=B, n=n, heads=H, head_dim=64, scale=0.125, stride=stride, causal=True)
             valid = (torch.arange(rows, device="cuda") % stride) < n
+            assert torch.isfinite(got[valid].float()).all(), (dt, B, n)
             assert relerr(got[valid], ref[valid]) < tol, (dt, B, n)
         tok = torch.randint(0, 1000, (7, 77), generator=gen).to(torch.int32).cuda()
         table, pos = torch.randn(1000, 128, generator=gen).to(dt).cuda(), torch.randn(77, 128, generator=gen).to(dt).cuda()
