@@ -20,6 +20,7 @@ import torch.nn as nn
 from ... import ops
 from ...layers import VisionLanguageAlign
 from ...packing import attach_cache, f32, pack_matrix
+from ...stagetap import tap
 from ...structures import make_instances
 from . import geometry as G
 from ._containers import MLP
@@ -335,7 +336,11 @@ class DeformableDETRSegmVL(nn.Module):
         P = self.packed(dt)
         h, w = image.shape[-2:]
         t0 = time.perf_counter()
-        maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std, vit_feat=vit_feat)
+        if stages is not None:
+            maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std, vit_feat=vit_feat, stages=stages)
+            maps = {k: (tap(stages, k, v[0]), v[1]) for k, v in maps.items()}
+        else:
+            maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std, vit_feat=vit_feat)
         self.backbone_time = time.perf_counter() - t0
         names = self.neck.in_features
         level_shapes = [maps[f][1] for f in names]
@@ -354,9 +359,7 @@ class DeformableDETRSegmVL(nn.Module):
         neck_level(0, names[0])
         for j in jobs:
             j.join()
-        if stages is not None:
-            stages.update({k: v[0] for k, v in maps.items()})
-            stages["enc_input"] = src
+        src = tap(stages, "enc_input", src)
         l0 = self.fusion_tokens(text_feats, prompt)
         want_masks = instance and with_masks and self.test_mask_on
         mask_job = []
@@ -391,6 +394,7 @@ class DeformableDETRSegmVL(nn.Module):
             tok, cbias, inv_scale = self.class_embed[lvl].text_side(tr["query_l"], dt)
         logits = self.class_embed[lvl].forward_tokens(x, tok, cbias, inv_scale)                       # [Q,K] fp32
         boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
+        logits, boxes = tap(stages, "pred_logits", logits), tap(stages, "pred_boxes", boxes)
         out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
         det = {}
         if instance:
@@ -405,10 +409,8 @@ class DeformableDETRSegmVL(nn.Module):
             det = self.inference_single(det_logits, boxes, (h, w), geo.box_scale)
             out.update(det)
         if want_masks or semantic is not None or panoptic:
-            mask_feat = mask_job[0].join()
-            membed = self.mask_embed.forward_tokens(x, dt, out_dtype=dt)                              # [Q,256]
-            if stages is not None:
-                stages.update(mask_features=mask_feat, mask_embed=membed)
+            mask_feat = tap(stages, "mask_features", mask_job[0].join())
+            membed = tap(stages, "mask_embed", self.mask_embed.forward_tokens(x, dt, out_dtype=dt))    # [Q,256]
         if semantic is not None:
             out["sem_seg"] = self.semantic_single(logits, boxes, membed, mask_feat, geo, (h, w), semantic, dt, stages)
         if panoptic:
@@ -437,7 +439,7 @@ class DeformableDETRSegmVL(nn.Module):
             if stages is not None:
                 stages.update(det_mask_logits=mlog)
         if stages is not None:
-            stages.update(pred_logits=logits, pred_boxes=boxes, inter_states=torch.stack(tr["inter_states"])[:, None],
+            stages.update(inter_states=torch.stack(tr["inter_states"])[:, None],
                           inter_references=torch.stack(tr["inter_references"])[:, None], **det)
         self.postprocess_time = time.perf_counter() - t0
         return out

@@ -15,6 +15,7 @@ import torch.nn as nn
 from ... import ops
 from ...layers import MultiScaleDeformableAttention
 from ...packing import attach_cache, f32, pack_matrix, round_up
+from ...stagetap import forcing, tap
 from . import geometry as G
 from ._containers import FFN, SelfAttention, TransformerLayer
 
@@ -50,8 +51,9 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
             x = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
             l = ljob.join()
             if stages is not None:
-                stages[f"enc{i}_fused_v"], stages[f"enc{i}_fused_l"] = v_new, l
-                stages[f"enc{i}_out"] = x
+                stages[f"enc{i}_fused_v"] = v_new
+                l = tap(stages, f"enc{i}_fused_l", l)
+                x = tap(stages, f"enc{i}_out", x)
         if self.post_norm_layer is not None:
             x = ops.layernorm(x, f32(self.post_norm_layer.weight), f32(self.post_norm_layer.bias), self.post_norm_layer.eps, out_dtype=dt)
         return x, l
@@ -85,9 +87,11 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
             return dict(wval=pack_matrix(torch.cat(ws, 0), dt), bval=torch.cat(bs).contiguous())
         return self._pack.get(self, dt, build)
 
-    def forward_tokens(self, query, query_pos, memory, geo, reference, dt):
+    def forward_tokens(self, query, query_pos, memory, geo, reference, dt, stages=None):
         """query/query_pos [Q,256], memory [T,256], reference [Q,4] fp32 (sigmoid space) -> (inter [list of Q,256],
-        inter_ref [list of Q,4]) -- reference loop :195-250"""
+        inter_ref [list of Q,4]) -- reference loop :195-250.  stages: per-layer taps "dec<i>_out", "dec<i>_delta" (box head
+        output), "dec<i>_ref" (refined reference); under teacher forcing (stagetap.StageTap) every layer starts from the
+        teacher's query stream and reference boxes."""
         P = self.packed(dt)
         E = self.embed_dim
         # value_proj of all layers in ONE pass over the encoder memory (the reference re-reads it per layer)
@@ -105,20 +109,32 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
             x2, x2p = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt, add=query_pos)
             reference, ref_in = refjob.join()                  # the previous layer's box head ran next to this self-attention
             if i > 0:
+                if stages is not None:
+                    forced = tap(stages, f"dec{i - 1}_ref", reference)
+                    if forced is not reference:                # teacher forcing: this layer samples around the teacher's boxes
+                        reference = forced
+                        _, ref_in = ops.box_refine(None, reference.contiguous(), vr4)
                 inter_ref.append(reference)
             x3 = layer.attentions[1].forward_tokens(x2p, x2, ref_in, geo.shapes, geo.starts, dt,
                                                     value=value_all[:, i * E:(i + 1) * E])
             x4 = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
             x5 = layer.ffns[0].forward_tokens(x4, dt)
             out, outp = ops.layernorm(x5, *layer.norm_params(2), out_dtype=dt, add=query_pos)
+            if stages is not None:
+                forced = tap(stages, f"dec{i}_out", out)
+                if forced is not out:
+                    out, outp = forced, (forced.float() + query_pos.float()).to(dt)
             if self.bbox_embed is not None:
                 # box head (3-layer MLP) + refinement (:232-246) feed only the NEXT layer's cross-attention: parallel branch
                 def refine(i=i, out=out, reference=reference):
                     tmp = self.bbox_embed[i].forward_tokens(out, dt, out_dtype=torch.float32)
+                    if stages is not None:
+                        stages[f"dec{i}_delta"] = tmp
                     return ops.box_refine(tmp, reference, vr4)
                 refjob = ops.fork(refine)
             inter.append(out)
         reference, _ = refjob.join()
+        reference = tap(stages, f"dec{len(self.layers) - 1}_ref", reference)
         inter_ref.append(reference)
         return inter, inter_ref
 
@@ -188,11 +204,12 @@ class DeformableDetrTransformerVL(nn.Module):
         P = self.packed(dt)
         lvl_pos = self.lvl_pos(geo, dt)
         memory, l_out = self.encoder.forward_tokens(src, geo, lvl_pos, l, dt, stages)
+        memory = tap(stages, "memory", memory)
         if after_encoder is not None:
             after_encoder(memory)
         # gen_encoder_output_proposals (:321-369): rows of padded / out-of-range anchors enter enc_output as zeros
         om = ops.gemm(memory, P["wenc"], P["benc"], rowmask=geo.invalid_u8, mask_mode=ops.MASK_ZERO_INPUT)
-        om = ops.layernorm(om, *P["nenc"], out_dtype=dt)
+        om = tap(stages, "output_memory", ops.layernorm(om, *P["nenc"], out_dtype=dt))
         E = self.embed_dim
         T = om.shape[0]
         h1 = ops.gemm(om, P["w1"], P["b1"], act=ops.ACT_RELU)                                    # [T, 2E]
@@ -207,7 +224,8 @@ class DeformableDetrTransformerVL(nn.Module):
         # anchors, and produce the clamped corner boxes the proposal NMS works on -- one kernel (csrc/topk.hip)
         enc_class, enc_coord, xyxy = ops.enc_finalize(cls2, d, geo.proposals)
         if stages is not None:
-            stages.update(memory=memory, query_l=l_out, output_memory=om, enc_class=enc_class, enc_coord_unact=enc_coord)
+            stages["query_l"] = l_out
+            enc_class, enc_coord = tap(stages, "enc_class", enc_class), tap(stages, "enc_coord_unact", enc_coord)
         if forced_topk is not None:
             topk = forced_topk.to(om.device).long()
         else:
@@ -223,8 +241,10 @@ class DeformableDetrTransformerVL(nn.Module):
         pix = ops.layernorm(ops.gemm(feats, P["wpix"], P["bpix"], out_dtype=torch.float32), *P["npix"], out_dtype=torch.float32)
         query = (pt[:, E:] + pix).to(dt).contiguous()
         if stages is not None:
-            stages.update(topk_proposals=topk, query_init=query, query_pos=query_pos, init_reference=reference)
-        inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt)
+            stages["topk_proposals"] = topk
+            query, query_pos = tap(stages, "query_init", query), tap(stages, "query_pos", query_pos)
+            reference = tap(stages, "init_reference", reference)
+        inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt, stages)
         return dict(inter_states=inter, init_reference=reference, inter_references=inter_ref, enc_class=enc_class,
                     enc_coord_unact=enc_coord, memory=memory, query_l=l_out, topk_proposals=topk)
 

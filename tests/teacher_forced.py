@@ -1,0 +1,170 @@
+"""Teacher-forced per-stage check of the bf16 pipeline (the arithmetic bench.py times) against the fp32 pipeline.
+
+The fp32-kernel run of the SAME model on the SAME input is the teacher: it is pinned to the reference's fixtures by
+test_L_D_fp32_matches_reference (stages <= 2e-6 ... 1e-3, logits / boxes <= 1e-3), so its stage tensors are the reference's
+fp32 tensors.  The bf16 run is teacher forced (ape_amd/stagetap.py): every stage (ViT block, pyramid map, encoder layer,
+decoder layer, head) starts from the teacher's input, rounded to the stage's storage dtype exactly as the product rounds it,
+and its output is compared with the teacher's output -- one stage's own error, not the accumulation of 60 stages.
+
+Tolerances are DERIVED, not fitted.  bf16 keeps 8 significant bits: one round-to-nearest has relative error <= 2^-8 and
+rms 2^-8 / sqrt(3) = 2.26e-3 (uniform mantissa).  All accumulation is fp32, so a contraction of ANY length over operands with
+independent relative errors of rms u has output error rms ~ u * sqrt(sum_k (a_k w_k)^2) -- relative to an output of rms
+sqrt(sum_k (a_k w_k)^2) that is u, independent of K (cancellation inside the sum is what GAIN allows for).  A stage whose
+longest input -> output path crosses R bf16 roundings (one per tensor stored in bf16, one per bf16 weight matrix) therefore
+has relative rms error <= GAIN * U_RMS * sqrt(R), with GAIN = 2 for the places where a normalisation or a softmax divides by
+something smaller than the stream it was computed from.  R per stage is listed in ROUNDINGS with what was counted.
+Box-like outputs are sigmoid(delta + logit(ref)): |d sigmoid| <= |d delta| / 4, so their ABSOLUTE rms tolerance is
+tol(delta's R) * rms(delta) / 4.  Max-norm errors are reported next to the rms ones (over N elements a Gaussian error reaches
+sqrt(2 ln N) ~ 5.7 sigma at N = 1e7) and asserted at 8 sigma.
+"""
+import math
+import re
+
+import torch
+
+from ape_amd.stagetap import StageTap, rel_max, rel_rms
+
+U_RMS = 2.0 ** -8 / math.sqrt(3.0)
+GAIN = 2.0
+SIGMA_MAX = 8.0
+
+# stage key (regex) -> (R, what is counted)
+ROUNDINGS = [
+    (r"vit_embed$", 2, "patch pixels stored bf16, patch-embed weight"),
+    (r"vit_blk\d+$", 12, "LN1 out, Wqk, q|k store, P, attention out, inner LN out, Wproj, LN2 out, W12, SwiGLU out, W3' (+ bf16 store of the last block)"),
+    (r"p2$", 12, "ViT feature, deconv W + store, LN/GELU store, deconv W + store, 1x1 W + store, LN store, 3x3 W + store, LN store"),
+    (r"p3$", 9, "ViT feature, deconv W + store, 1x1 W + store + LN store, 3x3 W + store + LN store"),
+    (r"p[456]$", 7, "ViT feature, 1x1 W + store + LN store, 3x3 W + store + LN store"),
+    (r"enc_input$", 4, "pyramid map, neck W, store, GroupNorm store"),
+    (r"enc\d+_out$", 15, "x, fused v store, Wval + value store, q+pos store, Woff, sampler out, Wout + store, LN store, W1 + store, W2 + store, LN store"),
+    (r"enc\d+_fused_l$", 6, "x, LN store, score W, pooled values, value / output projections of the language side"),
+    (r"memory$", 1, "cast of the teacher's last encoder output"),
+    (r"output_memory$", 4, "memory, Wenc, store, LN store"),
+    (r"enc_class$", 2, "output_memory, Wcls (fp32 output)"),
+    (r"enc_coord_unact$", 6, "output_memory, W1 + store, W2 + store, W3 (fp32 output + fp32 anchors)"),
+    (r"query_init$", 4, "gathered output_memory, Wpix, position embedding store, query store"),
+    (r"query_pos$", 3, "position embedding store, Wpos, query_pos store"),
+    (r"dec\d+_out$", 21, "query, q+pos store, Wqk + store, P, attention out, Wo + store, LN store, Woff, memory value (Wval + store), "
+                         "sampler out, Wout + store, LN store, W1 + store, W2 + store, LN store"),
+    (r"dec\d+_delta$", 6, "query, W1 + store, W2 + store, W3 (fp32 output)"),
+    (r"pred_logits$", 3, "query, text tokens store, (fp32 output, fp32 bias / scale)"),
+    (r"mask_features$", 10, "p2, lateral W + store, GN(+memory) store, 3x3 W + store, GN store, 1x1 W + store"),
+    (r"mask_embed$", 7, "query, (W + store) x 3"),
+]
+BOX_KEYS = re.compile(r"(dec\d+_ref|pred_boxes|init_reference)$")
+CENTERED = re.compile(r"(pred_logits|enc_class)$")          # logits sit on a constant bias (log(1/99)): relative to their spread
+
+
+def roundings(key):
+    for pat, r, _ in ROUNDINGS:
+        if re.match(pat, key):
+            return r
+    return None
+
+
+def tolerance(key):
+    r = roundings(key)
+    return None if r is None else GAIN * U_RMS * math.sqrt(r)
+
+
+def _f(t):
+    return t.detach().float()
+
+
+def stage_errors(got, teacher):
+    """-> {key: dict(rms, max, tol, tol_max, R, n)} for every key the teacher-forced run tapped and the table knows"""
+    res = {}
+    for key, g in got.items():
+        if key not in teacher or not torch.is_tensor(g) or not g.is_floating_point():
+            continue
+        t = teacher[key]
+        if tuple(t.shape) != tuple(g.shape):
+            continue
+        g, t = _f(g), _f(t).to(g.device)
+        fin = torch.isfinite(t)
+        if not bool(fin.all()):                   # anchors of padded / out-of-range positions are +-inf by construction (:352-357)
+            if not torch.equal(torch.isfinite(g), fin):
+                res[key] = dict(rms=float("inf"), max=float("inf"), tol=0.0, tol_max=0.0, R=0, n=g.numel(), kind="finite-pattern")
+                continue
+            g, t = g[fin], t[fin]
+        n = g.numel()
+        if BOX_KEYS.search(key):
+            # absolute error in sigmoid space, bounded through the box head's delta of the same decoder level
+            last = max([int(m.group(1)) for m in (re.match(r"dec(\d+)_delta$", k) for k in teacher) if m] + [0])
+            dkey = f"dec{last}_delta" if key == "pred_boxes" else key.replace("_ref", "_delta")
+            err = (g - t)
+            rms = err.pow(2).mean().sqrt().item()
+            mx = err.abs().max().item()
+            if dkey in teacher and key != "init_reference":
+                d_rms = _f(teacher[dkey]).pow(2).mean().sqrt().item()
+                tol = 0.25 * tolerance("dec0_delta") * d_rms
+                R = roundings("dec0_delta")
+            else:
+                tol, R = 1e-6, 0                 # sigmoid of teacher-forced fp32 coordinates: fp32 arithmetic only
+            res[key] = dict(rms=rms, max=mx, tol=tol, tol_max=SIGMA_MAX * tol, R=R, n=n, kind="abs")
+            continue
+        tol = tolerance(key)
+        if tol is None:
+            continue
+        if CENTERED.search(key):
+            tc = t - t.mean()
+            rms = ((g - t).pow(2).mean().sqrt() / tc.pow(2).mean().sqrt().clamp_min(1e-30)).item()
+            mx = ((g - t).abs().max() / tc.abs().max().clamp_min(1e-30)).item()
+        else:
+            rms, mx = rel_rms(g, t), rel_max(g, t)
+        # the max-norm bound is on err / rms(ref); rel_max divides by max|ref| >= rms(ref), so it is the weaker statement
+        res[key] = dict(rms=rms, max=mx, tol=tol, tol_max=SIGMA_MAX * tol, R=roundings(key), n=n, kind="rel")
+    return res
+
+
+def _natural(key):
+    return [int(p) if p.isdigit() else p for p in re.split(r"(\d+)", key)]
+
+
+ORDER = ["vit_embed", "vit_blk", "p2", "p3", "p4", "p5", "p6", "enc_input", "enc", "memory", "output_memory", "enc_class",
+         "enc_coord_unact", "query_init", "query_pos", "init_reference", "dec", "pred_logits", "pred_boxes", "mask_features", "mask_embed"]
+
+
+def _rank(key):
+    for i, p in enumerate(ORDER):
+        if key == p or (key.startswith(p) and key[len(p):len(p) + 1].isdigit()):
+            return (i, _natural(key))
+    return (len(ORDER), _natural(key))
+
+
+def run(model, image, text, ref_topk, semantic=None, free_run=True):
+    """fp32 teacher run, teacher-forced bf16 run, (optionally) free-running bf16 run of one model on one image.
+    -> (forced errors {key: ...}, free-running errors {key: ...} or None, outputs dict)"""
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.float32)
+    teacher = StageTap()
+    out32 = mv.forward_single(image, text, forced_topk=ref_topk, stages=teacher, semantic=semantic)
+    mv.set_compute_dtype(torch.bfloat16)
+    forced = StageTap(teacher=teacher)
+    out_f = mv.forward_single(image, text, forced_topk=ref_topk, stages=forced, semantic=semantic)
+    ferr = stage_errors(forced, teacher)
+    free_err = out_b = None
+    if free_run:
+        free = StageTap()
+        out_b = mv.forward_single(image, text, forced_topk=ref_topk, stages=free, semantic=semantic)
+        free_err = stage_errors(free, teacher)
+    return ferr, free_err, dict(fp32=out32, forced=out_f, free=out_b, teacher=teacher)
+
+
+def report(tag, ferr, free_err=None, file=None):
+    lines = [f"[{tag}] stage: teacher-forced bf16 error (rms / max, relative unless 'abs') | derived tolerance (R roundings)"
+             + (" | free-running bf16 error (rms / max)" if free_err else "")]
+    for key in sorted(ferr, key=_rank):
+        e = ferr[key]
+        line = (f"[{tag}] {key:18s} {e['kind']} rms {e['rms']:.2e}  max {e['max']:.2e} | tol rms {e['tol']:.2e} max {e['tol_max']:.2e} "
+                f"(R={e['R']:2d})  {'ok' if e['rms'] <= e['tol'] and e['max'] <= e['tol_max'] else 'EXCEEDS'}")
+        if free_err and key in free_err:
+            line += f" | free rms {free_err[key]['rms']:.2e}  max {free_err[key]['max']:.2e}"
+        lines.append(line)
+    text = "\n".join(lines)
+    print(text, file=file, flush=True)
+    return text
+
+
+def violations(ferr):
+    return {k: (e["rms"], e["tol"], e["max"], e["tol_max"]) for k, e in ferr.items() if e["rms"] > e["tol"] or e["max"] > e["tol_max"]}

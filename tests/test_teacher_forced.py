@@ -1,0 +1,85 @@
+"""Per-stage, teacher-forced parity of the bf16 pipeline (what bench.py times) -- see tests/teacher_forced.py for the method and
+the derivation of the tolerances.  CPU: the harness itself on the tiny model with the torch definitions of the ops at the
+product's rounding points.  GPU: the HIP kernels at the BASELINE configurations (APE-L_D 1024^2 square / padded, 1536^2 with
+the semantic branch)."""
+import os
+
+import pytest
+import torch
+
+import model_util as M
+import teacher_forced as TF
+from ape_amd.stagetap import StageTap
+
+SELF = os.environ.get("APE_TEST_SELFCHECK") == "1"
+
+
+def _case(case, dev):
+    model, image, text, gold = M.build_model(case, dev, torch.float32)
+    mv = model.model_vision
+    sem = None
+    if "semantic_meta" in gold:
+        meta = gold["semantic_meta"]
+        mv.semantic_on = True
+        mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
+        sem = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    return model, image.to(dev), text.to(dev), gold, sem
+
+
+def test_stage_tap_teacher_forcing_on_the_host_model(fake_ops):
+    """the harness: a teacher-forced run hands every stage the teacher's tensor, records its own; with teacher == own dtype the
+    recorded error is exactly zero; with bf16 rounding points (torch definitions) every stage is inside its derived tolerance"""
+    model, image, text, gold, sem = _case("tiny_padded", "cpu")
+    mv = model.model_vision
+    ref_topk = gold["full"]["topk_proposals"][0]
+    teacher = StageTap()
+    mv.forward_single(image, text, forced_topk=ref_topk, stages=teacher)
+    ne, nd = mv.transformer.encoder.num_layers - 1, mv.transformer.decoder.num_layers - 1
+    for k in ("vit_embed", "vit_blk0", "p2", "p6", "enc_input", "enc0_out", f"enc{ne}_out", "memory", "output_memory", "query_init",
+              "dec0_out", "dec0_delta", "dec0_ref", f"dec{nd}_out", f"dec{nd}_ref", "pred_logits", "pred_boxes", "mask_features", "mask_embed"):
+        assert k in teacher, k
+    again = StageTap(teacher=teacher)
+    mv.forward_single(image, text, forced_topk=ref_topk, stages=again)
+    for k, e in TF.stage_errors(again, teacher).items():
+        assert e["rms"] == 0.0, (k, e)                       # same arithmetic from the same inputs
+    assert torch.equal(again["pred_boxes"], teacher["pred_boxes"])
+    ferr, free_err, _ = TF.run(model, image, text, ref_topk)
+    TF.report("tiny_padded / torch definitions", ferr, free_err)
+    assert len(ferr) >= 25 and not TF.violations(ferr), TF.violations(ferr)
+    # forcing isolates: the free-running error of the last decoder layer is not smaller than its forced error
+    assert free_err[f"dec{nd}_out"]["rms"] >= 0.5 * ferr[f"dec{nd}_out"]["rms"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_1536_sseg"])
+def test_L_D_bf16_teacher_forced(case):
+    """every stage of the bf16 HIP pipeline, fed the fp32 pipeline's input, is inside the tolerance derived from bf16's 8
+    significant bits and the number of roundings on its path (teacher_forced.ROUNDINGS) -- at the benchmarked sizes"""
+    dev = "cpu" if SELF else "cuda"
+    if SELF:
+        import ape_amd.ops as _ops
+        import ref_ops as _ref
+        for _n in dir(_ref):
+            if not _n.startswith("_") and callable(getattr(_ref, _n)) and hasattr(_ops, _n):
+                setattr(_ops, _n, getattr(_ref, _n))
+    model, image, text, gold, sem = _case(case, dev)
+    ref_topk = gold["full"]["topk_proposals"][0].to(dev)
+    ferr, free_err, outs = TF.run(model, image, text, ref_topk, semantic=sem)
+    TF.report(f"{case} bf16", ferr, free_err)
+    # the teacher really is the reference: its heads against the fixture (north_star tolerance)
+    t = outs["teacher"]
+    logits = t["pred_logits"].float().cpu()
+    if "logit_cols" in gold:
+        logits = logits[:, gold["logit_cols"]]
+    import oracle_util as U
+    assert U.relerr(logits, gold["full"]["pred_logits"][0]) < 1e-3
+    assert U.relerr(t["pred_boxes"].float().cpu(), gold["full"]["pred_boxes"][0]) < 1e-3
+    assert len(ferr) >= 60
+    bad = TF.violations(ferr)
+    assert not bad, bad
+    if sem is not None:
+        a = outs["forced"]["sem_seg"].argmax(0)
+        b = outs["fp32"]["sem_seg"].argmax(0)
+        agree = (a == b).float().mean().item()
+        print(f"[{case} bf16] semantic labels, teacher-forced bf16 vs fp32: {agree:.5f}")
+        assert agree > 0.99
