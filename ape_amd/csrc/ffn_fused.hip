@@ -44,6 +44,10 @@ struct FfnParams {
   int M, HID;
 };
 
+// W2P: W2's hidden columns arrive PRE-PERMUTED inside every group of 32 (position 8g + e holds hidden 4g + e for e < 4 and
+// 16 + 4g + e - 4 for e >= 4 -- the k order of the second MFMA's B operand above; ape_amd.packing.permute_ffn_w2): the W2 fragment
+// of a lane is then ONE ds_read_b128 instead of two ds_read_b64 (which reach their LDS rate only from ~4 waves per SIMD).
+template <bool W2P>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * FF_STAGE);
@@ -151,10 +155,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       for (int ot = 0; ot < 16; ++ot) {
         const int rho = ot * 16 + fm;
         const int sw = (rho >> 1) & 7;
-        const unsigned char* rowp = i2 + rho * 128 + (g & 1) * 8;
-        const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + (g >> 1)) ^ sw) << 4));
-        const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + 2 + (g >> 1)) ^ sw) << 4));
-        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        bf16x8_t wf;
+        if (W2P) {
+          wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(i2 + rho * 128 + (((kk * 4 + g) ^ sw) << 4)));
+        } else {
+          const unsigned char* rowp = i2 + rho * 128 + (g & 1) * 8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + (g >> 1)) ^ sw) << 4));
+          const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + 2 + (g >> 1)) ^ sw) << 4));
+          wf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
         yacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[0], yacc[ot][0], 0, 0, 0);
         yacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[1], yacc[ot][1], 0, 0, 0);
       }
@@ -187,7 +196,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 }
 
 extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
-                                 const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, void* stream) {
+                                 const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted,
+                                 void* stream) {
   APE_CHECK_ARG(X && W1 && b1 && W2 && b2 && Y && M > 0, "ape_hip_ffn_fused: null pointer / empty problem");
   APE_CHECK_ARG(K == FF_K && N == FF_N && HID % FF_HC == 0 && HID >= FF_HC && HID <= 4096,
                 "ape_hip_ffn_fused: the kernel is built for 256 -> HID -> 256 with HID %% 64 == 0, HID <= 4096 (got %d -> %d -> %d)", K, HID, N);
@@ -203,10 +213,12 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
   const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(ffn_fused_kernel, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
+  if (w2_permuted) hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
   APE_CHECK_LAUNCH("ffn_fused_kernel");
   return 0;
 }

@@ -1,7 +1,8 @@
 """Per-image data parallelism over the GPUs of one node.
 
-Images are independent units (the reference evaluates batch 1 per rank with a strided InferenceSampler,
-ape/data/build.py:79,127), so the forward has NO collective on its data path.  The only exchanges are
+Images are independent units (the reference evaluates batch 1 per rank, each rank a contiguous block of the dataset:
+InferenceSampler, ape/data/samplers/distributed_sampler_multi_dataset.py:139-170, used by ape/data/build.py:79,127), so the
+forward has NO collective on its data path.  The only exchanges are
   * one broadcast of the text-embedding bank [K, 1024] from rank 0 per vocabulary (RCCL over xGMI; 160 KB for 80
     classes, 2.4 MB for LVIS-1203) -- the reference instead recomputes / caches the text tower on every rank
     (clip_wrapper_eva02.py:88-128), and
@@ -16,8 +17,17 @@ import torch.distributed as dist
 
 
 def shard_indices(n_items, rank, world):
-    """rank r processes items r, r + world, ...  (InferenceSampler striding)"""
-    return list(range(rank, n_items, world))
+    """the items rank `rank` processes: CONTIGUOUS blocks like the reference's InferenceSampler._get_local_indices
+    (ape/data/samplers/distributed_sampler_multi_dataset.py:160-170) -- the first n % world ranks get one item more, and a
+    shorter block starts one item early (that item is evaluated twice) so that every rank runs the same number of steps and
+    the per-step all-gather of the detection records never waits for a rank that has run out of images."""
+    size, left = n_items // world, n_items % world
+    sizes = [size + int(r < left) for r in range(world)]
+    begin = sum(sizes[:rank])
+    end = min(sum(sizes[:rank + 1]), n_items)
+    if end - begin < max(sizes) and begin > 0:
+        begin -= 1
+    return list(range(begin, end))
 
 
 class DataParallelRunner:

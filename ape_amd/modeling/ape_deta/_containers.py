@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...packing import attach_cache, f32, pack_matrix
+from ...packing import attach_cache, f32, pack_matrix, permute_ffn_w2
 
 
 class FFN(nn.Module):
@@ -25,16 +25,26 @@ class FFN(nn.Module):
     def packed(self, dt):
         def build(dt):
             l0, l1 = self.layers[0][0], self.layers[1]
-            return dict(w1=pack_matrix(l0.weight, dt), b1=f32(l0.bias), w2=pack_matrix(l1.weight, dt), b2=f32(l1.bias))
+            d = dict(w1=pack_matrix(l0.weight, dt), b1=f32(l0.bias), w2=pack_matrix(l1.weight, dt), b2=f32(l1.bias))
+            if dt == torch.bfloat16 and l0.weight.shape[0] % 64 == 0:
+                d["w2p"] = permute_ffn_w2(d["w2"])            # hidden columns in the fused kernel's k order
+            return d
         return self._pack.get(self, dt, build)
+
+    # rows from which the one-kernel FFN (csrc/ffn_fused.hip) replaces the two GEMMs: the encoder's 87 296 tokens write and
+    # re-read a 357 MB hidden tensor per layer in the two-GEMM form; APE_FFN_FUSED=0 restores it, =b64 selects the kernel
+    # variant on the un-permuted W2 (A/B)
+    FUSED_MIN_ROWS = 2048
 
     def forward_tokens(self, x, dt, out_dtype=None):
         """x + Linear(ReLU(Linear(x)))  (detrex FFN with add_identity)"""
         P = self.packed(dt)
-        if (os.environ.get("APE_FFN_FUSED") == "1" and dt == torch.bfloat16 and (out_dtype or dt) == torch.bfloat16 and x.shape[0] >= 2048
-                and x.shape[1] == 256 and P["w2"].shape[0] == 256 and P["w1"].shape[0] % 64 == 0 and P["w1"].shape[0] <= 4096):
-            # EXPERIMENTAL: one kernel, the hidden activations stay in registers (csrc/ffn_fused.hip); off by default until validated
-            return ops.ffn_fused(x, P["w1"], P["b1"], P["w2"], P["b2"], residual=x)
+        mode = os.environ.get("APE_FFN_FUSED", "1")
+        if (mode != "0" and "w2p" in P and (out_dtype or dt) == torch.bfloat16 and x.shape[0] >= self.FUSED_MIN_ROWS
+                and x.shape[1] == 256 and P["w2"].shape[0] == 256 and P["w1"].shape[0] <= 4096):
+            if mode == "b64":
+                return ops.ffn_fused(x, P["w1"], P["b1"], P["w2"], P["b2"], residual=x)
+            return ops.ffn_fused(x, P["w1"], P["b1"], P["w2p"], P["b2"], residual=x, w2_permuted=True)
         h = ops.gemm(x, P["w1"], P["b1"], act=ops.ACT_RELU)
         return ops.gemm(h, P["w2"], P["b2"], residual=x, out_dtype=out_dtype or dt)
 

@@ -20,6 +20,22 @@ def pack_matrix(w, dtype, kpad=8, rows=None):
     return out
 
 
+def ffn_w2_perm(hid):
+    """column order of the pre-permuted W2 of the fused FFN kernel (csrc/ffn_fused.hip, W2P): inside every group of 32 hidden
+    units position 8 g + e holds hidden 4 g + e (e < 4) / 16 + 4 g + (e - 4) (e >= 4) -- the k order in which the first MFMA's
+    accumulator registers are the second MFMA's B operand"""
+    assert hid % 32 == 0
+    pos = torch.arange(hid)
+    grp, r = pos // 32, pos % 32
+    g, e = r // 8, r % 8
+    return grp * 32 + torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4))
+
+
+def permute_ffn_w2(w2):
+    """w2 [N, HID] -> the same matrix with its hidden columns in the fused FFN kernel's order"""
+    return w2[:, ffn_w2_perm(w2.shape[1]).to(w2.device)].contiguous()
+
+
 def f32(t):
     return None if t is None else t.detach().float().contiguous()
 

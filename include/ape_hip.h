@@ -397,13 +397,15 @@ int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* or
                      uint64_t* workspace, float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * EXPERIMENTAL (not on the default path; opt-in with APE_FFN_FUSED=1): the encoder FFN in one kernel,
- * y = x + relu(x W1^T + b1) W2^T + b2 (detrex FFN, ape/modeling/ape_deta/deformable_transformer_vl.py:45-54), bf16 in / out,
- * K = N = 256, HID %% 64 == 0 (<= 4096).  The hidden activations stay in registers as the B operand of the second MFMA
- * (csrc/ffn_fused.hip); residual may be NULL.
+ * The encoder / decoder FFN in one kernel: y = residual + relu(x W1^T + b1) W2^T + b2 (detrex FFN with add_identity,
+ * ape/modeling/ape_deta/deformable_transformer_vl.py:45-54 and :160-166), bf16 in / out, K = N = 256, HID %% 64 == 0 (<= 4096).
+ * The hidden activations stay in registers as the B operand of the second MFMA (csrc/ffn_fused.hip): the [M, HID] tensor the
+ * two-GEMM form writes and reads back (357 MB per encoder layer at 1024^2) never exists.  residual may be NULL.
+ * w2_permuted != 0: W2's hidden columns are stored pre-permuted inside every group of 32 -- position 8 g + e holds hidden
+ * 4 g + e (e < 4) / 16 + 4 g + e - 4 (e >= 4), g = 0..3 -- the k order of the second MFMA (ape_amd.packing.permute_ffn_w2).
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
-                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, void* stream);
+                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted, void* stream);
 
 #ifdef __cplusplus
 }

@@ -513,8 +513,13 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
     return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)
 
 
-def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None):
+def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False):
     """the two-GEMM form at the kernel's rounding points: H rounded to bf16, fp32 accumulation, one rounding of the output"""
+    if w2_permuted:
+        from ape_amd.packing import ffn_w2_perm
+        inv = torch.empty(w2.shape[1], dtype=torch.long)
+        inv[ffn_w2_perm(w2.shape[1])] = torch.arange(w2.shape[1])
+        w2 = w2[:, inv.to(w2.device)]
     h = torch.relu(x.float() @ w1.float().t() + b1.float()).to(torch.bfloat16)
     y = h.float() @ w2.float().t() + b2.float()
     if residual is not None:

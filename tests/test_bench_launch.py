@@ -1,0 +1,40 @@
+"""bench.py's launch contract, on the CPU: `python bench.py --gpus N` WITHOUT a launcher in the environment re-executes itself
+under torch.distributed.run with N ranks (a driver that calls `python bench.py --gpus 8` must get 8 ranks, not a silent 1-GPU
+run); `--dry --backend gloo` runs the rendezvous and the data-parallel exchanges (text-bank broadcast, per-step all-gather of
+the detection records) with no device."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--dry", "--steps", "3", "--warmup", "0", *extra],
+                       capture_output=True, text=True, timeout=600, env=e)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, lines
+
+
+def test_gpus_2_without_a_launcher_spawns_two_ranks():
+    p, lines = _run("--gpus", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout                          # rank 0 prints ONE JSON line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["gathered_shape"][0] == 2 and r["config"]["gathered_rank_ids"] == [0, 1]
+    assert r["config"]["text_bank_identical_on_all_ranks"] is True
+    assert r["config"]["shard_of_rank0"] == [0, 499]          # contiguous shards of the 1000-image stream
+    assert r["value"] is None and r["data"].startswith("dry-run")
+
+
+def test_gpus_1_runs_in_process_and_a_mismatched_world_size_is_refused():
+    p, lines = _run("--gpus", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["config"]["rccl_ranks"] == 1
+    p, lines = _run("--gpus", "4", env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29591"})
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test (CPU) of the data-parallel runner: strided image shards, text-bank broadcast from rank 0,
+"""world_size-2 gloo test (CPU) of the data-parallel runner: contiguous image shards (the reference's InferenceSampler), text-bank broadcast from rank 0,
 all-gather of fixed-size detection records.  The model runs on the torch definitions of the ops (fake backend)."""
 import os
 import sys
@@ -91,7 +91,7 @@ def _worker(rank, world, port, ret):
         ok = True
         for step, allrec in enumerate(gathered):
             for r in range(world):
-                ok &= torch.allclose(allrec[r], want[step * world + r], atol=1e-5)
+                ok &= torch.allclose(allrec[r], want[shard_indices(len(images), r, world)[step]], atol=1e-5)
         ret["ok"] = bool(ok) and same
         ret["text_sum"] = float(text.sum())
     else:
@@ -113,5 +113,17 @@ def test_dp_two_ranks_gloo():
 
 def test_shard_indices():
     from ape_amd.dp import shard_indices
-    assert shard_indices(10, 1, 4) == [1, 5, 9]
-    assert sorted(sum((shard_indices(1000, r, 8) for r in range(8)), [])) == list(range(1000))
+    # the reference's InferenceSampler._get_local_indices (distributed_sampler_multi_dataset.py:160-170), restated
+    def reference(total_size, world_size, rank):
+        shard_size, left = total_size // world_size, total_size % world_size
+        shard_sizes = [shard_size + int(r < left) for r in range(world_size)]
+        begin, end = sum(shard_sizes[:rank]), min(sum(shard_sizes[: rank + 1]), total_size)
+        if end - begin < max(shard_sizes):
+            begin = begin - 1
+        return list(range(begin, end))
+
+    assert shard_indices(10, 1, 4) == [3, 4, 5] and shard_indices(10, 3, 4) == [7, 8, 9]      # rank 3's short block starts one early
+    for n, w in ((1000, 8), (10, 4), (5000, 8), (7, 2), (8, 8), (1203, 4)):
+        shards = [shard_indices(n, r, w) for r in range(w)]
+        assert all(s == reference(n, w, r) for r, s in enumerate(shards))
+        assert sorted(set(sum(shards, []))) == list(range(n)) and len({len(s) for s in shards}) == 1

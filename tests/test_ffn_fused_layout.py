@@ -76,9 +76,23 @@ def read_w2_frag(img, ot, kk, lane):
     return np.concatenate([lo, hi])
 
 
-def fused_ffn_wave(X32, W1, b1, W2, b2):
+def read_w2_frag_permuted(img, ot, kk, lane):
+    """W2P variant: the image was staged from the PRE-PERMUTED W2 (ape_amd.packing.permute_ffn_w2), so the lane's 8 values are
+    one 16-byte chunk kk*4 + g"""
+    m, g = lane & 15, lane >> 4
+    rho = ot * 16 + m
+    return img[rho, (kk * 4 + g) ^ ((rho >> 1) & 7)]
+
+
+def fused_ffn_wave(X32, W1, b1, W2, b2, w2_permuted=False):
     """one wave = 32 tokens: returns Y [32, 256] = x + relu(x W1^T + b1) W2^T + b2 computed the kernel's way"""
     hid = W1.shape[0]
+    read_w2 = read_w2_frag
+    if w2_permuted:
+        import torch
+        from ape_amd.packing import permute_ffn_w2
+        W2 = permute_ffn_w2(torch.from_numpy(W2)).numpy()
+        read_w2 = read_w2_frag_permuted
     # X fragments (B operand of the first MFMA): lane (n = lane & 15 -> token rt*16 + n, g): k = ks*32 + 8g .. +8
     xf = [[np.stack([X32[rt * 16 + (lane & 15), ks * 32 + 8 * (lane >> 4): ks * 32 + 8 * (lane >> 4) + 8] for lane in range(64)])
            for ks in range(8)] for rt in range(2)]
@@ -101,7 +115,7 @@ def fused_ffn_wave(X32, W1, b1, W2, b2):
         for kk in range(2):
             hb = [np.concatenate([hacc[2 * kk][rt], hacc[2 * kk + 1][rt]], axis=1) for rt in range(2)]
             for ot in range(16):
-                wf = np.stack([read_w2_frag(i2, ot, kk, lane) for lane in range(64)])
+                wf = np.stack([read_w2(i2, ot, kk, lane) for lane in range(64)])
                 for rt in range(2):
                     yacc[ot][rt] = mfma_16x16x32(wf, hb[rt], yacc[ot][rt])
     # epilogue: yacc[ot][rt][lane][r] = Y[token rt*16 + (lane & 15)][channel g*64 + ot*4 + r]
@@ -123,6 +137,8 @@ def test_fused_ffn_lane_level_formulas_reproduce_the_ffn():
     W2, b2 = rng.standard_normal((N_OUT, hid)) / 8, rng.standard_normal(N_OUT)
     ref = X + np.maximum(X @ W1.T + b1, 0) @ W2.T + b2
     got = fused_ffn_wave(X, W1, b1, W2, b2)
+    assert np.abs(got - ref).max() < 1e-9
+    got = fused_ffn_wave(X, W1, b1, W2, b2, w2_permuted=True)          # one ds_read_b128 per W2 fragment on the pre-permuted matrix
     assert np.abs(got - ref).max() < 1e-9
 
 

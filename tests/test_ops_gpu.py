@@ -274,7 +274,7 @@ def test_msda_half_offsets_path(ops):
     assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))            # same accumulators, one RNE rounding
     if not SELF:
         from ape_amd import _lib
-        assert b"kres_kernel<0, false, true>" in _lib.load().ape_hip_gemm_last_kernel() or True
+        assert b"kres_kernel<0, false, true>" in _lib.load().ape_hip_gemm_last_kernel()
     got = ops.msda_fused(value, shapes, starts, o16, ref, out_dtype=torch.float32)
     want = ref_ops.msda_fused(value, shapes, starts, o16.float(), ref, out_dtype=torch.float32)
     e = relerr(got, want)
@@ -731,18 +731,25 @@ def test_detections(ops, Q, K, topk):
     assert (got["det_boxes"] - ref["det_boxes"]).abs().max().item() < 1e-3
 
 
-@pytest.mark.skipif(os.environ.get("APE_TEST_EXPERIMENTAL") != "1", reason="experimental kernel (csrc/ffn_fused.hip): written without GPU time left to "
-                    "validate it; run with APE_TEST_EXPERIMENTAL=1")
 @pytest.mark.parametrize("M,HID", [(128, 64), (300, 128), (4096, 2048), (87296, 2048)])
 def test_ffn_fused(ops, M, HID):
-    """y = x + relu(x W1^T + b1) W2^T + b2 in one kernel vs the two-GEMM definition at the same rounding points"""
+    """y = x + relu(x W1^T + b1) W2^T + b2 in one kernel vs the two-GEMM definition at the same rounding points; both W2
+    layouts (row-major: two ds_read_b64 per fragment; pre-permuted hidden columns: one ds_read_b128)"""
+    from ape_amd.packing import permute_ffn_w2
+
     bf = torch.bfloat16
     x = rnd(M, 256, dtype=bf, seed=1)
+    res = rnd(M, 256, dtype=bf, seed=6)
     w1, b1 = rnd(HID, 256, dtype=bf, scale=1 / 16, seed=2), rnd(HID, seed=3)
     w2, b2 = rnd(256, HID, dtype=bf, scale=HID ** -0.5, seed=4), rnd(256, seed=5)
-    got = ops.ffn_fused(x, w1, b1, w2, b2, residual=x)
-    ref = ref_ops.ffn_fused(x, w1, b1, w2, b2, residual=x)
+    ref = ref_ops.ffn_fused(x, w1, b1, w2, b2, residual=res)
+    got = ops.ffn_fused(x, w1, b1, w2, b2, residual=res)
     e = relerr(got, ref)
-    print(f"ffn_fused M{M} HID{HID}: {e:.3e}")
-    assert e < TOL[bf]
+    w2p = permute_ffn_w2(w2)
+    assert relerr(ref_ops.ffn_fused(x, w1, b1, w2p, b2, residual=res, w2_permuted=True), ref) == 0.0
+    gotp = ops.ffn_fused(x, w1, b1, w2p, b2, residual=res, w2_permuted=True)
+    ep = relerr(gotp, ref)
+    print(f"ffn_fused M{M} HID{HID}: {e:.3e} (row-major W2), {ep:.3e} (pre-permuted W2)")
+    assert e < TOL[bf] and ep < TOL[bf]
+    assert torch.equal(got, gotp)                      # the same MFMAs on the same operands
     assert relerr(ops.ffn_fused(x, w1, b1, w2, b2), ref_ops.ffn_fused(x, w1, b1, w2, b2)) < TOL[bf]
