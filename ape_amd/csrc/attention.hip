@@ -13,6 +13,8 @@
 // traffic for P.  Row max / row sum need only two xor-shuffles (lanes l, l^16, l^32, l^48 share a query).
 // V is consumed TRANSPOSED ([head*HD + d][token]); the producing GEMM writes it that way (trans_out).
 // f32 kernel: one query per lane, K / V tiles broadcast from LDS -- exact-math validation mode.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -32,10 +34,29 @@ __device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
   /* 4 chunks (64-byte rows) */ return row * 32 + ((c ^ (((row >> 3) & 1) << 1)) << 3);
 }
 
+// ---- key order of the score tiles (PERM kernels).  Tile i, MFMA row rho of S^T = K.Q^T is key
+//      kappa(i, rho) = 32 (i >> 1) + 8 (rho >> 2) + 4 (i & 1) + (rho & 3)
+// instead of 16 i + rho: a lane (fq = lane >> 4) then holds, in the accumulators of tiles 2s and 2s+1, the EIGHT CONSECUTIVE keys
+// 32 s + 8 fq .. + 7 -- the plain k order of the P.V MFMA's B operand -- so the V^T fragment is ONE ds_read_b128 (the natural
+// order needed two ds_read_b64 halves per fragment, which hipcc merges into the half-rate ds_read2st64_b64).  Only the ROW the K
+// fragment read addresses changes; the 128-byte K rows use the chunk swizzle bits (1, 3, 4) of the row, which is conflict-free
+// for the permuted rows (bank-group check: 16 distinct 16-byte slots per ds_read_b128 lane group).
+__device__ __forceinline__ int kperm_row(int i, int rho) { return 32 * (i >> 1) + 8 * (rho >> 2) + 4 * (i & 1) + (rho & 3); }
+__device__ __forceinline__ int kperm_swz(int row) { return ((row >> 1) & 1) | ((row >> 2) & 6); }
+// max over the 4 lanes l, l^16, l^32, l^48 that share a query: two VALU lane swaps (gfx950) instead of two LDS round trips
+__device__ __forceinline__ float quad_rows_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
-template <int HD, int QT, bool CAUSAL = false>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
+template <int HD, int QT, bool CAUSAL = false, bool PERM = true>
+__global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 : 1) void attn_bf16_kernel(const AttnParams p) {
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
   constexpr int DT = HD / 16;       // output d tiles
@@ -76,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
     const int slot = (wave * PER + i) * 64 + lane;
     {
       const int row = slot / KC, cp = slot % KC;
-      const int c = KC == 8 ? (cp ^ ((row >> 1) & 7)) : (cp ^ (((row >> 3) & 1) << 1));
+      const int c = KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
       krow[i] = row;
       ksrc[i] = Kp + (size_t)b * p.bstride * p.ldk + h * HD + c * 8;
     }
@@ -131,33 +152,33 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
       for (int u = 0; u < QT; ++u) sacc[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[swz_rows(i * 16 + frow, ks * 4 + fq, KC)]));
+        const int krow_ = PERM ? kperm_row(i, frow) : i * 16 + frow;
+        const int koff = (PERM && KC == 8) ? krow_ * 64 + (((ks * 4 + fq) ^ kperm_swz(krow_)) << 3) : swz_rows(krow_, ks * 4 + fq, KC);
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[koff]));
 #pragma unroll
         for (int u = 0; u < QT; ++u) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][i], 0, 0, 0);
       }
     }
     // keys >= N only exist in the last tile
     if (t == nt - 1 && (N & 63) != 0) {
-      const int kbase = t * 64 + fq * 4;
 #pragma unroll
       for (int u = 0; u < QT; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kbase + i * 16 + r >= N) sacc[u][i][r] = -INFINITY;
+            if (t * 64 + (PERM ? kperm_row(i, fq * 4 + r) : i * 16 + fq * 4 + r) >= N) sacc[u][i][r] = -INFINITY;
     }
     if (CAUSAL) {
       // key > query -> -inf.  Key 0 is visible to every query, so the running maximum is finite from tile 0 on and a fully
       // masked later tile contributes exact zeros.
-      const int kbase = t * 64 + fq * 4;
 #pragma unroll
       for (int u = 0; u < QT; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kbase + i * 16 + r > qrow[u]) sacc[u][i][r] = -INFINITY;
+            if (t * 64 + (PERM ? kperm_row(i, fq * 4 + r) : i * 16 + fq * 4 + r) > qrow[u]) sacc[u][i][r] = -INFINITY;
     }
     uint4 pk[QT][2];
 #pragma unroll
@@ -166,8 +187,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
       float mx = fmaxf(fmaxf(sacc[u][0][0], sacc[u][0][1]), fmaxf(sacc[u][0][2], sacc[u][0][3]));
 #pragma unroll
       for (int i = 1; i < 4; ++i) mx = fmaxf(mx, fmaxf(fmaxf(sacc[u][i][0], sacc[u][i][1]), fmaxf(sacc[u][i][2], sacc[u][i][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (PERM) {
+        mx = quad_rows_max(mx);
+      } else {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      }
       const float m_new = fmaxf(m_run[u], mx * p.scale_log2);
       const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
       // p = 2^(s * scale_log2 - m): one fma + one v_exp_f32 per score
@@ -194,8 +219,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         pk[u][s2].w = pack2bf(pv[2 * s2 + 1][2], pv[2 * s2 + 1][3]);
       }
     }
-    // O^T[d][query] += Vt[d][key] P^T[key][query]; k-step s covers key tiles 2s, 2s+1 with the permuted
-    // in-step order e<4 -> key (2s)*16 + fq*4 + e ; e>=4 -> key (2s+1)*16 + fq*4 + (e-4); every V fragment feeds QT MFMAs
+    // O^T[d][query] += Vt[d][key] P^T[key][query]; k-step s covers score tiles 2s, 2s+1.  PERM: their accumulators are keys
+    // 32 s + 8 fq + e in order (kperm_row); natural order: e<4 -> key (2s)*16 + fq*4 + e ; e>=4 -> key (2s+1)*16 + fq*4 + (e-4),
+    // matched by two 8-byte halves of the V^T row.  Every V fragment feeds QT MFMAs
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
@@ -208,9 +234,13 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const AttnParams p) {
         const int o0 = swz_rows(row, s2 * 4 + (fq >> 1), 8) + (fq & 1) * 4;
         const int o1 = swz_rows(row, s2 * 4 + 2 + (fq >> 1), 8) + (fq & 1) * 4;
         uint4 vk;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(&sV[o0]);
-        const uint2 a1 = *reinterpret_cast<const uint2*>(&sV[o1]);
-        vk.x = a0.x; vk.y = a0.y; vk.z = a1.x; vk.w = a1.y;
+        if (PERM) {                       // keys 32 s + 8 fq .. + 7: chunk s*4 + fq of the 128-byte V^T row
+          vk = *reinterpret_cast<const uint4*>(&sV[swz_rows(row, s2 * 4 + fq, 8)]);
+        } else {
+          const uint2 a0 = *reinterpret_cast<const uint2*>(&sV[o0]);
+          const uint2 a1 = *reinterpret_cast<const uint2*>(&sV[o1]);
+          vk.x = a0.x; vk.y = a0.y; vk.z = a1.x; vk.w = a1.y;
+        }
 #pragma unroll
         for (int u = 0; u < QT; ++u)
           oacc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), __builtin_bit_cast(bf16x8_t, pk[u][s2]), oacc[u][d], 0, 0, 0);
@@ -321,10 +351,14 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
     const bool big = (size_t)ceil_div(N, 128) * H * B >= 512;
     if (big) grid.x = ceil_div(N, 128);
+    static const bool natural = getenv("APE_ATTN_NATURAL_KEY_ORDER") != nullptr;     // A/B: the round-2 kernel (two b64 V halves, LDS shuffles)
     if (causal) {
       APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
       if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true>), grid, dim3(256), 0, s, p);
+    } else if (natural) {
+      if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false>), grid, dim3(256), 0, s, p); }
+      else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false>), grid, dim3(256), 0, s, p); }
     } else if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p); }
     else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
   } else {

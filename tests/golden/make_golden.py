@@ -39,6 +39,9 @@ CASES = {
     "L_D_lvis1203": ("L_D", 0, 2, (1024, 1024), 1203, 4),
     # config 4 flavour: a COCO-shaped (padded) image in the 1024 square
     "L_D_padded": ("L_D_coco", 0, 5, (683, 1024), 80, 3),
+    # config 3 flavour: phrase prompt at full size -- 24 phrase tokens + 232 zero bank slots = L = 256 language tokens
+    # fused DENSELY with the 87 296 vision tokens in every encoder layer; the fused tokens are the vocabulary (256 columns)
+    "L_D_phrase256": ("L_D_coco", 0, 2, (1024, 1024), 24, 9, "phrase"),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }

@@ -132,23 +132,40 @@ def _rank(key):
     return (len(ORDER), _natural(key))
 
 
-def run(model, image, text, ref_topk, semantic=None, free_run=True):
+def path_roundings(model):
+    """roundings in sequence from the image to a stage of the FREE-RUNNING pipeline (the per-stage R of ROUNDINGS summed along the
+    path): relative rms error <= GAIN * U_RMS * sqrt(R_path) -- loose (residual streams dilute each block's error) but derived"""
+    mv = model.model_vision
+    dv = len(mv.backbone.net.blocks)
+    ne, nd = mv.transformer.encoder.num_layers, mv.transformer.decoder.num_layers
+    p2 = dv * 12 + 12
+    memory = p2 + 4 + ne * 15
+    return {"p2": p2, "p6": dv * 12 + 7, "memory": memory, "enc_class": memory + 4 + 2, "pred_logits": memory + 4 + nd * 21 + 3,
+            "pred_boxes": memory + 4 + nd * 21 + 6}
+
+
+def path_bound(model, key):
+    return GAIN * U_RMS * math.sqrt(path_roundings(model)[key])
+
+
+def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name"):
     """fp32 teacher run, teacher-forced bf16 run, (optionally) free-running bf16 run of one model on one image.
     -> (forced errors {key: ...}, free-running errors {key: ...} or None, outputs dict)"""
     mv = model.model_vision
     mv.set_compute_dtype(torch.float32)
     teacher = StageTap()
-    out32 = mv.forward_single(image, text, forced_topk=ref_topk, stages=teacher, semantic=semantic)
+    out32 = mv.forward_single(image, text, forced_topk=ref_topk, stages=teacher, semantic=semantic, prompt=prompt)
     mv.set_compute_dtype(torch.bfloat16)
     forced = StageTap(teacher=teacher)
-    out_f = mv.forward_single(image, text, forced_topk=ref_topk, stages=forced, semantic=semantic)
+    out_f = mv.forward_single(image, text, forced_topk=ref_topk, stages=forced, semantic=semantic, prompt=prompt)
     ferr = stage_errors(forced, teacher)
-    free_err = out_b = None
+    free_err = out_b = free = None
     if free_run:
         free = StageTap()
-        out_b = mv.forward_single(image, text, forced_topk=ref_topk, stages=free, semantic=semantic)
+        out_b = mv.forward_single(image, text, forced_topk=ref_topk, stages=free, semantic=semantic, prompt=prompt)
         free_err = stage_errors(free, teacher)
-    return ferr, free_err, dict(fp32=out32, forced=out_f, free=out_b, teacher=teacher)
+    return ferr, free_err, dict(fp32=out32, forced=out_f, free=out_b, teacher=teacher, forced_stages=forced,
+                                free_stages=free)
 
 
 def report(tag, ferr, free_err=None, file=None):
