@@ -222,6 +222,8 @@ class DeformableDetrTransformerVL(nn.Module):
         cls2 = ops.gemm(om, P["wcls"], P["bcls"], out_dtype=torch.float32)                       # [T, 2]
         # ambiguous heads (:508-533): per token keep the (logit, box) pair with the larger logit (first on ties), add the
         # anchors, and produce the clamped corner boxes the proposal NMS works on -- one kernel (csrc/topk.hip)
+        if stages is not None:
+            cls2, d = tap(stages, "enc_cls2", cls2), tap(stages, "enc_delta8", d)
         enc_class, enc_coord, xyxy = ops.enc_finalize(cls2, d, geo.proposals)
         if stages is not None:
             stages["query_l"] = l_out

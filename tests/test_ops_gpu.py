@@ -270,11 +270,11 @@ def test_msda_half_offsets_path(ops):
     w = rnd(480, 256, dtype=torch.bfloat16, scale=0.3, seed=8)
     b = rnd(480, seed=9)
     o16 = ops.gemm(q, w, b, out_dtype=torch.float16)
-    o32 = ops.gemm(q, w, b, out_dtype=torch.float32)
-    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))            # same accumulators, one RNE rounding
     if not SELF:
         from ape_amd import _lib
-        assert b"kres_kernel<0, false, true>" in _lib.load().ape_hip_gemm_last_kernel()
+        assert b"kres_kernel<0, false, true>" in _lib.load().ape_hip_gemm_last_kernel()      # the K = 256 kernel's half-output instantiation
+    o32 = ops.gemm(q, w, b, out_dtype=torch.float32)
+    assert o16.dtype == torch.float16 and torch.equal(o16, o32.to(torch.float16))            # same accumulators, one RNE rounding
     got = ops.msda_fused(value, shapes, starts, o16, ref, out_dtype=torch.float32)
     want = ref_ops.msda_fused(value, shapes, starts, o16.float(), ref, out_dtype=torch.float32)
     e = relerr(got, want)
