@@ -16,6 +16,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators live in VGPRs (gfx950 has a unified file); without it hipcc parks them in AGPRs and
 # the softmax / epilogue code pays a v_accvgpr_read/write per value (176 of ~500 VALU slots per attention key tile)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+# per-file overrides: the fused FFN keeps 160 accumulator registers per lane next to 64 operand and 64 prefetch registers -- one
+# wave per SIMD owns the whole 512-entry file, so its accumulators belong in the AGPR half (with the VGPR form hipcc shuffles
+# them through v_accvgpr moves between the MFMAs of a batch)
+FILE_FLAGS = {"ffn_fused.hip": ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=0"]}
 
 
 def _sources():
@@ -30,6 +34,7 @@ def _digest():
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -46,7 +51,7 @@ def build(force=False, verbose=True):
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FILE_FLAGS.get(os.path.basename(src), FLAGS) + ["-c", src, "-o", obj]
         if src.endswith(".cpp"):
             cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
         if verbose:

@@ -55,12 +55,16 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 
 // QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
-template <int HD, int QT, bool CAUSAL = false, bool PERM = true>
-__global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 : 1) void attn_bf16_kernel(const AttnParams p) {
+template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p) {
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
   constexpr int DT = HD / 16;       // output d tiles
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2][64 * HD + HD * 64];  // [buf][K tile | Vt tile]
+  // two SEPARATE arrays (not one [2][...]) and a tile loop unrolled by two: with a run-time buffer index hipcc cannot tell the
+  // LDS-DMA writes of the NEXT tile from the ds_reads of the current one and drains the DMA queue (s_waitcnt vmcnt(0)) in front of
+  // the V^T reads of every tile -- the prefetch then overlaps nothing.  Distinct objects are provably disjoint.
+  __shared__ __attribute__((aligned(16))) bf16_t smemA[64 * HD + HD * 64];    // [K tile | Vt tile], even tiles
+  __shared__ __attribute__((aligned(16))) bf16_t smemB[64 * HD + HD * 64];    // odd tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
@@ -89,9 +93,10 @@ __global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 :
   constexpr int PER = HD * 8 / 256;  // instructions per wave per operand: 2 (HD=64) or 1 (HD=32)
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
-  const bf16_t* ksrc[PER];
-  const bf16_t* vsrc[PER];
-  int krow[PER];
+  // per-lane source positions as 32-bit element offsets from wave-uniform bases (64-bit per-lane pointers cost twice the registers)
+  const bf16_t* kbase = Kp + (size_t)b * p.bstride * p.ldk + h * HD;
+  const bf16_t* vbase = Vp + (size_t)(h * HD) * p.ldvt + (size_t)b * p.bstride;
+  int kcol[PER], voff[PER], krow[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int slot = (wave * PER + i) * 64 + lane;
@@ -99,21 +104,21 @@ __global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 :
       const int row = slot / KC, cp = slot % KC;
       const int c = KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
       krow[i] = row;
-      ksrc[i] = Kp + (size_t)b * p.bstride * p.ldk + h * HD + c * 8;
+      kcol[i] = c * 8;
     }
     {
       const int row = slot >> 3, cp = slot & 7;
       const int c = cp ^ ((row >> 1) & 7);
-      vsrc[i] = Vp + (size_t)(h * HD + row) * p.ldvt + (size_t)b * p.bstride + c * 8;
+      voff[i] = row * p.ldvt + c * 8;          // < HD * ldvt: 32 bits suffice (ldvt < 2^24)
     }
   }
-  auto issue = [&](int t, int buf) {
+  auto issue = [&](int t, bf16_t* dst) __attribute__((always_inline)) {
     const int key0 = t * 64;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int key = key0 + krow[i]; key = key < N ? key : N - 1;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(ksrc[i] + (size_t)key * p.ldk), (lds_void_t*)(&smem[buf][(wave * PER + i) * 512]), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(vsrc[i] + key0), (lds_void_t*)(&smem[buf][64 * HD + (wave * PER + i) * 512]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(kbase + ((size_t)key * p.ldk + kcol[i])), (lds_void_t*)(dst + (wave * PER + i) * 512), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(vbase + ((size_t)voff[i] + key0)), (lds_void_t*)(dst + 64 * HD + (wave * PER + i) * 512), 16, 0, 0);
     }
   };
 
@@ -136,13 +141,12 @@ __global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 :
     const int last_q = min(N - 1, qblk * (64 * QT) + 64 * QT - 1);
     nt = min(nt, last_q / 64 + 1);
   }
-  issue(0, 0);
+  issue(0, smemA);
   __syncthreads();                       // s_waitcnt vmcnt(0) + barrier: tile 0 has landed for every wave
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) issue(t + 1, buf ^ 1);   // lands while this tile is consumed; the buffer was released by the last barrier
-    const bf16_t* sK = &smem[buf][0];
-    const bf16_t* sV = &smem[buf][64 * HD];
+  auto tile = [&](int t, const bf16_t* cur, bf16_t* nxt) __attribute__((always_inline)) {
+    if (t + 1 < nt) issue(t + 1, nxt);       // lands while this tile is consumed; the buffer was released by the last barrier
+    const bf16_t* sK = cur;
+    const bf16_t* sV = cur + 64 * HD;
 
     // S^T[key][query] for the 64 keys of this tile: 4 key tiles x KSTEPS, every K fragment feeds QT MFMAs
     f32x4_t sacc[QT][4];
@@ -246,7 +250,11 @@ __global__ __launch_bounds__(256, (PERM && QT == 2 && HD == 64 && !CAUSAL) ? 4 :
           oacc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), __builtin_bit_cast(bf16x8_t, pk[u][s2]), oacc[u][d], 0, 0, 0);
       }
     }
-    __syncthreads();
+    __syncthreads();                       // drains this wave's DMA of tile t + 1 (issued a whole tile ago) and releases `cur`
+  };
+  for (int t = 0; t < nt; t += 2) {
+    tile(t, smemA, smemB);
+    if (t + 1 < nt) tile(t + 1, smemB, smemA);
   }
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -359,7 +367,12 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
     } else if (natural) {
       if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false>), grid, dim3(256), 0, s, p); }
       else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false>), grid, dim3(256), 0, s, p); }
-    } else if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p); }
+    } else if (HD == 64) {
+      static const bool occ4 = getenv("APE_ATTN_OCC4") != nullptr;       // A/B: cap the 128-query kernel at 128 registers (4 waves per SIMD)
+      if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4>), grid, dim3(256), 0, s, p);
+      else if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p);
+    }
     else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
   } else {
     if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);

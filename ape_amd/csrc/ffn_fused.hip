@@ -116,20 +116,44 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     const unsigned char* i1 = smem + s * FF_STAGE;
     const unsigned char* i2 = i1 + 32768;
 
-    // ---- H^T = W1c . x^T : 4 hidden tiles x 2 token tiles, 8 k steps
-    f32x4_t hacc[4][2];
-#pragma unroll
-    for (int ht = 0; ht < 4; ++ht) {
-      hacc[ht][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      hacc[ht][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // Fragment reads run ONE GROUP AHEAD of the MFMAs that consume them (two register sets of 8 fragments, ping-pong): a wave is
+    // alone on its SIMD (128 KB of LDS per workgroup), so nothing else hides the LDS latency -- left to itself hipcc emits
+    // read -> wait -> 2 MFMAs -> read ..., i.e. one exposed LDS round trip per MFMA pair (measured: 7.8 k cycles per chunk for
+    // 2 k cycles of MFMA).  The sched_barriers pin the order.
+    bf16x8_t fa[8], fb[8];
+    auto rd1 = [&](int ht, bf16x8_t (&f)[8]) __attribute__((always_inline)) {        // W1 fragments of hidden tile ht, all 8 k steps
       const int rho = ht * 16 + fm;
       const unsigned char* rowp = i1 + rho * 512;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(rowp + (((ks * 4 + g) ^ (rho & 31)) << 4)));
-        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[0][ks], hacc[ht][0], 0, 0, 0);
-        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[1][ks], hacc[ht][1], 0, 0, 0);
+      for (int ks = 0; ks < 8; ++ks) f[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(rowp + (((ks * 4 + g) ^ (rho & 31)) << 4)));
+    };
+    auto rd2 = [&](int kk, int og, bf16x8_t (&f)[8]) __attribute__((always_inline)) { // W2 fragments of channel tiles og*8 .. +7, k step kk
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rho = (og * 8 + j) * 16 + fm;
+        const int sw = (rho >> 1) & 7;
+        if (W2P) {
+          f[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(i2 + rho * 128 + (((kk * 4 + g) ^ sw) << 4)));
+        } else {
+          const unsigned char* rowp = i2 + rho * 128 + (g & 1) * 8;
+          const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + (g >> 1)) ^ sw) << 4));
+          const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + 2 + (g >> 1)) ^ sw) << 4));
+          f[j] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
       }
+    };
+    f32x4_t hacc[4][2];
+    auto mm1 = [&](int ht, const bf16x8_t (&f)[8]) __attribute__((always_inline)) {
+      hacc[ht][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      hacc[ht][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[0][ks], hacc[ht][0], 0, 0, 0);
+        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[1][ks], hacc[ht][1], 0, 0, 0);
+      }
+    };
+    bf16x8_t hb[2][2];                                                                  // [kk][rt]: the activations as B operands
+    auto act = [&](int ht) __attribute__((always_inline)) {
       // bias + ReLU: lane holds hidden c*64 + ht*16 + 4g .. +3 of token rt*16 + fm
       const float4 b = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
 #pragma unroll
@@ -139,35 +163,43 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
         hacc[ht][rt][2] = fmaxf(hacc[ht][rt][2] + b.z, 0.f);
         hacc[ht][rt][3] = fmaxf(hacc[ht][rt][3] + b.w, 0.f);
       }
-    }
-    // ---- Y^T += W2c . H^T : the activations are the B operand (k step kk = hidden tiles 2kk, 2kk + 1, permuted inside the step)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t hb[2];
+    };
+    auto pack = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         const uint4 u = make_uint4(pack2bf(hacc[2 * kk][rt][0], hacc[2 * kk][rt][1]), pack2bf(hacc[2 * kk][rt][2], hacc[2 * kk][rt][3]),
                                    pack2bf(hacc[2 * kk + 1][rt][0], hacc[2 * kk + 1][rt][1]),
                                    pack2bf(hacc[2 * kk + 1][rt][2], hacc[2 * kk + 1][rt][3]));
-        hb[rt] = __builtin_bit_cast(bf16x8_t, u);
+        hb[kk][rt] = __builtin_bit_cast(bf16x8_t, u);
       }
+    };
+    auto mm2 = [&](int kk, int og, const bf16x8_t (&f)[8]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int ot = 0; ot < 16; ++ot) {
-        const int rho = ot * 16 + fm;
-        const int sw = (rho >> 1) & 7;
-        bf16x8_t wf;
-        if (W2P) {
-          wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(i2 + rho * 128 + (((kk * 4 + g) ^ sw) << 4)));
-        } else {
-          const unsigned char* rowp = i2 + rho * 128 + (g & 1) * 8;
-          const uint2 lo = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + (g >> 1)) ^ sw) << 4));
-          const uint2 hi = *reinterpret_cast<const uint2*>(rowp + (((kk * 4 + 2 + (g >> 1)) ^ sw) << 4));
-          wf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
-        yacc[ot][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[0], yacc[ot][0], 0, 0, 0);
-        yacc[ot][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, hb[1], yacc[ot][1], 0, 0, 0);
+      for (int j = 0; j < 8; ++j) {
+        yacc[og * 8 + j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][0], yacc[og * 8 + j][0], 0, 0, 0);
+        yacc[og * 8 + j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][1], yacc[og * 8 + j][1], 0, 0, 0);
       }
-    }
+    };
+#define FF_SB() __builtin_amdgcn_sched_barrier(0)
+    // ---- H^T = W1c . x^T (4 hidden tiles x 2 token tiles x 8 k steps), then Y^T += W2c . H^T (k step kk = hidden tiles 2kk, 2kk + 1,
+    //      permuted inside the step; 16 channel tiles in two groups of 8)
+    rd1(0, fa);
+    rd1(1, fb); FF_SB();
+    mm1(0, fa); FF_SB();
+    rd1(2, fa); act(0); FF_SB();
+    mm1(1, fb); FF_SB();
+    rd1(3, fb); act(1); pack(0); FF_SB();
+    mm1(2, fa); FF_SB();
+    rd2(0, 0, fa); act(2); FF_SB();
+    mm1(3, fb); FF_SB();
+    rd2(0, 1, fb); act(3); pack(1); FF_SB();
+    mm2(0, 0, fa); FF_SB();
+    rd2(1, 0, fa); FF_SB();
+    mm2(0, 1, fb); FF_SB();
+    rd2(1, 1, fb); FF_SB();
+    mm2(1, 0, fa); FF_SB();
+    mm2(1, 1, fb); FF_SB();
+#undef FF_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (for this wave's share; the barrier covers the others)
     __syncthreads();
   }

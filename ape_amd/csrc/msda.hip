@@ -11,6 +11,8 @@
 //   are assigned to XCDs contiguously so one XCD's L2 only sees one band of every level.
 // The fused variant also does the softmax over the L*P logits and the sampling-location arithmetic
 // (multi_scale_deform_attn.py:278-311) in registers, so locations / weights never touch HBM.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -188,6 +190,31 @@ __device__ __forceinline__ void group_load(const TV* __restrict__ vb, int ldv, c
   }
 }
 
+// IEEE-half values: v_fma_mix_f32 multiplies one half of a dword (op_sel picks it) by an fp32 weight into an fp32 accumulator --
+// ONE 2-cycle instruction per channel and no unpacking.  The kernel is VALU bound (rocprofv3, profiles/r03_msda_counters_before.txt:
+// 1779 VALU instructions per wave at one quad-cycle each = 77 % of the SIMDs' time; L2 hit rate 87 %): a bf16 corner costs 8
+// shift / and unpack instructions + 4 v_pk_fma_f32 (4 cycles each), a half corner 8 v_fma_mix_f32.  hipcc does not form the
+// instruction from (float)h * w + acc (it converts, then multiplies), hence the asm; the operands are plain VGPR values, so the
+// compiler's own waitcnt bookkeeping for the loads that produced them still applies.
+__device__ __forceinline__ void fma_mix_lo(float& acc, uint32_t d, float w) {
+  asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(d), "v"(w));
+}
+__device__ __forceinline__ void fma_mix_hi(float& acc, uint32_t d, float w) {
+  asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(d), "v"(w));
+}
+template <typename TV>
+__device__ __forceinline__ void group_fma_half(const CornerGroup<TV>& g, float (&acc)[8]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t d[4] = {g.raw[c].x, g.raw[c].y, g.raw[c].z, g.raw[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      fma_mix_lo(acc[2 * e], d[e], g.w[c]);
+      fma_mix_hi(acc[2 * e + 1], d[e], g.w[c]);
+    }
+  }
+}
+
 // acc += sum_c w[c] * row[c]: the kernel is VALU bound (each lane: 80 corners x 8 channels), so one v_pk_fma_f32 per bf16 pair
 template <typename TV>
 __device__ __forceinline__ void group_fma(const CornerGroup<TV>& g, f32x2_t (&a2)[4]) {
@@ -283,7 +310,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   // Software pipeline over the L*4 samples: the 4 loads of sample s+1 are issued before the FMAs of sample s; the
   // sched_barriers pin that order (left alone the compiler hoists all 80 loads and spills).
   float acc[8];
-  if (sizeof(TV) == 2) {
+  if (std::is_same<TV, f16_t>::value) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    CornerGroup<TV> g0, g1;
+    group_load<TV, L>(vb, p.ldv, cw, ci, 0, g0);
+#pragma unroll
+    for (int s = 0; s < L * 4; s += 2) {
+      group_load<TV, L>(vb, p.ldv, cw, ci, s + 1, g1);
+      __builtin_amdgcn_sched_barrier(0);
+      group_fma_half<TV>(g0, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 2 < L * 4) group_load<TV, L>(vb, p.ldv, cw, ci, s + 2, g0);
+      __builtin_amdgcn_sched_barrier(0);
+      group_fma_half<TV>(g1, acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if (sizeof(TV) == 2) {
     f32x2_t a2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) a2[e] = (f32x2_t){0.f, 0.f};
@@ -412,6 +455,8 @@ static int msda_fused_launch(const void* value, int ldv, int v_dt, const int64_t
   hipStream_t s = (hipStream_t)stream;
   if (v_dt == APE_DT_BF16 && out_dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, true>(p, B, L, s);
   else if (v_dt == APE_DT_BF16 && out_dt == APE_DT_F32) rc = launch_msda<bf16_t, float, true>(p, B, L, s);
+  else if (v_dt == APE_DT_F16 && out_dt == APE_DT_BF16) rc = launch_msda<f16_t, bf16_t, true>(p, B, L, s);    // half values (production)
+  else if (v_dt == APE_DT_F16 && out_dt == APE_DT_F32) rc = launch_msda<f16_t, float, true>(p, B, L, s);
   else if (v_dt == APE_DT_F32 && out_dt == APE_DT_F32) rc = launch_msda<float, float, true>(p, B, L, s);
   else { ape_set_error("msda_fused: unsupported dtype combination v=%d out=%d", v_dt, out_dt); return -1; }
   if (rc) return rc;
@@ -430,7 +475,7 @@ extern "C" int ape_hip_msda_fused(const void* value, int ldv, int v_dt, const in
 extern "C" int ape_hip_msda_fused_h(const void* value, int ldv, int v_dt, const int64_t* spatial_shapes,
                                     const int64_t* level_start_index, const void* offw_f16, int ldoffw, const float* ref,
                                     int refdim, void* out, int ldout, int out_dt, int B, int S, int Q, int L, void* stream) {
-  APE_CHECK_ARG(v_dt == APE_DT_BF16, "msda_fused_h: bf16 values (the production mode)");
+  APE_CHECK_ARG(v_dt == APE_DT_BF16 || v_dt == APE_DT_F16, "msda_fused_h: bf16 or f16 values (the production modes)");
   return msda_fused_launch(value, ldv, v_dt, spatial_shapes, level_start_index, offw_f16, ldoffw, 1, ref, refdim, out, ldout, out_dt, B, S, Q,
                            L, stream);
 }

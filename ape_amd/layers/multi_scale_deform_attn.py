@@ -46,6 +46,19 @@ def _register_torch_op():
 _TORCH_LIB = _register_torch_op()
 
 
+HALF_MAX = 65504.0
+
+
+def half_value_kwargs(dt, rows):
+    """production mode (bf16), >= 2048 value rows: the value projection is written as IEEE HALF, saturated at +-65504.  The sampler
+    is VALU bound and consumes a half value with one v_fma_mix_f32 per channel (a bf16 value must be unpacked first: -40 % VALU
+    work, csrc/msda.hip), and half keeps 11 significant bits instead of 8.  The K = 256 GEMM kernel produces half only from 2048
+    rows on, which is every encoder / decoder value projection of the full-size models; APE_MSDA_BF16_VALUE=1 keeps bf16."""
+    if dt == torch.bfloat16 and rows >= 2048 and os.environ.get("APE_MSDA_BF16_VALUE") != "1":
+        return dict(out_dtype=torch.float16, clamp=HALF_MAX)
+    return {}
+
+
 class MultiScaleDeformableAttention(nn.Module):
     def __init__(self, embed_dim=256, num_heads=8, num_levels=4, num_points=4, img2col_step=64, dropout=0.1,
                  batch_first=False, pytorch_attn=False):
@@ -79,7 +92,8 @@ class MultiScaleDeformableAttention(nn.Module):
         Either value_src [S,256] (projected here, padded rows zeroed with `mask`) or a pre-projected `value`."""
         P = self.packed(dt)
         if value is None:
-            value = ops.gemm(value_src, P["wval"], P["bval"], rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT)
+            value = ops.gemm(value_src, P["wval"], P["bval"], rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT,
+                             **half_value_kwargs(dt, value_src.shape[0]))
         # offsets | logits: fp32 in validation mode and for the decoder's 900 queries; IEEE half for the encoder's 87 k tokens in
         # production mode -- that GEMM is bound by the bytes it writes (168 MB per layer in fp32) and the sampler reads them
         # back; half keeps 11 significant bits (offsets are a few pixels, logits feed a 20-way softmax)

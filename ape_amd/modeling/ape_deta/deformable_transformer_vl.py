@@ -95,7 +95,9 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         P = self.packed(dt)
         E = self.embed_dim
         # value_proj of all layers in ONE pass over the encoder memory (the reference re-reads it per layer)
-        value_all = ops.gemm(memory, P["wval"], P["bval"], rowmask=geo.mask_u8, mask_mode=ops.MASK_ZERO_OUTPUT)
+        from ...layers.multi_scale_deform_attn import half_value_kwargs
+        value_all = ops.gemm(memory, P["wval"], P["bval"], rowmask=geo.mask_u8, mask_mode=ops.MASK_ZERO_OUTPUT,
+                             **half_value_kwargs(dt, memory.shape[0]))
         Q = query.shape[0]
         vt_buf = torch.zeros((E, round_up(Q, 64)), dtype=dt, device=query.device)
         vr4 = geo.vr4                                                   # [L, 4] = cat(valid_ratios, valid_ratios)

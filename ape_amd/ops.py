@@ -304,8 +304,8 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
 def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, out_dtype=None, out=None):
     """Fused softmax + sampling-location + bilinear gather (multi_scale_deform_attn.py:278-348).
 
-    value [batch*S, >=256] (row-major view), offw [batch*Q, 8*L*4*3] fp32 or (bf16 values only) fp16 (offsets then logits),
-    ref [batch*Q, L, 2|4] fp32 -> [batch*Q, 256].
+    value [batch*S, >=256] (row-major view; f32, bf16 or IEEE half), offw [batch*Q, 8*L*4*3] fp32 or (bf16 / half values only)
+    fp16 (offsets then logits), ref [batch*Q, L, 2|4] fp32 -> [batch*Q, 256].
     """
     _dev(value, offw, ref, out)
     _rowmajor(value, "value"), _rowmajor(offw, "offw")
@@ -319,7 +319,10 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     if out is None:
         out = torch.empty((batch * Q, 256), dtype=out_dtype or value.dtype, device=value.device)
     fn = _lib.load().ape_hip_msda_fused_h if offw.dtype == torch.float16 else _lib.load().ape_hip_msda_fused
-    rc = fn(_p(value), _ld(value), _dt(value), shp, st, _p(offw), _ld(offw), _p(ref), ref.shape[-1], _p(out), _ld(out), _dt(out),
+    v_dt = _lib.DT_F16 if value.dtype == torch.float16 else _dt(value)          # IEEE-half values: bf16 / f32 output
+    if value.dtype == torch.float16 and out is None and out_dtype is None:
+        raise TypeError("ape_amd.ops.msda_fused: half values need an explicit out / out_dtype (bfloat16 or float32)")
+    rc = fn(_p(value), _ld(value), v_dt, shp, st, _p(offw), _ld(offw), _p(ref), ref.shape[-1], _p(out), _ld(out), _dt(out),
             batch, S, Q, L, _stream())
     _lib.check(rc, "ape_hip_msda_fused")
     return out

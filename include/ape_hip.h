@@ -159,7 +159,9 @@ int ape_hip_groupnorm(const ApeGroupNormArgs* args, void* stream);
  * ape_hip_msda_fused additionally folds multi_scale_deform_attn.py:278-311 (softmax over L*P,
  *   sampling-location arithmetic for 2-d and 4-d reference points) into the sampler:
  *   offw [B*Q, ldoffw] fp32: columns [0, M*L*P*2) raw sampling offsets, then M*L*P raw logits;
- *   ref [B*Q, L, refdim] fp32.
+ *   ref [B*Q, L, refdim] fp32.  v_dt: 0 = f32, 1 = bf16, 2 = IEEE half values (out_dt 1 = bf16 or 0 = f32): the sampler is VALU
+ *   bound and a half value needs no unpacking (one v_fma_mix_f32 per channel and corner), so the production path projects the
+ *   values to half (ape_hip_gemm, out_dt = APE_DT_F16) -- 11 significant bits instead of bf16's 8.
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_ms_deform_attn_forward(const void* value, int ldv, const int64_t* spatial_shapes,
                                    const int64_t* level_start_index, const void* sampling_loc,

@@ -259,6 +259,31 @@ def test_msda_fused(ops, dtype, refdim, shapes, Q):
         assert relerr(got32, want) < 1e-4
 
 
+@pytest.mark.parametrize("refdim,Q", [(2, 20000), (4, 900), (2, 341)])
+def test_msda_half_values(ops, refdim, Q):
+    """production path: values projected to IEEE half (saturating K = 256 GEMM), consumed by the sampler with v_fma_mix_f32;
+    vs the definition on the SAME half tensor (fp32 and half offsets), and the masked / saturating value projection itself"""
+    shapes = [(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)] if Q > 341 else [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    value, shapes, starts, offw, ref, S = _msda_inputs(shapes, Q, refdim, torch.bfloat16)
+    vh = (value.float() * 3.0).to(torch.float16)                    # a genuinely half tensor (values off the bf16 grid)
+    for ow in (offw, offw.to(torch.float16)):
+        want = ref_ops.msda_fused(vh, shapes, starts, ow.float(), ref, out_dtype=torch.float32)
+        got32 = ops.msda_fused(vh, shapes, starts, ow, ref, out_dtype=torch.float32)
+        got16 = ops.msda_fused(vh, shapes, starts, ow, ref, out_dtype=torch.bfloat16)
+        e32, e16 = relerr(got32, want), relerr(got16, want)
+        print(f"msda_fused half values refdim{refdim} Q{Q} offsets {ow.dtype}: f32 out {e32:.3e}, bf16 out {e16:.3e}")
+        assert e32 < 1e-4 and e16 < TOL[torch.bfloat16]
+    if S >= 2048:
+        x = rnd(S, 256, dtype=torch.bfloat16, seed=11)
+        w, b = rnd(256, 256, dtype=torch.bfloat16, scale=1 / 16, seed=12), rnd(256, seed=13)
+        b[3] = 1e6                                                   # one column saturates
+        mask = (torch.arange(S) % 7 == 0).to(torch.uint8).to(DEV)
+        got = ops.gemm(x, w, b, rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT, out_dtype=torch.float16, clamp=65504.0)
+        want = ref_ops.gemm(x, w, b, rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT, out_dtype=torch.float16, clamp=65504.0)
+        assert got.dtype == torch.float16 and torch.isfinite(got.float()).all() and float(got[1, 3]) == 65504.0 and float(got[0, 3]) == 0.0
+        assert relerr(got, want) < 1e-3
+
+
 def test_msda_half_offsets_path(ops):
     """production encoder path: the K = 256 offset | logit GEMM writes IEEE half, the sampler reads it (exactly the rounded
     values: vs the definition on the SAME half tensor the sampler matches like the fp32 path; vs fp32 offsets the difference

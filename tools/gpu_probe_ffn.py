@@ -45,10 +45,14 @@ def main():
         if err > 6e-3:
             print("MISMATCH -- stop here")
             return
+    from ape_amd.packing import permute_ffn_w2
+    w2p = permute_ffn_w2(w2)
     t_f = bench(lambda: ops.ffn_fused(x, w1, b1, w2, b2, residual=x))
+    t_p = bench(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True))
     t_2 = bench(lambda: ops.gemm(ops.gemm(x, w1, b1, act=ops.ACT_RELU), w2, b2, residual=x))
     fl = 2.0 * M * 256 * HID * 2
-    print(f"87296 x 256 -> 2048 -> 256: fused {t_f:.1f} us ({fl / t_f / 1e6:.0f} TF/s)   two GEMMs {t_2:.1f} us")
+    print(f"87296 x 256 -> 2048 -> 256: fused, row-major W2 {t_f:.1f} us ({fl / t_f / 1e6:.0f} TF/s)   fused, pre-permuted W2 {t_p:.1f} us "
+          f"({fl / t_p / 1e6:.0f} TF/s)   two GEMMs {t_2:.1f} us")
 
 
 if __name__ == "__main__":
