@@ -116,11 +116,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     const unsigned char* i1 = smem + s * FF_STAGE;
     const unsigned char* i2 = i1 + 32768;
 
-    // Fragment reads run ONE GROUP AHEAD of the MFMAs that consume them (two register sets of 8 fragments, ping-pong): a wave is
+    // Fragment reads run AHEAD of the MFMAs that consume them (three register sets of 8 fragments, rotating): a wave is
     // alone on its SIMD (128 KB of LDS per workgroup), so nothing else hides the LDS latency -- left to itself hipcc emits
     // read -> wait -> 2 MFMAs -> read ..., i.e. one exposed LDS round trip per MFMA pair (measured: 7.8 k cycles per chunk for
     // 2 k cycles of MFMA).  The sched_barriers pin the order.
-    bf16x8_t fa[8], fb[8];
+    bf16x8_t fa[8], fb[8], fc[8];
+    float4 bch[4];
     auto rd1 = [&](int ht, bf16x8_t (&f)[8]) __attribute__((always_inline)) {        // W1 fragments of hidden tile ht, all 8 k steps
       const int rho = ht * 16 + fm;
       const unsigned char* rowp = i1 + rho * 512;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     bf16x8_t hb[2][2];                                                                  // [kk][rt]: the activations as B operands
     auto act = [&](int ht) __attribute__((always_inline)) {
       // bias + ReLU: lane holds hidden c*64 + ht*16 + 4g .. +3 of token rt*16 + fm
-      const float4 b = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
+      const float4 b = bch[ht];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         hacc[ht][rt][0] = fmaxf(hacc[ht][rt][0] + b.x, 0.f);
@@ -183,22 +184,34 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
     // ---- H^T = W1c . x^T (4 hidden tiles x 2 token tiles x 8 k steps), then Y^T += W2c . H^T (k step kk = hidden tiles 2kk, 2kk + 1,
     //      permuted inside the step; 16 channel tiles in two groups of 8)
-    rd1(0, fa);
-    rd1(1, fb); FF_SB();
+    // three register sets, reads TWO groups ahead of the MFMAs (one group ahead left ~200 exposed cycles at every batch boundary);
+    // the bias / ReLU / pack VALU of hidden tile ht - 1 is interleaved with the MFMAs of tile ht (two VALU per MFMA slot) instead
+    // of standing between two batches with the matrix pipe idle
+#define FF_MIX()                                          \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    \
+  }
+    // the chunk's four bias quads first: read behind the fragments they would turn every counted lgkmcnt wait into a full drain
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) bch[ht] = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
+    FF_SB();
+    rd1(0, fa); rd1(1, fb); FF_SB();
+    rd1(2, fc); FF_SB();
     mm1(0, fa); FF_SB();
-    rd1(2, fa); act(0); FF_SB();
-    mm1(1, fb); FF_SB();
-    rd1(3, fb); act(1); pack(0); FF_SB();
-    mm1(2, fa); FF_SB();
-    rd2(0, 0, fa); act(2); FF_SB();
-    mm1(3, fb); FF_SB();
-    rd2(0, 1, fb); act(3); pack(1); FF_SB();
-    mm2(0, 0, fa); FF_SB();
+    rd1(3, fa); FF_SB();
+    act(0); mm1(1, fb); FF_MIX(); FF_SB();
+    rd2(0, 0, fb); FF_SB();
+    act(1); pack(0); mm1(2, fc); FF_MIX(); FF_SB();
+    rd2(0, 1, fc); FF_SB();
+    act(2); mm1(3, fa); FF_MIX(); FF_SB();
     rd2(1, 0, fa); FF_SB();
-    mm2(0, 1, fb); FF_SB();
+    act(3); pack(1); mm2(0, 0, fb); FF_MIX(); FF_SB();
     rd2(1, 1, fb); FF_SB();
+    mm2(0, 1, fc); FF_SB();
     mm2(1, 0, fa); FF_SB();
     mm2(1, 1, fb); FF_SB();
+#undef FF_MIX
 #undef FF_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (for this wave's share; the barrier covers the others)
     __syncthreads();

@@ -88,10 +88,29 @@ def _f(t):
     return t.detach().float()
 
 
-def stage_errors(got, teacher, biases=None):
-    """-> {key: dict(rms, max, tol, tol_max, R, n)} for every key the teacher-forced run tapped and the table knows"""
+def linear_head_scales(model, teacher):
+    """For a head that is ONE linear map of a teacher-forced input (enc_cls2 / enc_class = output_memory . Wcls^T + b), the first-order
+    rounding model can be evaluated exactly instead of through the output's rms: y = sum_k x_k w_k with independent relative errors
+    of rms u on every x_k and w_k has error rms u sqrt(2) sqrt(sum_k (x_k w_k)^2).  The term norm sqrt(sum_k (x_k w_k)^2) is the right
+    denominator -- the output itself can be much smaller than its terms (cancellation: measured rms(y - b) / rms(term norm) ~ 0.5
+    for this head on the seeded weights).  -> {key: rms of the term norm over the tokens}"""
+    if "output_memory" not in teacher:
+        return {}
+    dec = model.model_vision.transformer.decoder
+    nd = dec.num_layers
+    W = torch.cat([dec.class_embed[nd].weight.detach().float(), dec.class_embed_ambiguous[0].weight.detach().float()], 0)   # [2, 256]
+    x = teacher["output_memory"].detach().float()
+    tn = ((x * x) @ (W * W).t().to(x.device)).sqrt()                                                                       # [T, 2]
+    s = float(tn.pow(2).mean().sqrt())
+    return {"enc_cls2": s, "enc_class": s}
+
+
+def stage_errors(got, teacher, biases=None, scales=None):
+    """-> {key: dict(rms, max, tol, tol_max, R, n)} for every key the teacher-forced run tapped and the table knows.
+    scales: {key: absolute rms scale} replaces the denominator rms(ref) (linear_head_scales)"""
     res = {}
     biases = biases or {}
+    scales = scales or {}
     for key, g in got.items():
         if key not in teacher or not torch.is_tensor(g) or not g.is_floating_point():
             continue
@@ -124,7 +143,10 @@ def stage_errors(got, teacher, biases=None):
         tol = tolerance(key)
         if tol is None:
             continue
-        if BIASED.search(key):
+        if key in scales:
+            rms = ((g - t).pow(2).mean().sqrt() / scales[key]).item()
+            mx = ((g - t).abs().max() / scales[key]).item()
+        elif BIASED.search(key):
             tc = t - biases.get(key, float(t.mean()))
             rms = ((g - t).pow(2).mean().sqrt() / tc.pow(2).mean().sqrt().clamp_min(1e-30)).item()
             mx = ((g - t).abs().max() / tc.abs().max().clamp_min(1e-30)).item()
@@ -176,8 +198,8 @@ def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name
     mv.set_compute_dtype(torch.bfloat16)
     forced = StageTap(teacher=teacher)
     out_f = mv.forward_single(image, text, forced_topk=ref_topk, stages=forced, semantic=semantic, prompt=prompt)
-    biases = head_biases(model)
-    ferr = stage_errors(forced, teacher, biases)
+    biases, scales = head_biases(model), linear_head_scales(model, teacher)
+    ferr = stage_errors(forced, teacher, biases, scales)
     if "enc_cls2" in forced and "enc_cls2" in teacher:          # tokens whose main / ambiguous choice a rounding flipped
         flips = int((forced["enc_cls2"].float().argmax(1) != teacher["enc_cls2"].float().argmax(1).to(forced["enc_cls2"].device)).sum())
         ferr["enc_cls2"]["flips"] = flips
@@ -185,7 +207,7 @@ def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name
     if free_run:
         free = StageTap()
         out_b = mv.forward_single(image, text, forced_topk=ref_topk, stages=free, semantic=semantic, prompt=prompt)
-        free_err = stage_errors(free, teacher, biases)
+        free_err = stage_errors(free, teacher, biases, scales)
     return ferr, free_err, dict(fp32=out32, forced=out_f, free=out_b, teacher=teacher, forced_stages=forced,
                                 free_stages=free)
 

@@ -71,8 +71,8 @@ def main():
         mv.forward_single(image, text, forced_topk=ref_topk, stages=forced)
         free = TF.StageTap()
         mv.forward_single(image, text, forced_topk=ref_topk, stages=free)
-        biases = TF.head_biases(model)
-        ferr, rerr = TF.stage_errors(forced, teacher, biases), TF.stage_errors(free, teacher, biases)
+        biases, scales = TF.head_biases(model), TF.linear_head_scales(model, teacher)
+        ferr, rerr = TF.stage_errors(forced, teacher, biases, scales), TF.stage_errors(free, teacher, biases, scales)
         TF.report(case, ferr, rerr)
         box_trace(case, dict(teacher=teacher, free_stages=free, forced_stages=forced))
         bad = TF.violations(ferr)
