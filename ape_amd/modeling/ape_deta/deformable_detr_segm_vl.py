@@ -70,11 +70,10 @@ class DeformableDETRSegmVL(nn.Module):
         self.transformer.decoder.class_embed[-1] = nn.Linear(embed_dim, 1)   # class-agnostic encoder classifier (:178-179)
         if self.transformer.proposal_ambiguous:
             n = self.transformer.proposal_ambiguous
-            assert n == 1, "ape_amd implements proposal_ambiguous in {0 -> unsupported, 1}"
+            assert n == 1, "ape_amd implements proposal_ambiguous in {0, 1}"
             self.transformer.decoder.bbox_embed_ambiguous = nn.ModuleList([MLP(embed_dim, embed_dim, 4, 3) for _ in range(n)])
             self.transformer.decoder.class_embed_ambiguous = nn.ModuleList([nn.Linear(embed_dim, 1) for _ in range(n)])
-        else:
-            raise NotImplementedError("ape_amd: proposal_ambiguous=0 (the eval scripts set it to 1)")
+        # proposal_ambiguous = 0 (the plain transformer of APE-L_A/B/C): no ambiguous copies (deformable_detr.py:181-200)
         self.select_box_nums_for_evaluation = select_box_nums_for_evaluation
         self.select_box_nums_for_evaluation_list = select_box_nums_for_evaluation_list
         self.test_topk_per_image = select_box_nums_for_evaluation
@@ -121,8 +120,9 @@ class DeformableDETRSegmVL(nn.Module):
             self.name_prompt_fusion_feature = nn.Parameter(torch.zeros(1, 1, embed_dim_language), requires_grad=False)
         elif name_prompt_fusion_type == "learnable":
             self.name_prompt_fusion_feature = nn.Parameter(torch.randn(1, 1, embed_dim_language))
-        else:
-            raise NotImplementedError("ape_amd: name_prompt_fusion_type must be 'zero' or 'learnable' (fusion needs a token)")
+        elif getattr(self.transformer.encoder, "vl_layers", None) is not None:
+            raise NotImplementedError("ape_amd: with fusion layers name_prompt_fusion_type must be 'zero' or 'learnable' (fusion needs a token)")
+        # "none" on the plain encoder (no fusion layers): there is no fusion token and no parameter for one
         self.model_language = None
         self.compute_dtype = torch.bfloat16
         self._geo, self._text = {}, {}
@@ -200,7 +200,7 @@ class DeformableDETRSegmVL(nn.Module):
                 w = m.weight.detach().float()
                 return pack_matrix(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1), dt)
             neck = [(pack_matrix(c.conv.weight.detach().reshape(c.conv.weight.shape[0], -1), dt), f32(c.conv.bias),
-                     f32(c.norm.weight), f32(c.norm.bias), c.norm.num_groups, c.norm.eps) for c in self.neck.convs]
+                     f32(c.norm.weight), f32(c.norm.bias), c.norm.num_groups, c.norm.eps) for c in self.neck.convs] if self.neck is not None else None
             gn = lambda m: (f32(m.norm.weight), f32(m.norm.bias), m.norm.num_groups, m.norm.eps)  # noqa: E731
             return dict(neck=neck, lat=(conv(self.lateral_conv),) + gn(self.lateral_conv),
                         outc=(conv(self.output_conv),) + gn(self.output_conv), maskc=conv(self.mask_conv))
@@ -288,6 +288,8 @@ class DeformableDETRSegmVL(nn.Module):
           * persistent bank (the APE-*_D default) while evaluating a dataset: the rows kept from earlier images act as
             negatives, then the bank is overwritten with the current tokens (stateful, in place);
           * otherwise (free-text prompts, dataset_id = -1, no reset): just the current tokens."""
+        if getattr(self.transformer.encoder, "vl_layers", None) is None:
+            return None                                                     # plain encoder (APE-L_A/B/C): nothing is fused
         if prompt == "name":
             nft = self.name_prompt_fusion_text
             if nft is not None and nft[self.eval_dataset_id]:          # (:343-347) ODinW-style: fuse the class names themselves
@@ -342,7 +344,8 @@ class DeformableDETRSegmVL(nn.Module):
         else:
             maps = self.backbone.forward_tokens(image.contiguous(), self._mean, self._std, vit_feat=vit_feat)
         self.backbone_time = time.perf_counter() - t0
-        names = self.neck.in_features
+        # neck = None (APE-L_A/B/C, ape_deta_vitl_eva02_lsj1024_cp_12ep.py:21): the pyramid's maps, in its order, are the levels
+        names = self.neck.in_features if self.neck is not None else list(maps.keys())
         level_shapes = [maps[f][1] for f in names]
         if geo is None:
             geo = self.geometry((h, w), level_shapes)
@@ -351,6 +354,9 @@ class DeformableDETRSegmVL(nn.Module):
         t0 = time.perf_counter()
         src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
         def neck_level(i, f):
+            if P["neck"] is None:
+                src[geo.starts[i]:geo.starts[i] + maps[f][0].shape[0]].copy_(maps[f][0])
+                return
             wn, bn, gw, gb, groups, eps = P["neck"][i]
             t = ops.gemm(maps[f][0], wn, bn)
             ops.groupnorm(t, gw, gb, groups, eps, out=src[geo.starts[i]:geo.starts[i] + t.shape[0]])

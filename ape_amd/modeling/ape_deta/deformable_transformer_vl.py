@@ -34,25 +34,36 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
         self.embed_dim = embed_dim
         self.pre_norm = False
         self.post_norm_layer = nn.LayerNorm(embed_dim) if post_norm else None
-        self.vl_layers = nn.ModuleList([copy.deepcopy(vl_layer) for _ in range(num_layers)])
+        # vl_layer=None: the plain encoder of APE-L_A/B/C (deformable_transformer.py:20-106) -- no fusion, no `vl_layers` in the
+        # state dict
+        self.vl_layers = nn.ModuleList([copy.deepcopy(vl_layer) for _ in range(num_layers)]) if vl_layer is not None else None
         self.use_checkpoint = use_act_checkpoint
 
     def forward_tokens(self, x, geo, lvl_pos, l, dt, stages=None):
         """x [T,256], l [1, l_dim] fp32 -> (memory [T,256], l) -- reference loop :84-115"""
-        for i, (vl, layer) in enumerate(zip(self.vl_layers, self.layers)):
-            # the language update feeds only the next layer's fusion: it runs as a parallel branch next to this layer's
-            # deformable attention and FFN and is joined at the end of the layer
-            v_new, qp, ljob = vl.b_attn.forward_tokens(x, lvl_pos, l, dt, defer_language=True)
+        xp = None
+        for i, layer in enumerate(self.layers):
+            if self.vl_layers is None:
+                # plain encoder: the layer's input is its value, x + pos its query (the previous layer's last LayerNorm wrote both)
+                v_new, qp, ljob = x, (xp if xp is not None else (x.float() + lvl_pos.float()).to(dt)), ops._Joined(l)
+            else:
+                # the language update feeds only the next layer's fusion: it runs as a parallel branch next to this layer's
+                # deformable attention and FFN and is joined at the end of the layer
+                v_new, qp, ljob = self.vl_layers[i].b_attn.forward_tokens(x, lvl_pos, l, dt, defer_language=True)
             # BaseTransformerLayer ("self_attn", "norm", "ffn", "norm"): value = fused tokens (no pos), identity = same
             x1 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
                                                     mask=geo.mask_u8)
             x2 = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt)
             x3 = layer.ffns[0].forward_tokens(x2, dt)
-            x = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt)
+            if self.vl_layers is None and stages is None:
+                x, xp = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt, add=lvl_pos)
+            else:
+                x, xp = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt), None
             l = ljob.join()
             if stages is not None:
-                stages[f"enc{i}_fused_v"] = v_new
-                l = tap(stages, f"enc{i}_fused_l", l)
+                if self.vl_layers is not None:
+                    stages[f"enc{i}_fused_v"] = v_new
+                    l = tap(stages, f"enc{i}_fused_l", l)
                 x = tap(stages, f"enc{i}_out", x)
         if self.post_norm_layer is not None:
             x = ops.layernorm(x, f32(self.post_norm_layer.weight), f32(self.post_norm_layer.bias), self.post_norm_layer.eps, out_dtype=dt)
@@ -170,8 +181,11 @@ class DeformableDetrTransformerVL(nn.Module):
         def build(dt):
             dec = self.decoder
             nd = dec.num_layers
-            be, bea = dec.bbox_embed[nd], dec.bbox_embed_ambiguous[0]
-            ce, cea = dec.class_embed[nd], dec.class_embed_ambiguous[0]
+            # proposal_ambiguous = 0 (APE-L_A/B/C): the "ambiguous" copy is the main head itself -- the per-token maximum of two
+            # identical logits keeps the first (= the main) pair, so the same kernels produce the single-head result
+            amb = bool(self.proposal_ambiguous)
+            be, bea = dec.bbox_embed[nd], (dec.bbox_embed_ambiguous[0] if amb else dec.bbox_embed[nd])
+            ce, cea = dec.class_embed[nd], (dec.class_embed_ambiguous[0] if amb else dec.class_embed[nd])
             return dict(
                 wenc=pack_matrix(self.enc_output.weight, dt), benc=f32(self.enc_output.bias),
                 nenc=(f32(self.enc_output_norm.weight), f32(self.enc_output_norm.bias), self.enc_output_norm.eps),

@@ -33,11 +33,38 @@ SIZES = {
                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02"),
     # APE-L_A / L_B / L_C: the EVA-02 MIM ViT-L of vit_eva02.py (configs/common/backbone/vitl_eva02.py:10-41: 16 x 16 windows on the
     # 64 x 64 grid, every sixth block global, separate q/k/v projections, SwiGLU with its sub-LayerNorm)
+    # ... under the PLAIN model family (vl=False): DeformableDETRSegm on DeformableDetrTransformer, neck = None, no ambiguous heads
+    # (configs/COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py:24-137 + ape_deta_vitl_eva02_lsj1024_cp_12ep.py:19-33)
     "L_A": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=16, pretrain_img_size=224, enc_layers=6,
-                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02", subln=True, global_every=6),
+                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02", subln=True, global_every=6, vl=False),
+    "small_A": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=2,
+                    dec_layers=2, num_queries=300, topk_eval=50, backbone="eva02", subln=True, global_every=3, vl=False),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
 }
+
+
+def _build_plain(c, backbone, shapes, model_language, vision_kwargs):
+    """APE-L_A/B/C: the reference's DeformableDETRSegm / DeformableDetrTransformer (no vision-language fusion), neck = None"""
+    from .ape_deta import (DeformableDETRSegm, DeformableDetrTransformer, DeformableDetrTransformerDecoder,
+                           DeformableDetrTransformerEncoder)
+    encoder = DeformableDetrTransformerEncoder(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0, ffn_dropout=0.0,
+                                               num_layers=c.enc_layers, post_norm=False, num_feature_levels=5)
+    decoder = DeformableDetrTransformerDecoder(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0, ffn_dropout=0.0,
+                                               num_layers=c.dec_layers, return_intermediate=True, num_feature_levels=5)
+    transformer = DeformableDetrTransformer(encoder=encoder, decoder=decoder, as_two_stage=True, num_feature_levels=5,
+                                            two_stage_num_proposals=c.num_queries, assign_first_stage=True)
+    vkw = dict(
+        backbone=backbone, position_embedding=PositionEmbeddingSine(num_pos_feats=128, temperature=10000, normalize=True, offset=-0.5),
+        neck=None, transformer=transformer, embed_dim=256, num_classes=1256, num_queries=c.num_queries, criterion=[],
+        pixel_mean=[123.675, 116.280, 103.530], pixel_std=[58.395, 57.120, 57.375], aux_loss=True, with_box_refine=True,
+        as_two_stage=True, select_box_nums_for_evaluation=c.topk_eval, input_format="RGB", mask_encode_level=0,
+        mask_in_features=["p2"], input_shapes=shapes, embed_dim_language=1024, instance_on=True, semantic_on=False,
+        panoptic_on=False, dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"], stuff_prob_thing=0.9)
+    vkw.update(vision_kwargs or {})
+    model = SomeThing(model_vision=DeformableDETRSegm(**vkw), model_language=model_language)
+    model.eval()
+    return model
 
 
 def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
@@ -61,6 +88,8 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
     backbone = SimpleFeaturePyramid(net=net, in_feature="last_feat", out_channels=256, scale_factors=(4.0, 2.0, 1.0, 0.5),
                                     top_block=LastLevelMaxPool(), norm="LN", square_pad=c.img_size)
     shapes = {f: SimpleNamespace(channels=256) for f in feats}
+    if not getattr(c, "vl", True):
+        return _build_plain(c, backbone, shapes, model_language, vision_kwargs)
     neck = ChannelMapper(input_shapes=shapes, in_features=feats, out_channels=256, num_outs=5, kernel_size=1,
                          norm_layer=nn.GroupNorm(num_groups=32, num_channels=256))
     vl = VisionLanguageFusion(v_dim=256, l_dim=1024, embed_dim=2048, num_heads=8, dropout=0.1, drop_path=0.0,

@@ -92,7 +92,9 @@ class ApeOracle:
         self.num_heads_vit = cfg["num_heads"]
         self.depth = cfg["depth"]
         self.ws = cfg["window_size"]
-        self.win_blocks = set(window_block_indexes(self.depth))
+        ge = cfg.get("global_every", 3)      # every ge-th block is global (vitl_eva02_clip.py:21-28: 3; vitl_eva02.py:21-24: 6)
+        self.win_blocks = set(window_block_indexes(self.depth)) if ge == 3 else {i for i in range(self.depth) if i % ge != ge - 1}
+        self.vl = bool(cfg.get("vl", True))  # False: APE-L_A/B/C -- DeformableDETRSegm on the plain DeformableDetrTransformer
         self.num_levels = 5
         self.nq = cfg["num_queries"]
         self.enc_layers, self.dec_layers = cfg["enc_layers"], cfg["dec_layers"]
@@ -186,9 +188,14 @@ class ApeOracle:
         x = x.reshape(B, N, C)
         nh = self.num_heads_vit
         q_bias, v_bias = self.p(pre + "q_bias"), self.p(pre + "v_bias")
-        qkv = F.linear(x, self.p(pre + "qkv.weight"), torch.cat((q_bias, torch.zeros_like(v_bias), v_bias)))
-        qkv = qkv.reshape(B, N, 3, nh, -1).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]
+        if self.cfg.get("subln"):            # vit_eva02.py:250-257: separate projections (q_bias / no k bias / v_bias), no inner LayerNorm
+            q = F.linear(x, self.p(pre + "q_proj.weight"), q_bias).reshape(B, N, nh, -1).permute(0, 2, 1, 3)
+            k = F.linear(x, self.p(pre + "k_proj.weight"), None).reshape(B, N, nh, -1).permute(0, 2, 1, 3)
+            v = F.linear(x, self.p(pre + "v_proj.weight"), v_bias).reshape(B, N, nh, -1).permute(0, 2, 1, 3)
+        else:
+            qkv = F.linear(x, self.p(pre + "qkv.weight"), torch.cat((q_bias, torch.zeros_like(v_bias), v_bias)))
+            qkv = qkv.reshape(B, N, 3, nh, -1).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
         cos, sin = rope
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
@@ -213,6 +220,10 @@ class ApeOracle:
             x = self.vit_attention_eva02(x, i, self.rope_glb)
         x = shortcut + x
         h = self.ln(x, pre + "norm2", 1e-6)
+        if self.cfg.get("subln"):            # SwiGLU with ffn_ln (vit_eva02.py:183-204)
+            hidden = F.silu(self.lin(h, pre + "mlp.w1")) * self.lin(h, pre + "mlp.w2")
+            hidden = self.ln(hidden, pre + "mlp.ffn_ln", 1e-6)
+            return x + self.lin(hidden, pre + "mlp.w3")
         w12, b12 = self.p(pre + "mlp.w12.weight"), self.p(pre + "mlp.w12.bias")
         hid = w12.shape[0] // 2
         hidden = F.silu(F.linear(h, w12[:hid], b12[:hid])) * F.linear(h, w12[hid:], b12[hid:])
@@ -443,8 +454,9 @@ class ApeOracle:
         x, l = feat, query_l
         for i in range(self.enc_layers):
             t0 = time.perf_counter()
-            x, l = self.vl_fusion(x, l, i)
-            S[f"enc{i}_fused_v"], S[f"enc{i}_fused_l"] = x, l
+            if self.vl:                     # deformable_transformer_vl.py:84-91; the plain encoder (deformable_transformer.py:78) has no fusion
+                x, l = self.vl_fusion(x, l, i)
+                S[f"enc{i}_fused_v"], S[f"enc{i}_fused_l"] = x, l
             pre = f"transformer.encoder.layers.{i}."
             x = self.msda(pre + "attentions.0.", x, x, x, lvl_pos, mask, ref, spatial_shapes)
             x = self.ln(x, pre + "norms.0")
@@ -460,13 +472,16 @@ class ApeOracle:
         nd = self.dec_layers
         cls = self.lin(om, f"transformer.decoder.class_embed.{nd}")
         box = self.mlp(om, f"transformer.decoder.bbox_embed.{nd}") + props
-        cls_a = self.lin(om, "transformer.decoder.class_embed_ambiguous.0")
-        box_a = self.mlp(om, "transformer.decoder.bbox_embed_ambiguous.0") + props
-        cls2 = torch.stack([cls, cls_a], dim=1)
-        box2 = torch.stack([box, box_a], dim=1)
-        idx = torch.argmax(cls2, dim=1, keepdim=True)
-        enc_class = torch.gather(cls2, 1, idx).squeeze(1)
-        enc_coord = torch.gather(box2, 1, idx.repeat(1, 1, 1, 4)).squeeze(1)
+        if (self.prefix + "transformer.decoder.class_embed_ambiguous.0.weight") in self.sd:    # proposal_ambiguous = 1 (:508-533)
+            cls_a = self.lin(om, "transformer.decoder.class_embed_ambiguous.0")
+            box_a = self.mlp(om, "transformer.decoder.bbox_embed_ambiguous.0") + props
+            cls2 = torch.stack([cls, cls_a], dim=1)
+            box2 = torch.stack([box, box_a], dim=1)
+            idx = torch.argmax(cls2, dim=1, keepdim=True)
+            enc_class = torch.gather(cls2, 1, idx).squeeze(1)
+            enc_coord = torch.gather(box2, 1, idx.repeat(1, 1, 1, 4)).squeeze(1)
+        else:                                                                                  # proposal_ambiguous = 0 (APE-L_A/B/C)
+            enc_class, enc_coord = cls, box
         S["output_memory"], S["enc_class"], S["enc_coord_unact"] = om, enc_class, enc_coord
 
         logit = enc_class[..., 0]
@@ -642,7 +657,9 @@ class ApeOracle:
         height = height or h
         width = width or w
         features_l = text_feats.float()[None]                       # [1,K,1024]  (:279-280)
-        if prompt == "name" and name_fusion_text:
+        if not self.vl:
+            fusion = None                                                # deformable_detr_segm.py: no fusion tokens at all
+        elif prompt == "name" and name_fusion_text:
             fusion = features_l                                          # (:343-347) name_prompt_fusion_text[dataset_id]
         elif prompt == "name":
             fusion = self.p("name_prompt_fusion_feature").repeat(1, 1, 1)  # zeros [1,1,1024] (:349-352)
@@ -659,7 +676,8 @@ class ApeOracle:
         fpn = self.fpn(feat)
         for k_, v_ in fpn.items():
             S[k_] = v_
-        ml_feats = self.neck(fpn)
+        # neck = None (APE-L_A/B/C, ape_deta_vitl_eva02_lsj1024_cp_12ep.py:21): the pyramid maps feed the transformer directly
+        ml_feats = self.neck(fpn) if (self.prefix + "neck.convs.0.conv.weight") in self.sd else [fpn[k_] for k_ in ("p2", "p3", "p4", "p5", "p6")]
         masks, pos = [], []
         for f in ml_feats:
             masks.append(F.interpolate(img_mask[None], size=f.shape[-2:]).to(torch.bool).squeeze(0))
@@ -669,7 +687,9 @@ class ApeOracle:
         S["inter_states"], S["inter_references"], S["init_reference"] = inter, inter_ref, init_ref
         mask_feat = self.mask_features(memory, fpn["p2"], spatial_shapes)
         S["mask_features"] = mask_feat
-        if prompt == "name":
+        if not self.vl:
+            pass                                                     # the classifier sees the raw text bank
+        elif prompt == "name":
             features_l = 1.0 * features_l + 0.0 * l_out              # (:446)
         else:
             features_l = 0.0 * features_l + 1.0 * l_out              # (:448)

@@ -23,6 +23,14 @@ CONFIGS = {
     # EVA-02 MIM ViT-Ti of vit_eva02.py, 14 x 14 windows on the 64 x 64 grid (zero-padded to 70 x 70), packed SwiGLU
     "Ti": dict(img_size=1024, embed_dim=192, depth=12, num_heads=3, window_size=14, pretrain_img_size=224,
                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02"),
+    # APE-L_A / L_B / L_C (scripts/eval_APE-L_A.sh): the EVA-02 MIM ViT-L of vit_eva02.py in its sub-LN / naive-SwiGLU configuration
+    # (configs/common/backbone/vitl_eva02.py:10-41: 16 x 16 windows, every sixth block global), NO neck (the pyramid maps feed the
+    # transformer directly), the plain DeformableDETRSegm / DeformableDetrTransformer (no vision-language fusion, no ambiguous heads:
+    # configs/COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py:24-137 + ape_deta_vitl_eva02_lsj1024_cp_12ep.py:19-33), top-300
+    "L_A": dict(img_size=1024, embed_dim=1024, depth=24, num_heads=16, window_size=16, pretrain_img_size=224,
+                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02", subln=True, global_every=6, vl=False),
+    "small_A": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224,
+                    enc_layers=2, dec_layers=2, num_queries=300, topk_eval=50, backbone="eva02", subln=True, global_every=3, vl=False),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500, spec="L_D"),
 }

@@ -28,6 +28,36 @@ class _TextStub(nn.Module):
         return {"last_hidden_state_eot": self.feats[: len(text_list)].clone()}
 
 
+def _build_plain(c, A, backbone, feats, text_feats, semantic_on, panoptic_on, panoptic_configs):
+    """APE-L_A/B/C: DeformableDETRSegm on the plain DeformableDetrTransformer, neck = None, constructor arguments of
+    configs/COCO_InstanceSegmentation/ape_deta/models/ape_deta_r50.py:24-137 as overridden by ape_deta_vitl_eva02_lsj1024_cp_12ep.py:19-33
+    and LVISCOCOCOCOSTUFF_O365_OID_VG/ape_deta/ape_deta_vitl_eva02_lsj1024_cp_720k.py:18-42"""
+    encoder = A.DeformableDetrTransformerEncoder(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0, ffn_dropout=0.0,
+                                                 num_layers=c.enc_layers, post_norm=False, num_feature_levels=5, pytorch_attn=True)
+    decoder = A.DeformableDetrTransformerDecoder(embed_dim=256, num_heads=8, feedforward_dim=2048, attn_dropout=0.0, ffn_dropout=0.0,
+                                                 num_layers=c.dec_layers, return_intermediate=True, num_feature_levels=5, pytorch_attn=True)
+    transformer = A.DeformableDetrTransformer(encoder=encoder, decoder=decoder, as_two_stage=True, num_feature_levels=5,
+                                              two_stage_num_proposals=c.num_queries, assign_first_stage=True)
+    criterion = [nn.Module() for _ in range(1)]
+    for cr in criterion:
+        cr.loss_class_type = "focal_loss"
+        cr.num_classes = 256
+    model_vision = A.DeformableDETRSegm(
+        backbone=backbone, position_embedding=refshim.PositionEmbeddingSine(num_pos_feats=128, temperature=10000,
+                                                                          normalize=True, offset=-0.5),
+        neck=None, transformer=transformer, embed_dim=256, num_classes=1256, num_queries=c.num_queries, aux_loss=True,
+        with_box_refine=True, as_two_stage=True, criterion=criterion, pixel_mean=[123.675, 116.280, 103.530],
+        pixel_std=[58.395, 57.120, 57.375], select_box_nums_for_evaluation=c.topk_eval, input_format="RGB",
+        mask_encode_level=0, mask_in_features=["p2"], input_shapes={f: refshim.ShapeSpec(channels=256) for f in feats},
+        output_dir=None, vis_period=0, embed_dim_language=1024, instance_on=True, semantic_on=semantic_on, panoptic_on=panoptic_on,
+        dataset_prompts=["name"], dataset_names=["coco"], dataset_metas=["coco_2017_val"],
+        **({"panoptic_configs": panoptic_configs} if panoptic_configs is not None else {}),
+    )
+    model = A.SomeThing(model_vision=model_vision, model_language=_TextStub(text_feats))
+    model.eval()
+    return model
+
+
 def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panoptic_configs=None):
     refshim.install()
     import ape.layers as L
@@ -35,13 +65,15 @@ def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panop
     from ape.modeling.backbone.vit_eva_clip import SimpleFeaturePyramid, ViT
 
     c = SimpleNamespace(**cfg)
-    if cfg.get("backbone") == "eva02":          # APE-Ti: configs/common/backbone/vitt_eva02.py:10-41
+    if cfg.get("backbone") == "eva02":          # APE-Ti: configs/common/backbone/vitt_eva02.py:10-41; APE-L_A/B/C: vitl_eva02.py:10-41
         from ape.modeling.backbone.vit_eva02 import SimpleFeaturePyramid, ViT
+        ge = cfg.get("global_every", 3)
+        subln = bool(cfg.get("subln", False))
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
                   drop_path_rate=0.0, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,
-                  norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=window_block_indexes(c.depth),
+                  norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1],
                   residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
-                  subln=False, swiglu=True, naiveswiglu=False)
+                  subln=subln, swiglu=not subln, naiveswiglu=subln)
     else:
         net = ViT(
             img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
@@ -54,6 +86,8 @@ def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panop
     backbone = SimpleFeaturePyramid(net=net, in_feature="last_feat", out_channels=256, scale_factors=(4.0, 2.0, 1.0, 0.5),
                                     top_block=refshim.LastLevelMaxPool(), norm="LN", square_pad=c.img_size)
     feats = ["p2", "p3", "p4", "p5", "p6"]
+    if not cfg.get("vl", True):
+        return _build_plain(c, A, backbone, feats, text_feats, semantic_on, panoptic_on, panoptic_configs)
     neck = refshim.ChannelMapper(input_shapes={f: refshim.ShapeSpec(channels=256) for f in feats}, in_features=feats,
                                  out_channels=256, num_outs=5, kernel_size=1, norm_layer=nn.GroupNorm(32, 256))
     vl_layer = L.VisionLanguageFusion(v_dim=256, l_dim=1024, embed_dim=2048, num_heads=8, dropout=0.1, drop_path=0.0,

@@ -530,8 +530,11 @@ def install():
     load("ape.modeling.ape_deta.fast_rcnn", "ape/modeling/ape_deta/fast_rcnn.py")
     load("ape.modeling.ape_deta.deformable_detr", "ape/modeling/ape_deta/deformable_detr.py")
     load("ape.modeling.ape_deta.deformable_detr_segm_vl", "ape/modeling/ape_deta/deformable_detr_segm_vl.py")
+    # the plain (non-VL) family of APE-L_A/B/C: scripts/eval_APE-L_A.sh
+    load("ape.modeling.ape_deta.deformable_transformer", "ape/modeling/ape_deta/deformable_transformer.py")
+    load("ape.modeling.ape_deta.deformable_detr_segm", "ape/modeling/ape_deta/deformable_detr_segm.py")
     load("ape.modeling.ape_deta.ape_deta", "ape/modeling/ape_deta/ape_deta.py")
-    for sub in ("deformable_transformer_vl", "deformable_detr", "deformable_detr_segm_vl", "ape_deta"):
+    for sub in ("deformable_transformer_vl", "deformable_transformer", "deformable_detr", "deformable_detr_segm_vl", "deformable_detr_segm", "ape_deta"):
         mod = sys.modules[f"ape.modeling.ape_deta.{sub}"]
         for name in dir(mod):
             obj = getattr(mod, name)

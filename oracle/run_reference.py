@@ -70,13 +70,15 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
     hook(net, "last_feat", lambda o: o["last_feat"])
     hooks.append(mv.backbone.register_forward_hook(lambda m, i, o: S.update({k: v for k, v in o.items()})))
     enc = mv.transformer.encoder
+    vl = cfg.get("vl", True)          # False: APE-L_A/B/C, the plain DeformableDETRSegm / DeformableDetrTransformer (no fusion layers)
     for i in range(len(enc.layers)):
-        hooks.append(enc.vl_layers[i].register_forward_hook(
-            lambda m, inp, o, i=i: S.update({f"enc{i}_fused_v": o[0], f"enc{i}_fused_l": o[1]})))
+        if vl:
+            hooks.append(enc.vl_layers[i].register_forward_hook(
+                lambda m, inp, o, i=i: S.update({f"enc{i}_fused_v": o[0], f"enc{i}_fused_l": o[1]})))
         hook(enc.layers[i], f"enc{i}_out")
     hooks.append(mv.transformer.register_forward_hook(lambda m, i, o: S.update({
         "inter_states": o[0], "init_reference": o[1], "inter_references": o[2], "enc_class": o[3],
-        "enc_coord_unact": o[4], "anchors": o[5], "memory": o[6], "query_l": o[7]})))
+        "enc_coord_unact": o[4], "anchors": o[5], "memory": o[6], **({"query_l": o[7]} if len(o) > 7 else {})})))
     hooks.append(mv.transformer.register_forward_pre_hook(lambda m, a: S.__setitem__("transformer_inputs", a)))
     hooks.append(mv.transformer.decoder.register_forward_pre_hook(
         lambda m, a, kw: S.update({"query_init": kw["query"], "query_pos": kw["query_pos"]}), with_kwargs=True))
@@ -84,8 +86,8 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
     hook(mv.mask_embed, "mask_embed")
     hook(mv.class_embed[len(mv.transformer.decoder.layers) - 1], "pred_logits_full")   # all K columns (the detector may see fewer)
 
-    tmod = sys.modules["ape.modeling.ape_deta.deformable_transformer_vl"]
-    smod = sys.modules["ape.modeling.ape_deta.deformable_detr_segm_vl"]
+    tmod = sys.modules["ape.modeling.ape_deta.deformable_transformer_vl" if vl else "ape.modeling.ape_deta.deformable_transformer"]
+    smod = sys.modules["ape.modeling.ape_deta.deformable_detr_segm_vl" if vl else "ape.modeling.ape_deta.deformable_detr_segm"]
     old_torch = tmod.torch
     tmod.torch = _TorchProxy(S, stable_ties)
     old_mf = mv.maskdino_mask_features

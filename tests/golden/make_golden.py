@@ -42,6 +42,9 @@ CASES = {
     # config 3 flavour: phrase prompt at full size -- 24 phrase tokens + 232 zero bank slots = L = 256 language tokens
     # fused DENSELY with the 87 296 vision tokens in every encoder layer; the fused tokens are the vocabulary (256 columns)
     "L_D_phrase256": ("L_D_coco", 0, 2, (1024, 1024), 24, 9, "phrase"),
+    # f4: APE-L_A -- the plain (non-VL) model family of scripts/eval_APE-L_A.sh at full size, and a small copy of it
+    "L_A_coco80": ("L_A", 0, 2, (1024, 1024), 80, 3),
+    "small_A": ("small_A", 1, 4, (416, 512), 9, 5),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }
@@ -93,7 +96,7 @@ def main():
             with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
                 json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
-        big = cfg.startswith("L_D") or cfg == "Ti"
+        big = cfg.startswith("L_D") or cfg in ("Ti", "L_A")
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)

@@ -68,7 +68,8 @@ def head_biases(model):
     mv = model.model_vision
     dec = mv.transformer.decoder
     nd = dec.num_layers
-    b_enc = 0.5 * (float(dec.class_embed[nd].bias.detach().float().mean()) + float(dec.class_embed_ambiguous[0].bias.detach().float().mean()))
+    amb = dec.class_embed_ambiguous[0] if hasattr(dec, "class_embed_ambiguous") else dec.class_embed[nd]     # plain family: one head
+    b_enc = 0.5 * (float(dec.class_embed[nd].bias.detach().float().mean()) + float(amb.bias.detach().float().mean()))
     return {"enc_class": b_enc, "enc_cls2": b_enc, "pred_logits": float(mv.class_embed[nd - 1].bias0.detach().float().mean())}
 
 
@@ -98,7 +99,8 @@ def linear_head_scales(model, teacher):
         return {}
     dec = model.model_vision.transformer.decoder
     nd = dec.num_layers
-    W = torch.cat([dec.class_embed[nd].weight.detach().float(), dec.class_embed_ambiguous[0].weight.detach().float()], 0)   # [2, 256]
+    amb = dec.class_embed_ambiguous[0] if hasattr(dec, "class_embed_ambiguous") else dec.class_embed[nd]
+    W = torch.cat([dec.class_embed[nd].weight.detach().float(), amb.weight.detach().float()], 0)                           # [2, 256]
     x = teacher["output_memory"].detach().float()
     tn = ((x * x) @ (W * W).t().to(x.device)).sqrt()                                                                       # [T, 2]
     s = float(tn.pow(2).mean().sqrt())

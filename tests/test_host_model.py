@@ -291,3 +291,40 @@ def test_fp16_model_runs_through_the_module_edge(fake_ops):
     out = msda(q, value=q, identity=q, query_pos=torch.zeros_like(q), reference_points=torch.rand(1, 86, 5, 2),
                spatial_shapes=shapes, level_start_index=torch.tensor([0, 64, 80, 84, 85]))
     assert out.dtype == torch.float16 and out.shape == q.shape and torch.isfinite(out).all()
+
+
+def test_plain_family_state_dict_contract_and_host_pipeline(fake_ops):
+    """APE-L_A/B/C = the reference's plain family (DeformableDETRSegm on DeformableDetrTransformer: no fusion layers,
+    neck = None, no ambiguous heads, vit_eva02 backbone with sub-LN).  State-dict names / shapes of the full-size model == the
+    reference model's own state_dict(); the host composition at reduced size vs the oracle and the reference-generated fixture."""
+    import json
+    import os
+    from ape_amd.modeling.build import build_ape
+
+    with torch.device("meta"):
+        model = build_ape("L_A")
+    own = {k: list(v.shape) for k, v in model.state_dict().items() if not k.endswith(("freqs_cos", "freqs_sin"))}
+    spec = {k: list(v) for k, v in U.load_spec("L_A") if not k.endswith(("freqs_cos", "freqs_sin"))}
+    assert own == spec and not any("vl_layers" in k or "neck" in k or "ambiguous" in k or "fusion" in k for k in own)
+    model, orc, image, text, gold = M.build_pair("small_A")
+    mv = model.model_vision
+    assert type(mv).__name__ == "DeformableDETRSegm" and type(mv.transformer).__name__ == "DeformableDetrTransformer"
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    for k in ("p2", "p4", "p6", "enc_input", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact"):
+        b = M.token_major(k, orc.stages[k])
+        assert U.relerr(stages[k].reshape(b.shape), b) < 2e-4, k
+    assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance, vs the reference run
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+    # the reference-signature forward of the plain transformer returns 7 values (deformable_transformer.py:644)
+    res = model([{"image": image, "height": image.shape[1], "width": image.shape[2], "text_features": text}])[0]["instances"]
+    gi = gold["instances"]
+    assert U.match_detections(res.pred_boxes, res.scores, res.pred_classes, gi["pred_boxes"], gi["scores"], gi["pred_classes"]) >= 0.97

@@ -13,7 +13,9 @@ from oracle.configs import CONFIGS
 FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order)
 
 
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase"])
+# small_A: the plain (non-VL) family of APE-L_A/B/C -- DeformableDETRSegm on DeformableDetrTransformer, no neck, no fusion, no
+# ambiguous heads, the EVA-02 MIM ViT with sub-LN (fixture produced by the reference's deformable_detr_segm.py / deformable_transformer.py)
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)

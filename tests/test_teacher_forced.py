@@ -51,7 +51,7 @@ def test_stage_tap_teacher_forcing_on_the_host_model(fake_ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_1536_sseg"])
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_1536_sseg", "L_A_coco80"])
 def test_L_D_bf16_teacher_forced(case):
     """every stage of the bf16 HIP pipeline, fed the fp32 pipeline's input, is inside the tolerance derived from bf16's 8
     significant bits and the number of roundings on its path (teacher_forced.ROUNDINGS) -- at the benchmarked sizes"""
@@ -74,7 +74,7 @@ def test_L_D_bf16_teacher_forced(case):
     import oracle_util as U
     assert U.relerr(logits, gold["full"]["pred_logits"][0]) < 1e-3
     assert U.relerr(t["pred_boxes"].float().cpu(), gold["full"]["pred_boxes"][0]) < 1e-3
-    assert len(ferr) >= 60
+    assert len(ferr) >= 55
     bad = TF.violations(ferr)
     assert not bad, bad
     if sem is not None:
