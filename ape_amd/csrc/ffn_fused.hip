@@ -184,31 +184,27 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
     // ---- H^T = W1c . x^T (4 hidden tiles x 2 token tiles x 8 k steps), then Y^T += W2c . H^T (k step kk = hidden tiles 2kk, 2kk + 1,
     //      permuted inside the step; 16 channel tiles in two groups of 8)
-    // three register sets, reads TWO groups ahead of the MFMAs (one group ahead left ~200 exposed cycles at every batch boundary);
-    // the bias / ReLU / pack VALU of hidden tile ht - 1 is interleaved with the MFMAs of tile ht (two VALU per MFMA slot) instead
-    // of standing between two batches with the matrix pipe idle
-#define FF_MIX()                                          \
-  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);    \
+    // three register sets, reads TWO groups ahead of the MFMAs, and ALL of a group's companions -- the 8 ds_read_b128 of the group
+    // after next, the bias / ReLU / pack VALU of the previous hidden tile -- issued INSIDE the MFMA stream (per two MFMAs: one LDS
+    // read, a few VALU): a wave alone on its SIMD has no other wave to fill the matrix pipe while it issues reads (measured with the
+    // reads between the batches: 5.8 k cycles per chunk for 2.2 k of MFMA issue)
+#define FF_MIX(NREAD)                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    if (i_ < (NREAD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
+    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    \
   }
     // the chunk's four bias quads first: read behind the fragments they would turn every counted lgkmcnt wait into a full drain
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) bch[ht] = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
     FF_SB();
     rd1(0, fa); rd1(1, fb); FF_SB();
-    rd1(2, fc); FF_SB();
-    mm1(0, fa); FF_SB();
-    rd1(3, fa); FF_SB();
-    act(0); mm1(1, fb); FF_MIX(); FF_SB();
-    rd2(0, 0, fb); FF_SB();
-    act(1); pack(0); mm1(2, fc); FF_MIX(); FF_SB();
-    rd2(0, 1, fc); FF_SB();
-    act(2); mm1(3, fa); FF_MIX(); FF_SB();
-    rd2(1, 0, fa); FF_SB();
-    act(3); pack(1); mm2(0, 0, fb); FF_MIX(); FF_SB();
-    rd2(1, 1, fb); FF_SB();
-    mm2(0, 1, fc); FF_SB();
+    rd1(2, fc); mm1(0, fa); FF_MIX(8); FF_SB();
+    rd1(3, fa); act(0); mm1(1, fb); FF_MIX(8); FF_SB();
+    rd2(0, 0, fb); act(1); pack(0); mm1(2, fc); FF_MIX(8); FF_SB();
+    rd2(0, 1, fc); act(2); mm1(3, fa); FF_MIX(8); FF_SB();
+    rd2(1, 0, fa); act(3); pack(1); mm2(0, 0, fb); FF_MIX(8); FF_SB();
+    rd2(1, 1, fb); mm2(0, 1, fc); FF_MIX(8); FF_SB();
     mm2(1, 0, fa); FF_SB();
     mm2(1, 1, fb); FF_SB();
 #undef FF_MIX

@@ -252,34 +252,8 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
 }
 
 // store NV values (NV % 4 == 0) starting at column ocol of row m; 16-byte pieces when the address allows
-// EXPERIMENT (APE_GEMM_STORE=sc1 | nt, vec_ok bits 64 / 128): write-through / non-temporal 16-byte stores for the output tile.
-// A kernel that ends with tens of MB dirty in the L2s pays their write-back at the kernel boundary (MI355X_MICROARCH.md: + B / 6 TB/s);
-// write-through stores stream the bytes out while later tiles still compute.
-typedef unsigned int epi_u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store16(void* dst, const uint4 v4, int flavour) {
-  const epi_u32x4_t v = {v4.x, v4.y, v4.z, v4.w};
-  if (flavour & 64) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-  else if (flavour & 128) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(v) : "memory");
-  else *reinterpret_cast<uint4*>(dst) = v4;
-}
-
 template <int NV>
 __device__ __forceinline__ void store_row(const GemmParams& p, int m, int ocol, const float* o) {
-  if (p.vec_ok & (64 | 128)) {
-    if (p.out_dt == APE_DT_F32) {
-      float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + ocol;
-#pragma unroll
-      for (int e = 0; e < NV / 4; ++e)
-        store16(dst + e * 4, make_uint4(__float_as_uint(o[e * 4]), __float_as_uint(o[e * 4 + 1]), __float_as_uint(o[e * 4 + 2]), __float_as_uint(o[e * 4 + 3])), p.vec_ok);
-      return;
-    } else if (NV % 8 == 0) {
-      bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ocol;
-#pragma unroll
-      for (int e = 0; e < NV / 8; ++e)
-        store16(dst + e * 8, make_uint4(pack2bf(o[e * 8], o[e * 8 + 1]), pack2bf(o[e * 8 + 2], o[e * 8 + 3]), pack2bf(o[e * 8 + 4], o[e * 8 + 5]), pack2bf(o[e * 8 + 6], o[e * 8 + 7])), p.vec_ok);
-      return;
-    }
-  }
   if (p.out_dt == APE_DT_F32) {
     float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + ocol;
 #pragma unroll

@@ -308,11 +308,6 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
     attr_done = true;
   }
-  {
-    const char* st = getenv("APE_GEMM_STORE");                  // experiment: output store flavour (read per call so a probe can flip it)
-    if (st != nullptr && st[0] == 's') p.vec_ok |= 64;
-    else if (st != nullptr && st[0] == 'n') p.vec_ok |= 128;
-  }
   const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
   if (bn == 256) {
     if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true>), dim3(tiles), dim3(512), 131072, s, p); return "gemm_bf16_p8_kernel<256, true>"; }
