@@ -42,7 +42,18 @@ struct FfnParams {
   const bf16_t* R; int ldr;      // residual (may be NULL)
   bf16_t* Y; int ldy;
   int M, HID;
+  const float* ln_w; const float* ln_b; float ln_eps;    // optional LayerNorm over the 256 output channels (NULL: none)
 };
+
+// sum over the 4 lanes l, l^16, l^32, l^48 (the lanes that hold the four 64-channel quarters of one token's output row)
+__device__ __forceinline__ float ff_rows_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 // W2P: W2's hidden columns arrive PRE-PERMUTED inside every group of 32 (position 8g + e holds hidden 4g + e for e < 4 and
 // 16 + 4g + e - 4 for e >= 4 -- the k order of the second MFMA's B operand above; ape_amd.packing.permute_ffn_w2): the W2 fragment
@@ -213,32 +224,60 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns channels g*64 .. g*64 + 63 of tokens tok[0], tok[1]; 16-byte pieces (ot pair 2q, 2q+1 = 8 channels)
+  // ---- epilogue: lane owns channels g*64 .. g*64 + 63 of tokens tok[0], tok[1]; 16-byte pieces (ot pair 2q, 2q+1 = 8 channels).
+  // Optional LayerNorm of the finished row (the post-FFN norm of the transformer layer, detrex BaseTransformerLayer "ffn", "norm"):
+  // a token's 256 channels sit in the 4 lanes fm + 16 g, so the statistics are two lane swaps; computed on the fp32 sums (two-pass
+  // variance), i.e. without the bf16 rounding a separate LayerNorm launch would read -- and without its 89 MB round trip.
+  // Every lane runs the arithmetic (clamped row for the residual of rows past M: cross-lane swaps need all lanes); only the store
+  // is predicated.
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt) {
-    if (tok[rt] >= p.M) continue;
-    bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 64;
-    const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tok[rt] * p.ldr + g * 64 : nullptr;
+    const int tk = tok[rt] < p.M ? tok[rt] : p.M - 1;
+    const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tk * p.ldr + g * 64 : nullptr;
+    float v[64];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float4 ba = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8);
       const float4 bb = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8 + 4);
-      float v[8] = {yacc[2 * q][rt][0] + ba.x, yacc[2 * q][rt][1] + ba.y, yacc[2 * q][rt][2] + ba.z, yacc[2 * q][rt][3] + ba.w,
-                    yacc[2 * q + 1][rt][0] + bb.x, yacc[2 * q + 1][rt][1] + bb.y, yacc[2 * q + 1][rt][2] + bb.z, yacc[2 * q + 1][rt][3] + bb.w};
+      v[q * 8 + 0] = yacc[2 * q][rt][0] + ba.x; v[q * 8 + 1] = yacc[2 * q][rt][1] + ba.y;
+      v[q * 8 + 2] = yacc[2 * q][rt][2] + ba.z; v[q * 8 + 3] = yacc[2 * q][rt][3] + ba.w;
+      v[q * 8 + 4] = yacc[2 * q + 1][rt][0] + bb.x; v[q * 8 + 5] = yacc[2 * q + 1][rt][1] + bb.y;
+      v[q * 8 + 6] = yacc[2 * q + 1][rt][2] + bb.z; v[q * 8 + 7] = yacc[2 * q + 1][rt][3] + bb.w;
       if (rp != nullptr) {
         float r[8];
         ld8<bf16_t>(rp + q * 8, r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
+        for (int e = 0; e < 8; ++e) v[q * 8 + e] += r[e];
       }
-      st8<bf16_t>(yp + q * 8, v);
+    }
+    if (p.ln_w != nullptr) {
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 64; ++e) sum += v[e];
+      const float mean = ff_rows_sum(sum) * (1.f / FF_N);
+      float d2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 64; ++e) { v[e] -= mean; d2 = fmaf(v[e], v[e], d2); }
+      const float rstd = rsqrtf(ff_rows_sum(d2) * (1.f / FF_N) + p.ln_eps);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 w = *reinterpret_cast<const float4*>(p.ln_w + g * 64 + q * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.ln_b + g * 64 + q * 4);
+        v[q * 4 + 0] = fmaf(v[q * 4 + 0] * rstd, w.x, b.x); v[q * 4 + 1] = fmaf(v[q * 4 + 1] * rstd, w.y, b.y);
+        v[q * 4 + 2] = fmaf(v[q * 4 + 2] * rstd, w.z, b.z); v[q * 4 + 3] = fmaf(v[q * 4 + 3] * rstd, w.w, b.w);
+      }
+    }
+    if (tok[rt] < p.M) {
+      bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 64;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) st8<bf16_t>(yp + q * 8, v + q * 8);
     }
   }
 }
 
 extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
                                  const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted,
-                                 void* stream) {
+                                 const float* ln_weight, const float* ln_bias, float ln_eps, void* stream) {
   APE_CHECK_ARG(X && W1 && b1 && W2 && b2 && Y && M > 0, "ape_hip_ffn_fused: null pointer / empty problem");
   APE_CHECK_ARG(K == FF_K && N == FF_N && HID % FF_HC == 0 && HID >= FF_HC && HID <= 4096,
                 "ape_hip_ffn_fused: the kernel is built for 256 -> HID -> 256 with HID %% 64 == 0, HID <= 4096 (got %d -> %d -> %d)", K, HID, N);
@@ -251,6 +290,9 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
   FfnParams p;
   p.X = (const bf16_t*)X; p.ldx = ldx; p.W1 = (const bf16_t*)W1; p.ldw1 = ldw1; p.b1 = b1; p.W2 = (const bf16_t*)W2; p.ldw2 = ldw2; p.b2 = b2;
   p.R = (const bf16_t*)residual; p.ldr = ldr; p.Y = (bf16_t*)Y; p.ldy = ldy; p.M = M; p.HID = HID;
+  APE_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr) && ((uintptr_t)ln_weight) % 16 == 0 && ((uintptr_t)ln_bias) % 16 == 0,
+                "ape_hip_ffn_fused: LayerNorm weight and bias come together, 16-byte aligned");
+  p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = ln_eps;
   const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {

@@ -532,6 +532,22 @@ __global__ __launch_bounds__(TK_THREADS) void det_topk1_kernel(const float* __re
   ws[(size_t)blockIdx.x * 1024 + threadIdx.x] = comp[threadIdx.x];
 }
 
+// intermediate stage for selections whose (lists x k) exceeds stage 2's LDS (e.g. LVIS-1203 x 900 pairs with test_topk_per_image > 722):
+// workgroup b merges lists b * group .. of `in` (k sorted composites each, stride 1024) into list b of `out`.  The union-of-top-k
+// argument of the two-stage scheme holds at every level, and composites carry (key, ~index), so ties still resolve to the lowest index.
+__global__ __launch_bounds__(TK_THREADS) void topk_merge_kernel(const u64* __restrict__ in, int nlists, int group, int k, u64* __restrict__ out) {
+  extern __shared__ u64 lds[];
+  __shared__ u64 comp[1024];
+  __shared__ uint32_t hist[256], sh[2], wcnt[32];
+  const int first = blockIdx.x * group;
+  const int cnt = min(group, nlists - first);
+  stage2_gather(in, first, cnt, k, lds);
+  auto key = [&](int i) { return (uint32_t)(lds[i] >> 32); };
+  auto composite = [&](int i) { return lds[i]; };
+  block_topk(key, composite, cnt * k, k, comp, hist, sh, wcnt);
+  out[(size_t)blockIdx.x * 1024 + threadIdx.x] = comp[threadIdx.x];
+}
+
 __global__ __launch_bounds__(TK_THREADS) void det_topk2_kernel(const u64* __restrict__ ws, int nchunks, const int32_t* __restrict__ order,
                                                                const float* __restrict__ xyxy, int Q, int k, float* __restrict__ det_boxes,
                                                                float* __restrict__ det_scores, long long* __restrict__ det_classes,
@@ -591,6 +607,7 @@ static void set_stage2_attr() {
   if (!done) {
     (void)hipFuncSetAttribute((const void*)proposal_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     (void)hipFuncSetAttribute((const void*)det_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+    (void)hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     done = true;
   }
 }
@@ -598,8 +615,10 @@ static void set_stage2_attr() {
 // uint64 words of workspace the two-stage selections need: 1024 per stage-1 workgroup
 extern "C" int ape_hip_topk_workspace_words(int n_total) {
   // proposals: <= TK_MAX_JOBS workgroups; detections: one per 8 k pairs at most
+  // + half as many again for the lists of an intermediate merge level (det_topk with lists x k beyond stage 2's LDS)
   const int det = ceil_div(n_total > 0 ? n_total : 1, 8 * TK_THREADS);
-  return 1024 * (det > TK_MAX_JOBS ? det : TK_MAX_JOBS);
+  const int lists = det > TK_MAX_JOBS ? det : TK_MAX_JOBS;
+  return 1024 * (lists + lists / 2 + 1);
 }
 
 extern "C" int ape_hip_proposal_topk(const float* logit, int T, const int* level_start, const int* level_n, int L, int k, int k_alt,
@@ -687,15 +706,30 @@ extern "C" int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const 
   APE_CHECK_ARG(sorted && keep && order && xyxy && workspace && det_boxes && det_scores && det_classes && det_query, "ape_hip_det_topk: null pointer");
   APE_CHECK_ARG(K > 0 && Q > 0 && (long long)K * Q < 0x7fffffffLL && k >= 1 && k <= 1024 && k <= K * Q, "ape_hip_det_topk: 1 <= k <= min(1024, K*Q)");
   const int total = K * Q;
-  const int per = topk_per(&total, &k, 1);
-  APE_CHECK_ARG(per > 0, "ape_hip_det_topk: %d (class, query) pairs with k = %d do not fit the two-stage selection", total, k);
-  const int nchunks = ceil_div(total, per * TK_THREADS);
+  int per = topk_per(&total, &k, 1);
+  const bool merge = per == 0;           // (lists x k) beyond stage 2's LDS at every chunk size: 64 k-element chunks + merge levels
+  if (merge) per = 64;
+  int nchunks = ceil_div(total, per * TK_THREADS);
   hipStream_t st = (hipStream_t)stream;
   u64* ws = reinterpret_cast<u64*>(workspace);
   if (per == 8) hipLaunchKernelGGL(det_topk1_kernel<8>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
   else if (per == 32) hipLaunchKernelGGL(det_topk1_kernel<32>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
   else hipLaunchKernelGGL(det_topk1_kernel<64>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
   set_stage2_attr();
+  if (merge) {
+    // ping-pong between the chunk lists and the spare half of the workspace until one stage-2 workgroup can hold what is left
+    const int cap_lists = ape_hip_topk_workspace_words(total) / 1024;
+    u64* a = ws;
+    u64* b = ws + (size_t)1024 * (cap_lists - (cap_lists / 3));      // the spare third starts behind the stage-1 lists
+    const int group = TK_STAGE2_MAX / k;                              // >= 12 lists per merge workgroup (k <= 1024)
+    while ((long long)nchunks * k > TK_STAGE2_MAX) {
+      const int nout = ceil_div(nchunks, group);
+      hipLaunchKernelGGL(topk_merge_kernel, dim3(nout), dim3(TK_THREADS), (size_t)group * k * sizeof(u64), st, a, nchunks, group, k, b);
+      u64* t = a; a = b; b = t;
+      nchunks = nout;
+    }
+    ws = a;
+  }
   hipLaunchKernelGGL(det_topk2_kernel, dim3(1), dim3(TK_THREADS), (size_t)nchunks * k * sizeof(u64), st, ws, nchunks, order, xyxy, Q, k,
                      det_boxes, det_scores, (long long*)det_classes, (long long*)det_query);
   APE_CHECK_LAUNCH("det_topk");

@@ -36,17 +36,22 @@ class FFN(nn.Module):
     # variant on the un-permuted W2 (A/B)
     FUSED_MIN_ROWS = 2048
 
-    def forward_tokens(self, x, dt, out_dtype=None):
-        """x + Linear(ReLU(Linear(x)))  (detrex FFN with add_identity)"""
+    def forward_tokens(self, x, dt, out_dtype=None, norm=None):
+        """x + Linear(ReLU(Linear(x)))  (detrex FFN with add_identity); norm = (weight, bias, eps): followed by that LayerNorm (the
+        layer's post-FFN norm) -- in the same launch on the one-kernel path"""
         P = self.packed(dt)
         mode = os.environ.get("APE_FFN_FUSED", "1")
         if (mode != "0" and "w2p" in P and (out_dtype or dt) == torch.bfloat16 and x.shape[0] >= self.FUSED_MIN_ROWS
                 and x.shape[1] == 256 and P["w2"].shape[0] == 256 and P["w1"].shape[0] <= 4096):
+            fuse_ln = norm if os.environ.get("APE_FFN_LN") != "0" else None
             if mode == "b64":
-                return ops.ffn_fused(x, P["w1"], P["b1"], P["w2"], P["b2"], residual=x)
-            return ops.ffn_fused(x, P["w1"], P["b1"], P["w2p"], P["b2"], residual=x, w2_permuted=True)
+                y = ops.ffn_fused(x, P["w1"], P["b1"], P["w2"], P["b2"], residual=x, norm=fuse_ln)
+            else:
+                y = ops.ffn_fused(x, P["w1"], P["b1"], P["w2p"], P["b2"], residual=x, w2_permuted=True, norm=fuse_ln)
+            return y if (norm is None or fuse_ln is not None) else ops.layernorm(y, norm[0], norm[1], norm[2], out_dtype=dt)
         h = ops.gemm(x, P["w1"], P["b1"], act=ops.ACT_RELU)
-        return ops.gemm(h, P["w2"], P["b2"], residual=x, out_dtype=out_dtype or dt)
+        y = ops.gemm(h, P["w2"], P["b2"], residual=x, out_dtype=out_dtype or dt)
+        return y if norm is None else ops.layernorm(y, norm[0], norm[1], norm[2], out_dtype=dt)
 
 
 class MLP(nn.Module):

@@ -54,11 +54,8 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
             x1 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
                                                     mask=geo.mask_u8)
             x2 = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt)
-            x3 = layer.ffns[0].forward_tokens(x2, dt)
-            if self.vl_layers is None and stages is None:
-                x, xp = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt, add=lvl_pos)
-            else:
-                x, xp = ops.layernorm(x3, *layer.norm_params(1), out_dtype=dt), None
+            # FFN + the layer's last norm: one launch on the one-kernel FFN path (csrc/ffn_fused.hip, LayerNorm in its epilogue)
+            x, xp = layer.ffns[0].forward_tokens(x2, dt, norm=layer.norm_params(1)), None
             l = ljob.join()
             if stages is not None:
                 if self.vl_layers is not None:

@@ -911,10 +911,11 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
     return det
 
 
-def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False):
+def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False, norm=None):
     """residual + relu(x w1^T + b1) w2^T + b2 in one kernel (csrc/ffn_fused.hip); x [M, 256] bf16, w1 [HID, 256],
     w2 [256, HID] bf16 (w2_permuted: hidden columns in packing.permute_ffn_w2's order), biases fp32 -> [M, 256] bf16.  The hidden
-    activations never reach HBM."""
+    activations never reach HBM.  norm = (weight [256], bias [256], eps): the result is LayerNorm(residual + ffn(x)) (fp32 statistics of
+    the fp32 sums) -- the transformer layer's post-FFN norm in the same launch."""
     _dev(x, w1, w2, b1, b2, residual, out)
     for t, name in ((x, "x"), (w1, "w1"), (w2, "w2")):
         _rowmajor(t, name)
@@ -930,8 +931,14 @@ def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False):
         _rowmajor(residual, "residual")
         if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, N):
             raise TypeError("ape_amd.ops.ffn_fused: residual must be bfloat16 [M, N]")
+    if norm is not None:
+        _dev(norm[0], norm[1])
+        if norm[0].numel() != N or norm[1].numel() != N:
+            raise ValueError("ape_amd.ops.ffn_fused: norm = (weight [N], bias [N], eps)")
     rc = _lib.load().ape_hip_ffn_fused(_p(x), _ld(x), _p(w1), _ld(w1), _p(_f32vec(b1, "b1")), _p(w2), _ld(w2), _p(_f32vec(b2, "b2")),
                                       _p(residual), _ld(residual) if residual is not None else 0, _p(out), _ld(out), M, K, HID, N,
-                                      1 if w2_permuted else 0, _stream())
+                                      1 if w2_permuted else 0, _p(_f32vec(norm[0], "norm weight")) if norm is not None else None,
+                                      _p(_f32vec(norm[1], "norm bias")) if norm is not None else None,
+                                      float(norm[2]) if norm is not None else 0.0, _stream())
     _lib.check(rc, "ape_hip_ffn_fused")
     return out

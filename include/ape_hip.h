@@ -405,9 +405,12 @@ int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* or
  * two-GEMM form writes and reads back (357 MB per encoder layer at 1024^2) never exists.  residual may be NULL.
  * w2_permuted != 0: W2's hidden columns are stored pre-permuted inside every group of 32 -- position 8 g + e holds hidden
  * 4 g + e (e < 4) / 16 + 4 g + e - 4 (e >= 4), g = 0..3 -- the k order of the second MFMA (ape_amd.packing.permute_ffn_w2).
+ * ln_weight / ln_bias (fp32 [256], both or neither): y = LayerNorm(residual + ffn(x)) over the 256 channels with eps = ln_eps -- the
+ * "norm" that follows the "ffn" in detrex's BaseTransformerLayer -- on the fp32 sums, in the same launch.
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
-                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted, void* stream);
+                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted,
+                      const float* ln_weight, const float* ln_bias, float ln_eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -513,7 +513,7 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
     return dict(det_boxes=xyxy[qidx], det_scores=top_scores, det_classes=cls, det_query=qidx)
 
 
-def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False):
+def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False, norm=None):
     """the two-GEMM form at the kernel's rounding points: H rounded to bf16, fp32 accumulation, one rounding of the output"""
     if w2_permuted:
         from ape_amd.packing import ffn_w2_perm
@@ -524,6 +524,8 @@ def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False):
     y = h.float() @ w2.float().t() + b2.float()
     if residual is not None:
         y = y + residual.float()
+    if norm is not None:                      # LayerNorm of the fp32 sums (the kernel's epilogue), one rounding of the result
+        y = F.layer_norm(y, (y.shape[1],), norm[0].float(), norm[1].float(), norm[2])
     y = y.to(torch.bfloat16)
     if out is not None:
         out.copy_(y)

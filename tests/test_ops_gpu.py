@@ -732,7 +732,10 @@ def test_select_proposals(ops, shapes, k, nq, mode):
     assert torch.equal(got.cpu(), ref.cpu()), f"{(got.cpu() != ref.cpu()).sum().item()} of {nq} proposals differ"
 
 
-@pytest.mark.parametrize("Q,K,topk", [(900, 80, 100), (900, 400, 300), (900, 1, 1), (300, 7, 500), (1024, 3, 100)])
+# (900, 1203, 500): LVIS vocabulary with top-500 -> the 64-elements-per-thread stage-1 instantiation; (900, 1203, 900): (lists x k)
+# beyond stage 2's LDS -> the intermediate merge level (no configuration raises from inside model.forward)
+@pytest.mark.parametrize("Q,K,topk", [(900, 80, 100), (900, 400, 300), (900, 1, 1), (300, 7, 500), (1024, 3, 100), (900, 1203, 500),
+                                      (900, 1203, 900)])
 def test_detections(ops, Q, K, topk):
     g = torch.Generator(device="cpu").manual_seed(5)
     logits = (torch.randint(-600, 200, (Q, K), generator=g).float() / 64).to(DEV)
@@ -778,3 +781,10 @@ def test_ffn_fused(ops, M, HID):
     assert e < TOL[bf] and ep < TOL[bf]
     assert torch.equal(got, gotp)                      # the same MFMAs on the same operands
     assert relerr(ops.ffn_fused(x, w1, b1, w2, b2), ref_ops.ffn_fused(x, w1, b1, w2, b2)) < TOL[bf]
+    # LayerNorm of the finished row in the epilogue (the transformer layer's post-FFN norm), incl. the rows past M of the last tile
+    lw, lb = 1.0 + 0.1 * rnd(256, seed=7), 0.1 * rnd(256, seed=8)
+    gotn = ops.ffn_fused(x, w1, b1, w2p, b2, residual=res, w2_permuted=True, norm=(lw, lb, 1e-5))
+    refn = ref_ops.ffn_fused(x, w1, b1, w2, b2, residual=res, norm=(lw, lb, 1e-5))
+    en = relerr(gotn, refn)
+    print(f"ffn_fused + LayerNorm epilogue M{M} HID{HID}: {en:.3e}")
+    assert en < TOL[bf] and torch.isfinite(gotn.float()).all()
