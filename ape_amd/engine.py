@@ -44,18 +44,26 @@ class DefaultPredictor:
         self.short_edge_length, self.max_size = short_edge_length, max_size
         self.input_format = input_format
         assert self.input_format in ("RGB", "BGR"), self.input_format
-        self._pinned = None
+        self._pinned = [None, None]       # two staging buffers in rotation: an upload may still be in flight when the next image arrives
+        self._pinned_done = [None, None]  # events recorded behind each buffer's host-to-device copy
+        self._pinned_next = 0
 
     def _upload(self, image_hwc):
         """HWC uint8 (host) -> the same bytes on the model's device through a pinned staging buffer"""
         dev = next(self.model.parameters()).device
         t = torch.from_numpy(np.ascontiguousarray(image_hwc))
         if dev.type == "cuda":
-            if self._pinned is None or self._pinned.numel() < t.numel():
-                self._pinned = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
-            buf = self._pinned[: t.numel()].view(t.shape)
+            i = self._pinned_next
+            self._pinned_next = 1 - i
+            if self._pinned_done[i] is not None:
+                self._pinned_done[i].synchronize()          # the copy that last read this buffer has finished
+            if self._pinned[i] is None or self._pinned[i].numel() < t.numel():
+                self._pinned[i] = torch.empty(t.numel(), dtype=torch.uint8, pin_memory=True)
+            buf = self._pinned[i][: t.numel()].view(t.shape)
             buf.copy_(t)
             t = buf.to(dev, non_blocking=True)
+            self._pinned_done[i] = torch.cuda.Event()
+            self._pinned_done[i].record()
         return t
 
     def _resize_params(self):

@@ -15,6 +15,30 @@ from .eva02_clip import TEXT_CONFIGS, CustomCLIPText
 from .tokenizer import get_tokenizer
 
 
+class _TextFeatures(dict):
+    """the forward_text dict of the reference; "last_hidden_state" materialises on first access"""
+    _lazy_full = None
+
+    def __missing__(self, key):
+        if key == "last_hidden_state" and self._lazy_full is not None:
+            self[key] = self._lazy_full()
+            self._lazy_full = None
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == "last_hidden_state" and self._lazy_full is not None)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def keys(self):
+        return list(dict.keys(self)) + (["last_hidden_state"] if self._lazy_full is not None else [])
+
+
 class EVA02CLIP(nn.Module):
     def __init__(self, clip_model="EVA02-CLIP-B-16", cache_dir=None, dtype="float32", max_batch_size=2560, freeze=True,
                  text_cfg=None, embed_dim=None, tokenizer=None, all_positions=False):
@@ -76,10 +100,21 @@ class EVA02CLIP(nn.Module):
             fulls.append(full)
         end_token_idx = text_token.argmax(dim=-1)
         attention_mask = (torch.arange(ctx, device=text_token.device)[None, :] <= end_token_idx[:, None]).to(end_token_idx.dtype)
-        ret = {"end_token_idx": end_token_idx, "attention_mask": attention_mask, "last_hidden_state_eot": torch.cat(feats, 0)}
+        ret = _TextFeatures({"end_token_idx": end_token_idx, "attention_mask": attention_mask, "last_hidden_state_eot": torch.cat(feats, 0)})
         if self.all_positions:
             ret["last_hidden_state"] = torch.cat(fulls, 0)
+        else:
+            # the reference always returns the projected features of all 77 positions (clip_wrapper_eva02.py:117-122); nothing on the
+            # name-prompt path reads them, so they are computed on first access instead of on every call (7x the work of the
+            # end-of-text features on the truncated context)
+            ret._lazy_full = lambda: self._all_position_features(text_token)
         return ret
+
+    @torch.no_grad()
+    def _all_position_features(self, text_token):
+        fulls = [self.net.text.forward_tokens(text_token[s:s + self.max_batch_size], all_positions=True)[1]
+                 for s in range(0, text_token.shape[0], self.max_batch_size)]
+        return torch.cat(fulls, 0)
 
     @torch.no_grad()
     def forward_text(self, text_list, cache=False):

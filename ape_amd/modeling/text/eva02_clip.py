@@ -122,9 +122,11 @@ class TextTransformer(nn.Module):
         return self._pack.get(self, dt, build)
 
     @torch.no_grad()
-    def forward_tokens(self, text, all_positions=False):
+    def forward_tokens(self, text, all_positions=False, project_all=True):
         """text int [B, context] token ids -> (eot features [B, output_dim] fp32, all-position features [B, L, output_dim] fp32
-        or None, L).  L = the positions computed: the whole context with all_positions, else max(eot) + 1 rounded up to 8."""
+        or None, L).  L = the positions computed: the whole context with all_positions, else max(eot) + 1 rounded up to 8.
+        project_all=False: the all-position features are ln_final(x) [B, L, width] WITHOUT the text projection (what the
+        reference's TextTransformer.forward(return_all_features=True) returns, transformer.py:722-737)."""
         dt = self.compute_dtype
         P = self.packed(dt)
         B, ctx = text.shape
@@ -142,13 +144,16 @@ class TextTransformer(nn.Module):
         feat = ops.gemm(xe, P["wproj"], None, out_dtype=torch.float32)
         full = None
         if all_positions:
-            xa = ops.layernorm(x, P["nf"][0], P["nf"][1], P["nf"][2], out_dtype=dt)
-            full = ops.gemm(xa, P["wproj"], None, out_dtype=torch.float32).view(B, Lp, -1)[:, :L]
+            if project_all:
+                xa = ops.layernorm(x, P["nf"][0], P["nf"][1], P["nf"][2], out_dtype=dt)
+                full = ops.gemm(xa, P["wproj"], None, out_dtype=torch.float32).view(B, Lp, -1)[:, :L]
+            else:
+                full = ops.layernorm(x, P["nf"][0], P["nf"][1], P["nf"][2], out_dtype=torch.float32).view(B, Lp, -1)[:, :L]
         return feat, full, L
 
     def forward(self, text, return_all_features=False):
         """reference signature (transformer.py:722-737)"""
-        feat, full, _ = self.forward_tokens(text, all_positions=return_all_features)
+        feat, full, _ = self.forward_tokens(text, all_positions=return_all_features, project_all=False)
         return full if return_all_features else feat
 
 

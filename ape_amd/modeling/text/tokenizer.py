@@ -58,12 +58,20 @@ def byte_alphabet():
     return table
 
 
+_FTFY_WARNED = [False]
+
+
 def _clean(text):
     try:
         import ftfy                                    # the reference repairs mojibake first; identity for clean text
         text = ftfy.fix_text(text)
     except ImportError:
-        pass
+        if not _FTFY_WARNED[0] and not text.isascii():
+            # plain ASCII passes through ftfy unchanged; anything else may tokenize differently from the reference
+            import warnings
+            warnings.warn("ape_amd tokenizer: `ftfy` is not installed -- the reference applies ftfy.fix_text before BPE; non-ASCII "
+                          "prompts may tokenize differently (class-name vocabularies are unaffected)", stacklevel=2)
+            _FTFY_WARNED[0] = True
     text = html.unescape(html.unescape(text)).strip()
     return " ".join(text.split()).strip() if _re is None else _re.sub(r"\s+", " ", text).strip()
 

@@ -45,7 +45,16 @@ from .structures import make_instances
 # tests/test_model_gpu.py in suite order; keeping the graph objects alive removes it).  Evicted / orphaned graphs are parked
 # here instead -- their private memory pools stay allocated, which is why a mixed-size stream should use `any_size=True`
 # (one graph) instead of churning through per-size graphs.
-_RETIRED = []
+_RETIRED = []                    # [(graph object, bytes of its private pool)]
+# ... but not without bound: the parked pools are HBM a long-running server never gets back.  Parking more than this many bytes raises
+# (with what to do about it) instead of letting the process creep towards an out-of-memory: APE_GRAPH_RETIRE_LIMIT_GB, default 64 GB of
+# the 288 GB -- about 20 evicted full-size two-image step graphs of ~3 GB each.
+RETIRE_LIMIT_BYTES = int(float(os.environ.get("APE_GRAPH_RETIRE_LIMIT_GB", "64")) * (1 << 30))
+
+
+def retired_graphs():
+    """(number of parked graphs, bytes of HBM their private pools hold) -- process wide"""
+    return len(_RETIRED), sum(b for _, b in _RETIRED)
 
 
 class _Ticket:
@@ -92,14 +101,29 @@ class GraphedForward:
         self._graphs = {}
         self._copy_stream = None
 
-    def _retire(self, entry):
-        if getattr(entry, "graph", None) is not None:
-            _RETIRED.append(entry.graph)
+    def _retire(self, entry, strict=True):
+        if getattr(entry, "graph", None) is None:
+            return
+        nbytes = int(getattr(entry, "pool_bytes", 0))
+        n, held = retired_graphs()
+        if strict and held + nbytes > RETIRE_LIMIT_BYTES:
+            raise RuntimeError(
+                f"GraphedForward: evicting this graph would park {(held + nbytes) / (1 << 30):.1f} GB of HBM in {n + 1} retired hipGraphs "
+                f"(limit {RETIRE_LIMIT_BYTES / (1 << 30):.0f} GB, APE_GRAPH_RETIRE_LIMIT_GB).  Captured graphs are never destroyed on this "
+                "stack, so a stream that keeps changing (image size, vocabulary, frame) grows without bound: use any_size=True (one "
+                f"size-agnostic graph), raise max_graphs (now {self.max_graphs}) above the number of distinct keys, or raise the limit.")
+        _RETIRED.append((entry.graph, nbytes))
+
+    def memory_report(self):
+        """{"live_graphs", "live_bytes", "retired_graphs", "retired_bytes", "retire_limit_bytes"}: HBM held by captured steps"""
+        n, held = retired_graphs()
+        return {"live_graphs": len(self._graphs), "live_bytes": sum(int(getattr(e, "pool_bytes", 0)) for e in self._graphs.values()),
+                "retired_graphs": n, "retired_bytes": held, "retire_limit_bytes": RETIRE_LIMIT_BYTES}
 
     def __del__(self):
         try:
             for e in self._graphs.values():
-                self._retire(e)
+                self._retire(e, strict=False)     # a destructor parks unconditionally
         except Exception:       # interpreter shutdown
             pass
 
@@ -264,9 +288,11 @@ class GraphedForward:
             self._run_entry(e)
         torch.cuda.synchronize()
         if self.use_graph:
+            reserved = torch.cuda.memory_reserved()
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
                 e.outs = self._run_entry(e)
+            e.pool_bytes = max(0, torch.cuda.memory_reserved() - reserved)      # the capture's private pool (what eviction parks)
         else:
             e.graph = None
         if bank is not None:

@@ -328,3 +328,25 @@ def test_plain_family_state_dict_contract_and_host_pipeline(fake_ops):
     res = model([{"image": image, "height": image.shape[1], "width": image.shape[2], "text_features": text}])[0]["instances"]
     gi = gold["instances"]
     assert U.match_detections(res.pred_boxes, res.scores, res.pred_classes, gi["pred_boxes"], gi["scores"], gi["pred_classes"]) >= 0.97
+
+
+def test_graph_retirement_is_bounded(monkeypatch):
+    """captured graphs are parked, never destroyed (ROCm 7.2: destroying one breaks later captures) -- but the parked HBM is
+    accounted and capped: exceeding APE_GRAPH_RETIRE_LIMIT_GB raises with instructions instead of creeping to an out-of-memory"""
+    from types import SimpleNamespace
+    from ape_amd import runtime
+
+    monkeypatch.setattr(runtime, "_RETIRED", [])
+    monkeypatch.setattr(runtime, "RETIRE_LIMIT_BYTES", 10 << 30)
+    run = runtime.GraphedForward.__new__(runtime.GraphedForward)
+    run._graphs, run.max_graphs = {}, 4
+    for i in range(3):
+        run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30))
+    assert runtime.retired_graphs() == (3, 9 << 30)
+    with pytest.raises(RuntimeError, match="any_size=True"):
+        run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30))
+    assert runtime.retired_graphs() == (3, 9 << 30)                      # nothing parked by the refused eviction
+    run._retire(SimpleNamespace(graph=None))                             # eager entries hold no graph
+    run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30), strict=False)      # destructors park unconditionally
+    rep = run.memory_report()
+    assert rep["retired_graphs"] == 4 and rep["retired_bytes"] == 12 << 30 and rep["retire_limit_bytes"] == 10 << 30

@@ -77,7 +77,17 @@ def test_host_model_matches_reference_fixture(fake_ops):
         # causality: the truncated context (default) gives the same end-of-text features
         m2 = _model(cfg, g[name]["seed"])
         short = g["tokens"][:8]                                     # class names only: 3-6 tokens -> 8 positions computed
-        assert relerr(m2.forward_tokens(short)["last_hidden_state_eot"], g[name]["eot"][:8]) < 1e-5
+        out2 = m2.forward_tokens(short)
+        assert relerr(out2["last_hidden_state_eot"], g[name]["eot"][:8]) < 1e-5
+        # the reference's dict always carries the projected features of all 77 positions (clip_wrapper_eva02.py:117-122): here
+        # they materialise on first access (nothing on the name-prompt path reads them)
+        assert "last_hidden_state" in out2 and "last_hidden_state" in out2.keys() and not dict.__contains__(out2, "last_hidden_state")
+        assert relerr(out2["last_hidden_state"], g[name]["full"][:8]) < 1e-5 and dict.__contains__(out2, "last_hidden_state")
+        # TextTransformer.forward(return_all_features=True) = ln_final(x) WITHOUT the projection (transformer.py:722-737)
+        raw = m2.net.text(short, return_all_features=True)
+        assert raw.shape == (8, short.shape[1], cfg["width"] if "width" in cfg else raw.shape[-1])
+        proj = raw.reshape(-1, raw.shape[-1]) @ m2.net.text.text_projection.detach().float()
+        assert relerr(proj.reshape(8, short.shape[1], -1), g[name]["full"][:8]) < 1e-4
 
 
 def test_forward_text_cache_and_chunks(fake_ops):
