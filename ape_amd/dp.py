@@ -108,3 +108,45 @@ class DataParallelRunner:
         if self.gather_masks and getattr(ticket, "mask_runs", None) is None and getattr(ticket, "runs", None) is not None:
             ticket.mask_runs = self._all_gather_runs(ticket.runs)       # every rank's masks as run lengths: ticket.mask_runs
         return inst, ticket.records
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The evaluators' gather format.  Every evaluator of the reference collects `self._predictions` -- a Python list of
+# {"image_id": ..., "instances": [COCO-json dicts]} per rank -- with detectron2's `comm.gather(self._predictions, dst=0)` and chains
+# the per-rank lists on the main process (ape/evaluation/lvis_evaluation.py:101-107, d3_evaluation.py, refcoco_evaluation.py, ...):
+# pickled Python objects over a gloo group.  `gather_predictions` is that call with the same return contract (the list of per-rank
+# lists on `dst`, [] elsewhere), so an evaluator built on `ape_amd.evaluation.instances_to_coco_json` finishes exactly like the
+# reference's.  The per-step tensor all-gathers above stay the fast path for serving; this is the end-of-run exchange.
+# ------------------------------------------------------------------------------------------------------------------
+_CPU_GROUP = [None]
+
+
+def _cpu_group():
+    """a gloo group over all ranks for pickled-object collectives (detectron2 comm._get_global_gloo_group): RCCL moves tensors only"""
+    if dist.get_backend() == "gloo":
+        return dist.group.WORLD
+    if _CPU_GROUP[0] is None:
+        _CPU_GROUP[0] = dist.new_group(backend="gloo")
+    return _CPU_GROUP[0]
+
+
+def gather_predictions(predictions, dst=0):
+    """detectron2.utils.comm.gather for the evaluators' prediction lists: -> [rank 0's list, rank 1's list, ...] on rank `dst`,
+    [] on the others; single process: [predictions]"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [predictions]
+    group = _cpu_group()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if rank == dst:
+        out = [None] * world
+        dist.gather_object(predictions, out, dst=dst, group=group)
+        return out
+    dist.gather_object(predictions, None, dst=dst, group=group)
+    return []
+
+
+def chain_predictions(gathered):
+    """`list(itertools.chain(*predictions))` of the evaluators (lvis_evaluation.py:104): one flat list in rank order -- with the
+    contiguous shards of shard_indices that is dataset order"""
+    import itertools
+    return list(itertools.chain(*gathered))

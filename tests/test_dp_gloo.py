@@ -81,6 +81,17 @@ def _worker(rank, world, port, ret):
             g = torch.Generator().manual_seed(len(names))
             return {"last_hidden_state_eot": torch.randn(len(names), 1024, generator=g)}
 
+    # the evaluators' end-of-run exchange: per-rank Python lists of {"image_id", "instances": [json dicts]} gathered to rank 0
+    from ape_amd.dp import chain_predictions, gather_predictions
+    preds = [{"image_id": i, "instances": [{"image_id": i, "category_id": int(r[5]), "bbox": r[:4].tolist(), "score": float(r[4])}
+                                            for r in gathered[s][rank][:2]]} for s, i in enumerate(mine)]
+    got = gather_predictions(preds, dst=0)
+    if rank == 0:
+        flat = chain_predictions(got)
+        same &= len(got) == world and [p["image_id"] for p in flat] == sorted(p["image_id"] for p in flat) == list(range(len(images)))
+        same &= all(len(p["instances"]) == 2 and p["instances"][0]["image_id"] == p["image_id"] for p in flat)
+    else:
+        same &= got == []
     named = runner.text_bank_from_names(Tower() if rank == 0 else None, ["cat", "dog", "traffic light"])
     same &= tuple(named.shape) == (3, 1024) and (Tower.calls == (1 if rank == 0 else 0))
     ret[f"named_sum_{rank}"] = float(named.sum())
