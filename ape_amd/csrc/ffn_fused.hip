@@ -99,17 +99,36 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       w2off[j] = (uint32_t)ch * (uint32_t)p.ldw2 + (uint32_t)q * 8u;             // + chunk * 64
     }
   }
+  // The LDS-DMA of chunk c + 1 is issued through inline asm, NOT __builtin_amdgcn_global_load_lds: hipcc cannot tell the DMA's
+  // destination stage from the stage the fragment reads address (one array, run-time stage index) and drains the DMA queue
+  // (s_waitcnt vmcnt(0)) in front of the first ds_read after every issue -- the weights of the next chunk were waited for before
+  // any MFMA of this one (measured: 2.8 us per chunk = DMA latency + compute, nothing overlapped).  An asm statement is outside its
+  // bookkeeping (cdna_hip_programming.md 5.7); completion is ours: `s_waitcnt vmcnt(0)` + barrier at the end of the chunk.
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(ff_lds_void_t*)smem;
+  const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(wave);
+  auto glds16 = [&](const void* gsrc, uint32_t lds_dst) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  };
   auto issue = [&](int c, int s) __attribute__((always_inline)) {
-    unsigned char* d1 = smem + s * FF_STAGE + wave * 8192;
-    unsigned char* d2 = smem + s * FF_STAGE + 32768 + wave * 8192;
+    const uint32_t d1 = lds0 + (uint32_t)s * FF_STAGE + wave_u * 8192u;
+    const uint32_t d2 = d1 + 32768u;
     const bf16_t* s1 = p.W1 + (size_t)c * FF_HC * p.ldw1;
     const bf16_t* s2 = p.W2 + (size_t)c * FF_HC;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      __builtin_amdgcn_global_load_lds((ff_gbl_void_t*)(s1 + w1off[j]), (ff_lds_void_t*)(d1 + j * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((ff_gbl_void_t*)(s2 + w2off[j]), (ff_lds_void_t*)(d2 + j * 1024), 16, 0, 0);
+      glds16(s1 + w1off[j], d1 + j * 1024);
+      glds16(s2 + w2off[j], d2 + j * 1024);
     }
   };
+
+  // make hipcc wait for the x fragments HERE: left pending, its counted vmcnt waits for them sit inside the chunk loop (it cannot
+  // know they have long landed) and -- VMEM returns in order -- drain the untracked LDS-DMA queue with them
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(xf[rt][ks]));
 
   f32x4_t yacc[16][2];
 #pragma unroll
