@@ -111,16 +111,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
   };
-  auto issue = [&](int c, int s) __attribute__((always_inline)) {
+  // piece j of a chunk's DMA (this wave's 1 KB of W1 + 1 KB of W2); a chunk = pieces 0 .. 7.  In the loop the pieces are spread over
+  // the MFMA batches: sixteen back-to-back LDS-DMA issues (~100 cycles each: the address path) at the top of a chunk kept a wave
+  // that is alone on its SIMD from issuing a single MFMA for ~1.6 k cycles
+  auto issue_piece = [&](int c, int s, int j) __attribute__((always_inline)) {
     const uint32_t d1 = lds0 + (uint32_t)s * FF_STAGE + wave_u * 8192u;
     const uint32_t d2 = d1 + 32768u;
     const bf16_t* s1 = p.W1 + (size_t)c * FF_HC * p.ldw1;
     const bf16_t* s2 = p.W2 + (size_t)c * FF_HC;
+    glds16(s1 + w1off[j], d1 + j * 1024);
+    glds16(s2 + w2off[j], d2 + j * 1024);
+  };
+  auto issue = [&](int c, int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      glds16(s1 + w1off[j], d1 + j * 1024);
-      glds16(s2 + w2off[j], d2 + j * 1024);
-    }
+    for (int j = 0; j < 8; ++j) issue_piece(c, s, j);
   };
 
   // make hipcc wait for the x fragments HERE: left pending, its counted vmcnt waits for them sit inside the chunk loop (it cannot
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   __syncthreads();
   for (int c = 0; c < nc; ++c) {
     const int s = c & 1;
-    if (c + 1 < nc) issue(c + 1, s ^ 1);          // the other stage was released by the barrier that ended chunk c - 1
+    const int cn = c + 1 < nc ? c + 1 : c;        // pieces of chunk c + 1 go to the other stage, released by the barrier that ended chunk c - 1
+                                                  // (last chunk: a harmless reload of itself -- no branch inside the MFMA stream)
     const unsigned char* i1 = smem + s * FF_STAGE;
     const unsigned char* i2 = i1 + 32768;
 
@@ -228,15 +233,18 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) bch[ht] = *reinterpret_cast<const float4*>(sb1 + c * FF_HC + ht * 16 + 4 * g);
     FF_SB();
+#define FF_DMA(J) issue_piece(cn, s ^ 1, (J)); FF_SB();
     rd1(0, fa); rd1(1, fb); FF_SB();
-    rd1(2, fc); mm1(0, fa); FF_MIX(8); FF_SB();
-    rd1(3, fa); act(0); mm1(1, fb); FF_MIX(8); FF_SB();
-    rd2(0, 0, fb); act(1); pack(0); mm1(2, fc); FF_MIX(8); FF_SB();
-    rd2(0, 1, fc); act(2); mm1(3, fa); FF_MIX(8); FF_SB();
-    rd2(1, 0, fa); act(3); pack(1); mm2(0, 0, fb); FF_MIX(8); FF_SB();
-    rd2(1, 1, fb); mm2(0, 1, fc); FF_MIX(8); FF_SB();
-    mm2(1, 0, fa); FF_SB();
+    rd1(2, fc); mm1(0, fa); FF_MIX(8); FF_SB(); FF_DMA(0)
+    rd1(3, fa); act(0); mm1(1, fb); FF_MIX(8); FF_SB(); FF_DMA(1)
+    rd2(0, 0, fb); act(1); pack(0); mm1(2, fc); FF_MIX(8); FF_SB(); FF_DMA(2)
+    rd2(0, 1, fc); act(2); mm1(3, fa); FF_MIX(8); FF_SB(); FF_DMA(3)
+    rd2(1, 0, fa); act(3); pack(1); mm2(0, 0, fb); FF_MIX(8); FF_SB(); FF_DMA(4)
+    rd2(1, 1, fb); mm2(0, 1, fc); FF_MIX(8); FF_SB(); FF_DMA(5)
+    mm2(1, 0, fa); FF_SB(); FF_DMA(6)
+    FF_DMA(7)
     mm2(1, 1, fb); FF_SB();
+#undef FF_DMA
 #undef FF_MIX
 #undef FF_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunk c + 1 has landed (for this wave's share; the barrier covers the others)
