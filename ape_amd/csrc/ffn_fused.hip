@@ -21,8 +21,6 @@
 //   * LDS images: W1 rows are 512 B with the 16-byte chunk XOR-ed by (row & 31), W2 rows 128 B with chunk ^ ((row >> 1) & 7); the
 //     XOR is applied to the LDS-DMA source address (its destination is lane-linear) and to the fragment read address.
 // Per layer: 183 GFLOP on the MFMA pipe, 44.7 MB read + 44.7 MB written instead of 2 x 357 MB more.
-#include <stdlib.h>
-
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -45,7 +43,6 @@ struct FfnParams {
   bf16_t* Y; int ldy;
   int M, HID;
   const float* ln_w; const float* ln_b; float ln_eps;    // optional LayerNorm over the 256 output channels (NULL: none)
-  int rotate;                    // per-workgroup rotation of the hidden-chunk order (APE_FFN_ROTATE=0 disables: A/B)
 };
 
 // sum over the 4 lanes l, l^16, l^32, l^48 (the lanes that hold the four 64-channel quarters of one token's output row)
@@ -144,17 +141,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     for (int rt = 0; rt < 2; ++rt) yacc[ot][rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nc = p.HID / FF_HC;
-  // every workgroup walks the hidden chunks in its own rotation: all 256 resident workgroups asking the L2 for the SAME 64 KB at the
-  // same moment queued on a few channels (the sum over the hidden units is order independent up to fp32 rounding)
-  const int rot = p.rotate ? (int)(blockIdx.x % (unsigned)nc) : 0;
-  auto chunk_of = [&](int i) __attribute__((always_inline)) { const int c_ = i + rot; return c_ >= nc ? c_ - nc : c_; };
-  issue(chunk_of(0), 0);
+  issue(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int ci = 0; ci < nc; ++ci) {
-    const int s = ci & 1;
-    const int c = chunk_of(ci);
-    const int cn = chunk_of(ci + 1 < nc ? ci + 1 : ci);        // pieces of chunk c + 1 go to the other stage, released by the barrier that ended chunk c - 1
+  for (int c = 0; c < nc; ++c) {
+    const int s = c & 1;
+    const int cn = c + 1 < nc ? c + 1 : c;        // pieces of chunk c + 1 go to the other stage, released by the barrier that ended chunk c - 1
                                                   // (last chunk: a harmless reload of itself -- no branch inside the MFMA stream)
     const unsigned char* i1 = smem + s * FF_STAGE;
     const unsigned char* i2 = i1 + 32768;
@@ -328,7 +320,6 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
   APE_CHECK_ARG((ln_weight == nullptr) == (ln_bias == nullptr) && ((uintptr_t)ln_weight) % 16 == 0 && ((uintptr_t)ln_bias) % 16 == 0,
                 "ape_hip_ffn_fused: LayerNorm weight and bias come together, 16-byte aligned");
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = ln_eps;
-  { const char* r = getenv("APE_FFN_ROTATE"); p.rotate = (r == nullptr || r[0] != '0') ? 1 : 0; }
   const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {

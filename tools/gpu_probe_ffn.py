@@ -49,10 +49,6 @@ def main():
     w2p = permute_ffn_w2(w2)
     t_f = bench(lambda: ops.ffn_fused(x, w1, b1, w2, b2, residual=x))
     t_p = bench(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True))
-    os.environ["APE_FFN_ROTATE"] = "0"
-    t_p0 = bench(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True))
-    os.environ.pop("APE_FFN_ROTATE")
-    print(f"   pre-permuted W2 without the per-workgroup chunk rotation: {t_p0:.1f} us")
     t_2 = bench(lambda: ops.gemm(ops.gemm(x, w1, b1, act=ops.ACT_RELU), w2, b2, residual=x))
     fl = 2.0 * M * 256 * HID * 2
     print(f"87296 x 256 -> 2048 -> 256: fused, row-major W2 {t_f:.1f} us ({fl / t_f / 1e6:.0f} TF/s)   fused, pre-permuted W2 {t_p:.1f} us "
