@@ -21,6 +21,8 @@
 //   * LDS images: W1 rows are 512 B with the 16-byte chunk XOR-ed by (row & 31), W2 rows 128 B with chunk ^ ((row >> 1) & 7); the
 //     XOR is applied to the LDS-DMA source address (its destination is lane-linear) and to the fragment read address.
 // Per layer: 183 GFLOP on the MFMA pipe, 44.7 MB read + 44.7 MB written instead of 2 x 357 MB more.
+#include <stdlib.h>
+
 #include "common.h"
 #include "../../include/ape_hip.h"
 
@@ -58,23 +60,26 @@ __device__ __forceinline__ float ff_rows_sum(float v) {
 // W2P: W2's hidden columns arrive PRE-PERMUTED inside every group of 32 (position 8g + e holds hidden 4g + e for e < 4 and
 // 16 + 4g + e - 4 for e >= 4 -- the k order of the second MFMA's B operand above; ape_amd.packing.permute_ffn_w2): the W2 fragment
 // of a lane is then ONE ds_read_b128 instead of two ds_read_b64 (which reach their LDS rate only from ~4 waves per SIMD).
-template <bool W2P>
+// RT = 16-row token tiles per wave (2 | 3): a workgroup covers 64 RT rows.  The chunk time is set by the LDS-DMA bytes a CU can keep in
+// flight (one 64 KB chunk ahead: ~2.3 us per chunk whatever the MFMA count, measured), so rows per workgroup is the lever: RT = 3
+// does 1.5 x the MFMAs per streamed weight byte.  One wave per SIMD owns the whole 512-entry register file: RT = 3 uses ~460 of it.
+template <bool W2P, int RT>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * FF_STAGE);
   float* sb2 = sb1 + p.HID;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fm = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * FF_BM + wave * 32;
+  const int row0 = blockIdx.x * (64 * RT) + wave * (16 * RT);
 
   for (int i = tid; i < p.HID; i += 256) sb1[i] = p.b1[i];
   for (int i = tid; i < FF_N; i += 256) sb2[i] = p.b2[i];
 
   // ---- x fragments: B operand of the first MFMA (token = rt*16 + fm, k = ks*32 + 8g .. +8)
-  bf16x8_t xf[2][8];
-  int tok[2];
+  bf16x8_t xf[RT][8];
+  int tok[RT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     tok[rt] = row0 + rt * 16 + fm;
     const bf16_t* xp = p.X + (size_t)(tok[rt] < p.M ? tok[rt] : p.M - 1) * p.ldx + g * 8;
 #pragma unroll
@@ -130,15 +135,15 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   // make hipcc wait for the x fragments HERE: left pending, its counted vmcnt waits for them sit inside the chunk loop (it cannot
   // know they have long landed) and -- VMEM returns in order -- drain the untracked LDS-DMA queue with them
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(xf[rt][ks]));
 
-  f32x4_t yacc[16][2];
+  f32x4_t yacc[16][RT];
 #pragma unroll
   for (int ot = 0; ot < 16; ++ot)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) yacc[ot][rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RT; ++rt) yacc[ot][rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nc = p.HID / FF_HC;
   issue(0, 0);
@@ -178,22 +183,21 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
         }
       }
     };
-    f32x4_t hacc[4][2];
+    f32x4_t hacc[4][RT];
     auto mm1 = [&](int ht, const bf16x8_t (&f)[8]) __attribute__((always_inline)) {
-      hacc[ht][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      hacc[ht][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        hacc[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[0][ks], hacc[ht][0], 0, 0, 0);
-        hacc[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[1][ks], hacc[ht][1], 0, 0, 0);
-      }
+      for (int rt = 0; rt < RT; ++rt) hacc[ht][rt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) hacc[ht][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[rt][ks], hacc[ht][rt], 0, 0, 0);
     };
-    bf16x8_t hb[2][2];                                                                  // [kk][rt]: the activations as B operands
+    bf16x8_t hb[2][RT];                                                                 // [kk][rt]: the activations as B operands
     auto act = [&](int ht) __attribute__((always_inline)) {
       // bias + ReLU: lane holds hidden c*64 + ht*16 + 4g .. +3 of token rt*16 + fm
       const float4 b = bch[ht];
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         hacc[ht][rt][0] = fmaxf(hacc[ht][rt][0] + b.x, 0.f);
         hacc[ht][rt][1] = fmaxf(hacc[ht][rt][1] + b.y, 0.f);
         hacc[ht][rt][2] = fmaxf(hacc[ht][rt][2] + b.z, 0.f);
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     };
     auto pack = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         const uint4 u = make_uint4(pack2bf(hacc[2 * kk][rt][0], hacc[2 * kk][rt][1]), pack2bf(hacc[2 * kk][rt][2], hacc[2 * kk][rt][3]),
                                    pack2bf(hacc[2 * kk + 1][rt][0], hacc[2 * kk + 1][rt][1]),
                                    pack2bf(hacc[2 * kk + 1][rt][2], hacc[2 * kk + 1][rt][3]));
@@ -211,10 +215,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     };
     auto mm2 = [&](int kk, int og, const bf16x8_t (&f)[8]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        yacc[og * 8 + j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][0], yacc[og * 8 + j][0], 0, 0, 0);
-        yacc[og * 8 + j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][1], yacc[og * 8 + j][1], 0, 0, 0);
-      }
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          yacc[og * 8 + j][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][rt], yacc[og * 8 + j][rt], 0, 0, 0);
     };
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
     // ---- H^T = W1c . x^T (4 hidden tiles x 2 token tiles x 8 k steps), then Y^T += W2c . H^T (k step kk = hidden tiles 2kk, 2kk + 1,
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     // reads between the batches: 5.8 k cycles per chunk for 2.2 k of MFMA issue)
 #define FF_MIX(NREAD)                                     \
   _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    \
+    __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);   \
     if (i_ < (NREAD)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); \
     __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);    \
   }
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   // Every lane runs the arithmetic (clamped row for the residual of rows past M: cross-lane swaps need all lanes); only the store
   // is predicated.
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     const int tk = tok[rt] < p.M ? tok[rt] : p.M - 1;
     const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tk * p.ldr + g * 64 : nullptr;
     float v[64];
@@ -323,12 +327,17 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
   const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (w2_permuted) hipLaunchKernelGGL(ffn_fused_kernel<true>, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(ffn_fused_kernel<false>, dim3(ceil_div(M, FF_BM)), dim3(256), lds, (hipStream_t)stream, p);
+  // 192-row workgroups once they still give every CU at least one (the weights stream once per workgroup); APE_FFN_RT=2|3 overrides (A/B)
+  const char* rt_env = getenv("APE_FFN_RT");
+  const int rt = rt_env != nullptr ? atoi(rt_env) : (ceil_div(M, 192) >= 256 ? 3 : 2);
+  if (w2_permuted && rt == 3) hipLaunchKernelGGL((ffn_fused_kernel<true, 3>), dim3(ceil_div(M, 192)), dim3(256), lds, (hipStream_t)stream, p);
+  else if (w2_permuted) hipLaunchKernelGGL((ffn_fused_kernel<true, 2>), dim3(ceil_div(M, 128)), dim3(256), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((ffn_fused_kernel<false, 2>), dim3(ceil_div(M, 128)), dim3(256), lds, (hipStream_t)stream, p);
   APE_CHECK_LAUNCH("ffn_fused_kernel");
   return 0;
 }

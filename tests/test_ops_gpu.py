@@ -788,3 +788,10 @@ def test_ffn_fused(ops, M, HID):
     en = relerr(gotn, refn)
     print(f"ffn_fused + LayerNorm epilogue M{M} HID{HID}: {en:.3e}")
     assert en < TOL[bf] and torch.isfinite(gotn.float()).all()
+    # both workgroup heights (128 / 192 rows; the launcher picks by M) give the same rows
+    for rt in ("2", "3"):
+        os.environ["APE_FFN_RT"] = rt
+        try:
+            assert torch.equal(ops.ffn_fused(x, w1, b1, w2p, b2, residual=res, w2_permuted=True, norm=(lw, lb, 1e-5)), gotn), rt
+        finally:
+            os.environ.pop("APE_FFN_RT")

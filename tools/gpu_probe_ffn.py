@@ -49,6 +49,13 @@ def main():
     w2p = permute_ffn_w2(w2)
     t_f = bench(lambda: ops.ffn_fused(x, w1, b1, w2, b2, residual=x))
     t_p = bench(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True))
+    for rt in ("2", "3"):
+        os.environ["APE_FFN_RT"] = rt
+        y = ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True)
+        err = ((y.float() - ref.float()).abs().max() / ref.float().abs().max()).item()
+        t_rt = bench(lambda: ops.ffn_fused(x, w1, b1, w2p, b2, residual=x, w2_permuted=True))
+        print(f"   pre-permuted W2, {int(rt) * 64}-row workgroups (RT = {rt}): {t_rt:.1f} us ({2.0 * M * 256 * HID * 2 / t_rt / 1e6:.0f} TF/s), relerr {err:.2e}")
+    os.environ.pop("APE_FFN_RT")
     t_2 = bench(lambda: ops.gemm(ops.gemm(x, w1, b1, act=ops.ACT_RELU), w2, b2, residual=x))
     fl = 2.0 * M * 256 * HID * 2
     print(f"87296 x 256 -> 2048 -> 256: fused, row-major W2 {t_f:.1f} us ({fl / t_f / 1e6:.0f} TF/s)   fused, pre-permuted W2 {t_p:.1f} us "
