@@ -61,6 +61,8 @@ SIGNATURES = {
     "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),
+    "ape_hip_gemv_affine": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ape_hip_layernorm": (c_int, [POINTER(LayerNormArgs), c_void_p]),
     "ape_hip_groupnorm_workspace_floats": (c_int, [c_int, c_int]),
     "ape_hip_groupnorm": (c_int, [POINTER(GroupNormArgs), c_void_p]),
@@ -75,7 +77,8 @@ SIGNATURES = {
     "ape_hip_geometry": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int, c_void_p, c_float, c_float, c_float,
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
-    "ape_hip_head_gemv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ape_hip_head_gemv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                  c_void_p]),
     "ape_hip_attention_strided": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_float, c_int, c_void_p]),
     "ape_hip_attention_causal": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -87,12 +90,13 @@ SIGNATURES = {
     "ape_hip_im2col3x3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_maxpool2x2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_gather_rows_i64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_nms_mask_words": (c_int, [c_int]),
     "ape_hip_nms_mask": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p]),
     "ape_hip_nms_scan_segments": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ape_hip_nms_scan_classes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ape_hip_vl_pool_workspace_floats": (c_int, [c_int, c_int]),
-    "ape_hip_vl_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_vl_pool": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ape_hip_segment_softmax": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_colstats_workspace_floats": (c_int, [c_int, c_int]),
     "ape_hip_colstats": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -104,6 +108,11 @@ SIGNATURES = {
     "ape_hip_mask_upsample_sigmoid": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                               c_void_p]),
     "ape_hip_box_refine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_det_records": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_query_init": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                   c_void_p]),
+    "ape_hip_query_finish": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_bilinear_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_enc_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ape_hip_topk_workspace_words": (c_int, [c_int]),

@@ -595,12 +595,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
-// GEMV (M small): out[m][n] = alpha * sum_k x[m][k] * W[n][k] + bias[n]; one wave per n
+// GEMV (M small): out[m][n] = scale[n] * (alpha * sum_k x[m][k] * W[n][k] + bias[n]); one wave per n.
+// Optional second output out2[m][n] = add[m][n] + out[m][n] (the single-token language side's residual / folded-bias updates,
+// layers/fuse_helper.py: gamma_v * delta_v next to LN bias + gamma_v * delta_v, l + gamma_l * delta_l).
 // ------------------------------------------------------------------------------------------
 template <typename TW>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, int ldx, const TW* __restrict__ W,
                                                    int ldw, const float* __restrict__ bias, float* __restrict__ out,
-                                                   int ldo, int M, int N, int K, float alpha) {
+                                                   int ldo, int M, int N, int K, float alpha, const float* __restrict__ scale,
+                                                   const float* __restrict__ add, int ldadd, float* __restrict__ out2, int ldo2) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -621,7 +624,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
       for (int k = lane; k < K; k += 64) s = fmaf(xr[k], ldf<TW>(w + k), s);
     }
     s = wave_sum(s);
-    if (lane == 0) out[(size_t)m * ldo + n] = s * alpha + (bias != nullptr ? bias[n] : 0.f);
+    if (lane == 0) {
+      float r = s * alpha + (bias != nullptr ? bias[n] : 0.f);
+      if (scale != nullptr) r *= scale[n];
+      out[(size_t)m * ldo + n] = r;
+      if (out2 != nullptr) out2[(size_t)m * ldo2 + n] = add[(size_t)m * ldadd + n] + r;
+    }
   }
 }
 
@@ -1035,15 +1043,33 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   return 0;
 }
 
-extern "C" int ape_hip_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out,
-                            int ldo, int M, int N, int K, float alpha, void* stream) {
-  APE_CHECK_ARG(x && W && out && M > 0 && N > 0 && K > 0, "ape_hip_gemv: bad args");
+static int launch_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out, int ldo, int M,
+                       int N, int K, float alpha, const float* scale, const float* add, int ldadd, float* out2, int ldo2,
+                       void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nblk = ceil_div(N, 4);
   if (w_dt == APE_DT_BF16)
-    hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha);
+    hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
+                       scale, add, ldadd, out2, ldo2);
   else
-    hipLaunchKernelGGL(gemv_kernel<float>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)W, ldw, bias, out, ldo, M, N, K, alpha);
+    hipLaunchKernelGGL(gemv_kernel<float>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)W, ldw, bias, out, ldo, M, N, K, alpha,
+                       scale, add, ldadd, out2, ldo2);
+  return 0;
+}
+
+extern "C" int ape_hip_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out,
+                            int ldo, int M, int N, int K, float alpha, void* stream) {
+  APE_CHECK_ARG(x && W && out && M > 0 && N > 0 && K > 0, "ape_hip_gemv: bad args");
+  launch_gemv(x, ldx, W, ldw, w_dt, bias, out, ldo, M, N, K, alpha, nullptr, nullptr, 0, nullptr, 0, stream);
   APE_CHECK_LAUNCH("ape_hip_gemv");
+  return 0;
+}
+
+extern "C" int ape_hip_gemv_affine(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out,
+                                   int ldo, int M, int N, int K, float alpha, const float* scale, const float* add, int ldadd,
+                                   float* out2, int ldo2, void* stream) {
+  APE_CHECK_ARG(x && W && out && M > 0 && N > 0 && K > 0 && ((add == nullptr) == (out2 == nullptr)), "ape_hip_gemv_affine: bad args");
+  launch_gemv(x, ldx, W, ldw, w_dt, bias, out, ldo, M, N, K, alpha, scale, add, ldadd, out2, ldo2, stream);
+  APE_CHECK_LAUNCH("ape_hip_gemv_affine");
   return 0;
 }

@@ -124,8 +124,8 @@ extern "C" int ape_hip_maxpool2x2(const void* x, int ldx, const int* perm, int H
   return 0;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, int ldx, const int* __restrict__ idx, int n,
+template <typename T, typename TI>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ x, int ldx, const TI* __restrict__ idx, int n,
                                                           int C, T* __restrict__ out, int ldo) {
   const int cpr = C >> 3;
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -141,9 +141,21 @@ extern "C" int ape_hip_gather_rows(const void* x, int ldx, const int* idx, int n
   const size_t total = (size_t)n * (C / 8);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  if (dt == APE_DT_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, int>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
+  else hipLaunchKernelGGL((gather_rows_kernel<float, int>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_gather_rows");
+  return 0;
+}
+
+// the same with int64 row indices (what the selection kernels hand out: torch's index dtype)
+extern "C" int ape_hip_gather_rows_i64(const void* x, int ldx, const int64_t* idx, int n, int C, void* out, int ldo, int dt, void* stream) {
+  APE_CHECK_ARG(x && idx && out && n > 0 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "ape_hip_gather_rows_i64: bad args");
+  const size_t total = (size_t)n * (C / 8);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == APE_DT_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, int64_t>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
+  else hipLaunchKernelGGL((gather_rows_kernel<float, int64_t>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  APE_CHECK_LAUNCH("ape_hip_gather_rows_i64");
   return 0;
 }
 

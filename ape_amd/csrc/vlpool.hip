@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void vl_pool_partial_kernel(const float* __res
 
 // grid (8 heads, C/32): 8 k-groups x 32 columns per block, LDS tree over the k-groups
 __global__ __launch_bounds__(256) void vl_pool_final_kernel(const float* __restrict__ pacc, const float* __restrict__ psum, int nchunk,
-                                                            int C, float* __restrict__ out) {
+                                                            int C, const float* __restrict__ sub, float* __restrict__ out) {
   __shared__ float sa[8][32];
   __shared__ float sl[256];
   const int h = blockIdx.x, t = threadIdx.x;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void vl_pool_final_kernel(const float* __restr
     float acc = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) acc += sa[g][t];
-    out[h * C + c] = acc / sl[0];
+    out[h * C + c] = acc / sl[0] - (sub != nullptr ? sub[c] : 0.f);
   }
 }
 
@@ -125,9 +125,10 @@ extern "C" int ape_hip_vl_pool_workspace_floats(int T, int C) {
   return nchunk * VL_H * (C + 2);
 }
 
-// S [T, 8] fp32 scores (already scaled), x [T, C] -> out [8, C] fp32: softmax-over-T weighted mean of x per head
+// S [T, 8] fp32 scores (already scaled), x [T, C] -> out [8, C] fp32: softmax-over-T weighted mean of x per head, minus the
+// vector sub [C] when given (the pooled rows are taken on x - sub: the folded gamma_v * delta_v of layers/fuse_helper.py)
 extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace,
-                               float* out, void* stream) {
+                               const float* sub, float* out, void* stream) {
   APE_CHECK_ARG(S && x && workspace && out && T > 0 && C > 0, "ape_hip_vl_pool: bad args");
   const int nchunk = ceil_div(T, VL_CHUNK);
   float* pmax = workspace;
@@ -139,7 +140,7 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
     hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
   else
     hipLaunchKernelGGL(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
-  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, out);
+  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, sub, out);
   APE_CHECK_LAUNCH("ape_hip_vl_pool");
   return 0;
 }
@@ -147,12 +148,13 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
 
 // ------------------------------------------------------------------------------------------
 // Per-head matrix-vector products of the single-token language side (ape/layers/fuse_helper.py:70-73,140,160-161 after the
-// reassociation of layers/fuse_helper.py): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n], all fp32.
+// reassociation of layers/fuse_helper.py): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n], all fp32
+// (optionally a bf16 copy of out: the GEMM operand of the score product).
 // One wave per (h, n); replaces torch.einsum / matmul (rocBLAS launches inside the captured forward).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo, int H,
-                                                        int N, int D, float alpha) {
+                                                        int N, int D, float alpha, bf16_t* __restrict__ out_bf16, int ldob) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // over H * N
   if (row >= H * N) return;
@@ -169,14 +171,19 @@ __global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict_
     for (int d = lane; d < D; d += 64) s = fmaf(w[d], xr[d], s);
   }
   s = wave_sum(s);
-  if (lane == 0) out[(size_t)h * ldo + n] = s * alpha + (bias != nullptr ? bias[row] : 0.f);
+  if (lane == 0) {
+    const float r = s * alpha + (bias != nullptr ? bias[row] : 0.f);
+    out[(size_t)h * ldo + n] = r;
+    if (out_bf16 != nullptr) out_bf16[(size_t)h * ldob + n] = f2bf(r);
+  }
 }
 
 extern "C" int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N,
-                                 int D, float alpha, void* stream) {
+                                 int D, float alpha, void* out_bf16, int ldob, void* stream) {
   APE_CHECK_ARG(x && W && out && H > 0 && N > 0 && D > 0, "ape_hip_head_gemv: bad args");
   APE_CHECK_ARG(((uintptr_t)x) % 16 == 0 && ((uintptr_t)W) % 16 == 0, "ape_hip_head_gemv: x / W must be 16-byte aligned");
-  hipLaunchKernelGGL(head_gemv_kernel, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha);
+  hipLaunchKernelGGL(head_gemv_kernel, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
+                     (bf16_t*)out_bf16, ldob);
   APE_CHECK_LAUNCH("ape_hip_head_gemv");
   return 0;
 }

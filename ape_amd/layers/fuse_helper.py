@@ -152,21 +152,21 @@ class BiAttentionBlock(nn.Module):
         l_n = ops.layernorm(l, P["lnl"][0], P["lnl"][1], P["lnl"][2], out_dtype=torch.float32)
         k = ops.gemv(l_n, P["wl"], P["bl"])                      # l_proj            [1, E]
         vl = ops.gemv(l_n, P["wvl"], P["bvl"])                   # values_l_proj     [1, E]
-        dv = ops.gemv(vl, P["wov"], P["bov"])                    # out_v_proj (softmax over one token == 1)
-        gdv = (P["gv"] * dv[0]).contiguous()                     # gamma_v * delta_v [v_dim]
-        v_new, qp = ops.layernorm(x, P["lnv"][0], (P["lnv"][1] + gdv).contiguous(), P["lnv"][2], out_dtype=dt, add=lvl_pos)
+        # out_v_proj (softmax over one token == 1) with gamma_v and the LayerNorm bias in the epilogue:
+        # gdv = gamma_v * delta_v [1, v_dim], lnb = LN_v bias + gdv
+        gdv, lnb = ops.gemv(vl, P["wov"], P["bov"], scale=P["gv"], add=P["lnv"][1][None, :])
+        v_new, qp = ops.layernorm(x, P["lnv"][0], lnb[0], P["lnv"][2], out_dtype=dt, add=lvl_pos)
 
         def language_side():
             kh = k.view(a.num_heads, a.head_dim)
-            u = ops.head_gemv(kh, P["wvT"])                          # W_v,h^T k_h       [8, v_dim]
-            c = ops.head_gemv(kh, P["bv1"])                          # b_v,h . k_h       [8, 1]
-            ug = ops.gemv(gdv[None, :].contiguous(), u)              # u . gamma_v delta_v   [1, 8]
-            sbias = (a.scale * (c[:, 0] - ug[0])).contiguous()       # scores are taken on LN_v(v) = v_new - gdv
-            S = ops.gemm(v_new, u.to(dt).contiguous(), sbias, alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
-            pooled = (ops.vl_pool(S, v_new) - gdv[None, :]).contiguous()   # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
+            u, u_c = ops.head_gemv(kh, P["wvT"], bf16_copy=True)     # W_v,h^T k_h       [8, v_dim] (+ the GEMM operand copy)
+            c = ops.head_gemv(kh, P["bv1"], alpha=a.scale)           # scale * b_v,h . k_h   [8, 1]
+            # scores are taken on LN_v(v) = v_new - gdv: bias_h = scale * (c_h - u_h . gamma_v delta_v)
+            _, sbias = ops.gemv(gdv, u, alpha=-a.scale, add=c.view(1, -1))
+            S = ops.gemm(v_new, u_c if dt == torch.bfloat16 else u, sbias[0], alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
+            pooled = ops.vl_pool(S, v_new, gdv[0])                   # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
             ol = ops.head_gemv(pooled, P["wvv"], P["bvv"])           # values_v_proj per head   [8, hd]
-            dl = ops.gemv(ol.reshape(1, -1).contiguous(), P["wol"], P["bol"])
-            return l_n + P["gl"] * dl
+            return ops.gemv(ol.view(1, -1), P["wol"], P["bol"], scale=P["gl"], add=l_n)[1]       # l_n + gamma_l * delta_l
 
         return v_new, qp, ops.fork(language_side)
 

@@ -399,7 +399,14 @@ class DeformableDETRSegmVL(nn.Module):
         else:                                    # the FUSED tokens are the vocabulary (:448); they change per image
             tok, cbias, inv_scale = self.class_embed[lvl].text_side(tr["query_l"], dt)
         logits = self.class_embed[lvl].forward_tokens(x, tok, cbias, inv_scale)                       # [Q,K] fp32
-        boxes = (self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32) + G.inverse_sigmoid(ref_prev)).sigmoid()
+        dec = self.transformer.decoder
+        if stages is None and dec.bbox_embed is not None and dec.bbox_embed[lvl] is self.bbox_embed[lvl]:
+            # with_box_refine: the decoder's own refinement of its last layer IS this head (:240-246 and :490-500 apply the same
+            # module to the same tensors: sigmoid(bbox_embed[lvl](x) + inverse_sigmoid(reference))) -- no second evaluation
+            boxes = tr["inter_references"][lvl]
+        else:
+            delta = self.bbox_embed[lvl].forward_tokens(x, dt, out_dtype=torch.float32)
+            boxes, _ = ops.box_refine(delta, ref_prev.contiguous(), geo.vr4)
         logits, boxes = tap(stages, "pred_logits", logits), tap(stages, "pred_boxes", boxes)
         out = dict(pred_logits=logits, pred_boxes=boxes, topk_proposals=tr["topk_proposals"], geo=geo)
         det = {}
@@ -430,14 +437,14 @@ class DeformableDETRSegmVL(nn.Module):
                 pvalid = torch.ones_like(pq, dtype=torch.bool)
             H0, W0 = geo.shapes[0]
             S = self.backbone.padding_constraints.get("square_size", 0)
-            pkept = ops.gather_rows(membed, pq.to(torch.int32))
+            pkept = ops.gather_rows(membed, pq)
             plog = ops.gemm(pkept, mask_feat, None, out_dtype=torch.float32)                          # [k, H0*W0]
             up = ops.bilinear_resize(plog.view(-1, H0, W0), S, S)
             out.update(pan_masks=up[:, :h, :w], pan_cls=logits[pq], pan_valid=pvalid, pan_query=pq)
         if want_masks:
             H0, W0 = geo.shapes[0]
             # only the kept queries are decoded / upsampled: the einsum (:510) and F.interpolate (:569-572) act per query
-            kept = ops.gather_rows(membed, det["det_query"].to(torch.int32))
+            kept = ops.gather_rows(membed, det["det_query"])
             mlog = ops.gemm(kept, mask_feat, None, out_dtype=torch.float32)                           # [n, H0*W0]
             S = self.backbone.padding_constraints.get("square_size", 0)
             bits = ops.mask_upsample_bits(mlog, H0, W0, S)

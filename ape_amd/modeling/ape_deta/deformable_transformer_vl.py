@@ -95,11 +95,11 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
             return dict(wval=pack_matrix(torch.cat(ws, 0), dt), bval=torch.cat(bs).contiguous())
         return self._pack.get(self, dt, build)
 
-    def forward_tokens(self, query, query_pos, memory, geo, reference, dt, stages=None):
+    def forward_tokens(self, query, query_pos, memory, geo, reference, dt, stages=None, query_sum=None):
         """query/query_pos [Q,256], memory [T,256], reference [Q,4] fp32 (sigmoid space) -> (inter [list of Q,256],
         inter_ref [list of Q,4]) -- reference loop :195-250.  stages: per-layer taps "dec<i>_out", "dec<i>_delta" (box head
         output), "dec<i>_ref" (refined reference); under teacher forcing (stagetap.StageTap) every layer starts from the
-        teacher's query stream and reference boxes."""
+        teacher's query stream and reference boxes.  query_sum = query + query_pos when the caller already has it."""
         P = self.packed(dt)
         E = self.embed_dim
         # value_proj of all layers in ONE pass over the encoder memory (the reference re-reads it per layer)
@@ -110,7 +110,7 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         vt_buf = torch.zeros((E, round_up(Q, 64)), dtype=dt, device=query.device)
         vr4 = geo.vr4                                                   # [L, 4] = cat(valid_ratios, valid_ratios)
         out = query
-        outp = (query.float() + query_pos.float()).to(dt)
+        outp = query_sum if query_sum is not None else (query.float() + query_pos.float()).to(dt)
         inter, inter_ref = [], []
         _, ref_in = ops.box_refine(None, reference.contiguous(), vr4)      # reference * valid ratios per level (:203-210)
         refjob = ops._Joined((reference, ref_in))
@@ -247,19 +247,20 @@ class DeformableDetrTransformerVL(nn.Module):
             # two-stage selection (:565-627): per-level top-k, NMS 0.9, per-level quota, fallback -- fixed-shape device code
             topk = ops.select_proposals(enc_class, xyxy, geo.shapes, self.pre_nms_topk, self.two_stage_num_proposals,
                                         self.nms_thresh_enc)
-        coords = enc_coord[topk]                                          # [Q,4] unactivated
-        reference = coords.sigmoid()
-        pe = G.proposal_pos_embed(coords).to(dt).contiguous()
-        pt = ops.layernorm(ops.gemm(pe, P["wpos"], P["bpos"], out_dtype=torch.float32), *P["npos"], out_dtype=torch.float32)
-        query_pos = pt[:, :E].to(dt).contiguous()
-        feats = ops.gather_rows(om, topk.to(torch.int32))
-        pix = ops.layernorm(ops.gemm(feats, P["wpix"], P["bpix"], out_dtype=torch.float32), *P["npix"], out_dtype=torch.float32)
-        query = (pt[:, E:] + pix).to(dt).contiguous()
+        # query initialisation (:629-645): sigmoid + sine embedding of the selected proposals in one launch, both LayerNorms +
+        # split + add + the first layer's query + query_pos in another (csrc/boxes.hip)
+        reference, pe, topk32 = ops.query_init(enc_coord, topk, G.dim_t_table(128, 10000, om.device), dt)
+        pos_raw = ops.gemm(pe, P["wpos"], P["bpos"], out_dtype=torch.float32)
+        pix_raw = ops.gemm(ops.gather_rows(om, topk32), P["wpix"], P["bpix"], out_dtype=torch.float32)
+        query_pos, query, query_sum = ops.query_finish(pos_raw, pix_raw, P["npos"], P["npix"], dt)
         if stages is not None:
             stages["topk_proposals"] = topk
+            q0, p0 = query, query_pos
             query, query_pos = tap(stages, "query_init", query), tap(stages, "query_pos", query_pos)
+            if query is not q0 or query_pos is not p0:
+                query_sum = None                                          # teacher forcing: the decoder recomputes it
             reference = tap(stages, "init_reference", reference)
-        inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt, stages)
+        inter, inter_ref = self.decoder.forward_tokens(query, query_pos, memory, geo, reference, dt, stages, query_sum=query_sum)
         return dict(inter_states=inter, init_reference=reference, inter_references=inter_ref, enc_class=enc_class,
                     enc_coord_unact=enc_coord, memory=memory, query_l=l_out, topk_proposals=topk)
 

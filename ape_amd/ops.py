@@ -5,6 +5,7 @@ PyTorch is used here only as the allocator / stream provider.  Every function la
 the library is missing -- there is no CPU or PyTorch fallback in the product path.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -168,19 +169,35 @@ def row_stats(x, eps):
     return out[0], out[1]
 
 
-def gemv(x, w, bias=None, alpha=1.0):
-    """out[m,n] = alpha * x[m,:] . w[n,:] + bias[n]; x fp32 [M,K] (M small), w f32/bf16 [N,K] -> fp32 [M,N]."""
-    _dev(x, w, bias)
+def gemv(x, w, bias=None, alpha=1.0, *, scale=None, add=None):
+    """out[m,n] = scale[n] * (alpha * x[m,:] . w[n,:] + bias[n]); x fp32 [M,K] (M small), w f32/bf16 [N,K] -> fp32 [M,N].
+    With `add` (fp32 [M,N]) returns (out, add + out): the element-wise tails of the single-token language side ride in the
+    epilogue instead of separate element-wise launches."""
+    _dev(x, w, bias, scale, add)
     _rowmajor(x, "x"), _rowmajor(w, "w")
     if x.dtype != torch.float32:
         raise TypeError("ape_amd.ops.gemv: x must be float32")
     M, K = x.shape
     N = w.shape[0]
     out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    rc = _lib.load().ape_hip_gemv(_p(x), _ld(x), _p(w), _ld(w), _dt(w), _p(_f32vec(bias, "bias")), _p(out), N, M, N, K,
-                                 float(alpha), _stream())
-    _lib.check(rc, "ape_hip_gemv")
-    return out
+    if scale is None and add is None:
+        rc = _lib.load().ape_hip_gemv(_p(x), _ld(x), _p(w), _ld(w), _dt(w), _p(_f32vec(bias, "bias")), _p(out), N, M, N, K,
+                                     float(alpha), _stream())
+        _lib.check(rc, "ape_hip_gemv")
+        return out
+    out2 = None
+    if add is not None:
+        _rowmajor(add, "add")
+        if add.dtype != torch.float32 or tuple(add.shape) != (M, N):
+            raise ValueError(f"ape_amd.ops.gemv: add must be float32 {(M, N)}")
+        out2 = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if scale is not None and scale.numel() != N:
+        raise ValueError("ape_amd.ops.gemv: scale must have one entry per output column")
+    rc = _lib.load().ape_hip_gemv_affine(_p(x), _ld(x), _p(w), _ld(w), _dt(w), _p(_f32vec(bias, "bias")), _p(out), N, M, N, K,
+                                        float(alpha), _p(_f32vec(scale, "scale")), _p(add), _ld(add) if add is not None else 0,
+                                        _p(out2), N, _stream())
+    _lib.check(rc, "ape_hip_gemv_affine")
+    return out if add is None else (out, out2)
 
 
 def geometry(S, h, w, level_shapes, dim_t, level_embeds, offset, eps, scale, *, lvl_pos, mask_u8, mask, invalid_u8, enc_ref,
@@ -202,8 +219,9 @@ def geometry(S, h, w, level_shapes, dim_t, level_embeds, offset, eps, scale, *, 
     _lib.check(rc, "ape_hip_geometry")
 
 
-def head_gemv(x, w, bias=None, alpha=1.0):
-    """out[h, n] = alpha * x[h, :] . w[h, n, :] + bias[h, n]; x [H, D], w [H, N, D], bias [H, N] (all fp32) -> [H, N] fp32."""
+def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):
+    """out[h, n] = alpha * x[h, :] . w[h, n, :] + bias[h, n]; x [H, D], w [H, N, D], bias [H, N] (all fp32) -> [H, N] fp32
+    (bf16_copy: -> (out, out rounded to bf16), the copy written by the same launch)."""
     _dev(x, w, bias)
     if x.dtype != torch.float32 or w.dtype != torch.float32 or not w.is_contiguous():
         raise TypeError("ape_amd.ops.head_gemv: fp32 x and contiguous fp32 w")
@@ -214,9 +232,10 @@ def head_gemv(x, w, bias=None, alpha=1.0):
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != H * N):
         raise ValueError("ape_amd.ops.head_gemv: bias must be a contiguous fp32 [H, N] tensor")
     out = torch.empty((H, N), dtype=torch.float32, device=x.device)
-    rc = _lib.load().ape_hip_head_gemv(_p(x), _ld(x), _p(w), _p(bias), _p(out), N, H, N, D, float(alpha), _stream())
+    cp = torch.empty((H, N), dtype=torch.bfloat16, device=x.device) if bf16_copy else None
+    rc = _lib.load().ape_hip_head_gemv(_p(x), _ld(x), _p(w), _p(bias), _p(out), N, H, N, D, float(alpha), _p(cp), N, _stream())
     _lib.check(rc, "ape_hip_head_gemv")
-    return out
+    return (out, cp) if bf16_copy else out
 
 
 def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None, add=None, out2=None):
@@ -417,11 +436,18 @@ def maxpool2x2(x, perm, h, w):
 
 
 def gather_rows(x, idx, *, out=None):
+    """out[r] = x[idx[r]]; idx int32 or int64 (contiguous)"""
     _dev(x, idx, out)
     _rowmajor(x, "x")
     n, C = idx.numel(), x.shape[1]
     if out is None:
         out = torch.empty((n, C), dtype=x.dtype, device=x.device)
+    if idx.dtype == torch.int64:
+        if not idx.is_contiguous():
+            raise ValueError("ape_amd.ops.gather_rows: idx must be contiguous")
+        rc = _lib.load().ape_hip_gather_rows_i64(_p(x), _ld(x), _p(idx), n, C, _p(out), _ld(out), _dt(x), _stream())
+        _lib.check(rc, "ape_hip_gather_rows_i64")
+        return out
     rc = _lib.load().ape_hip_gather_rows(_p(x), _ld(x), _p(_i32(idx, "idx")), n, C, _p(out), _ld(out), _dt(x), _stream())
     _lib.check(rc, "ape_hip_gather_rows")
     return out
@@ -471,17 +497,20 @@ def nms_classes(boxes, order, iou_thr, valid=None):
     return keep
 
 
-def vl_pool(scores, x):
-    """out[h,:] = sum_t softmax_t(scores[t,h]) x[t,:]  (single-text-token language side, fuse_helper.py:89-116,140)."""
-    _dev(scores, x)
+def vl_pool(scores, x, sub=None):
+    """out[h,:] = sum_t softmax_t(scores[t,h]) x[t,:] - sub  (single-text-token language side, fuse_helper.py:89-116,140; sub [C]
+    fp32: pooling x - sub)."""
+    _dev(scores, x, sub)
     _rowmajor(scores, "scores"), _rowmajor(x, "x")
     if scores.dtype != torch.float32 or scores.shape[1] != 8:
         raise ValueError("ape_amd.ops.vl_pool: scores must be float32 [T,8]")
     T, C = x.shape
+    if sub is not None and sub.numel() != C:
+        raise ValueError("ape_amd.ops.vl_pool: sub must have one entry per channel")
     lib = _lib.load()
     ws = torch.empty((lib.ape_hip_vl_pool_workspace_floats(T, C),), dtype=torch.float32, device=x.device)
     out = torch.empty((8, C), dtype=torch.float32, device=x.device)
-    rc = lib.ape_hip_vl_pool(_p(scores), _ld(scores), _p(x), _ld(x), _dt(x), T, C, _p(ws), _p(out), _stream())
+    rc = lib.ape_hip_vl_pool(_p(scores), _ld(scores), _p(x), _ld(x), _dt(x), T, C, _p(ws), _p(_f32vec(sub, "sub")), _p(out), _stream())
     _lib.check(rc, "ape_hip_vl_pool")
     return out
 
@@ -619,6 +648,61 @@ def box_refine(delta, ref, vr4, eps=1e-3):
                                         _p(new_ref) if delta is not None else None, _p(ref_in), _stream())
     _lib.check(rc, "ape_hip_box_refine")
     return new_ref, ref_in
+
+
+def det_records(det_boxes, det_scores, det_classes, det_query, frame):
+    """Detection records in the output frame, kept rows first (csrc/boxes.hip det_records_kernel): det_boxes [k,4] / det_scores [k]
+    fp32, det_classes / det_query [k] int64, frame [8] fp32 (sx, sy, sx, sy, width, height, width, height) ->
+    (rec [k,8] = box, score | -1, class, query, keep; boxes [k,4]; order [k] int32 = source row of every output row)."""
+    _dev(det_boxes, det_scores, det_classes, det_query, frame)
+    k = det_scores.numel()
+    for t, dt_, n in ((det_boxes, torch.float32, 4 * k), (det_scores, torch.float32, k), (det_classes, torch.int64, k),
+                      (det_query, torch.int64, k), (frame, torch.float32, 8)):
+        if t.dtype != dt_ or not t.is_contiguous() or t.numel() != n:
+            raise ValueError("ape_amd.ops.det_records: contiguous fp32 boxes [k,4] / scores [k] / frame [8], int64 classes / query [k]")
+    dev = det_boxes.device
+    rec = torch.empty((k, 8), dtype=torch.float32, device=dev)
+    boxes = torch.empty((k, 4), dtype=torch.float32, device=dev)
+    order = torch.empty((k,), dtype=torch.int32, device=dev)
+    rc = _lib.load().ape_hip_det_records(_p(det_boxes), _p(det_scores), _p(det_classes), _p(det_query), _p(frame), k, _p(rec), _p(boxes),
+                                        _p(order), _stream())
+    _lib.check(rc, "ape_hip_det_records")
+    return rec, boxes, order
+
+
+def query_init(coords_unact, topk, dim_t, out_dtype, scale=2 * math.pi):
+    """Two-stage query initialisation, part 1 (deformable_transformer_vl.py:412-420, 629-634): coords_unact [T,4] fp32, topk [Q]
+    int64 -> (reference [Q,4] fp32 = sigmoid(coords[topk]), pe [Q, 4P] out_dtype = sine embedding of the proposals, topk as int32)."""
+    _dev(coords_unact, topk, dim_t)
+    if coords_unact.dtype != torch.float32 or not coords_unact.is_contiguous() or coords_unact.dim() != 2 or coords_unact.shape[1] != 4:
+        raise ValueError("ape_amd.ops.query_init: coords must be contiguous float32 [T,4]")
+    if topk.dtype != torch.int64 or not topk.is_contiguous():
+        raise ValueError("ape_amd.ops.query_init: topk must be contiguous int64")
+    T, Q, P = coords_unact.shape[0], topk.numel(), dim_t.numel()
+    dev = coords_unact.device
+    reference = torch.empty((Q, 4), dtype=torch.float32, device=dev)
+    pe = torch.empty((Q, 4 * P), dtype=out_dtype, device=dev)
+    topk32 = torch.empty((Q,), dtype=torch.int32, device=dev)
+    rc = _lib.load().ape_hip_query_init(_p(coords_unact), _p(topk), T, _p(_f32vec(dim_t, "dim_t")), P, float(scale), Q, _p(reference),
+                                       _p(pe), 4 * P, _dt(pe), _p(topk32), _stream())
+    _lib.check(rc, "ape_hip_query_init")
+    return reference, pe, topk32
+
+
+def query_finish(pos, pix, norm_pos, norm_pix, out_dtype):
+    """Two-stage query initialisation, part 2 (:635-645): pos [Q, 2E] / pix [Q, E] fp32 GEMM outputs, norm_* = (weight, bias, eps)
+    -> (query_pos, query, query + query_pos) [Q, E] in out_dtype."""
+    _dev(pos, pix)
+    _rowmajor(pos, "pos"), _rowmajor(pix, "pix")
+    Q, E = pix.shape
+    if pos.dtype != torch.float32 or pix.dtype != torch.float32 or pos.shape != (Q, 2 * E):
+        raise ValueError("ape_amd.ops.query_finish: pos [Q, 2E] / pix [Q, E] float32")
+    outs = [torch.empty((Q, E), dtype=out_dtype, device=pos.device) for _ in range(3)]
+    rc = _lib.load().ape_hip_query_finish(_p(pos), _ld(pos), _p(pix), _ld(pix), Q, E, _p(_f32vec(norm_pos[0], "w")), _p(_f32vec(norm_pos[1], "b")),
+                                         float(norm_pos[2]), _p(_f32vec(norm_pix[0], "w")), _p(_f32vec(norm_pix[1], "b")), float(norm_pix[2]),
+                                         _p(outs[0]), _p(outs[1]), _p(outs[2]), E, _dt(outs[0]), _stream())
+    _lib.check(rc, "ape_hip_query_finish")
+    return tuple(outs)
 
 
 # ------------------------------------------------------------------------------------------------------------------

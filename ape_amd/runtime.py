@@ -128,45 +128,38 @@ class GraphedForward:
             pass
 
     # ------------------------------------------------------------------ device work of one image
-    def _device_part(self, image, text, height, width, prompt="name", vit_feat=None, geo=None, frame=None, encoder_done=None):
+    def _device_part(self, image, text, height, width, frame, prompt="name", vit_feat=None, geo=None, encoder_done=None):
         """everything up to (excluding) the mask paste: (record [k,8], 128x128 masks or None, boxes in the output frame).
-        frame (any_size): device vector [8] = (sx, sy, sx, sy, width, height, width, height) of the output frame."""
+        frame: device vector [8] = (sx, sy, sx, sy, width, height, width, height) of the output frame (rewritten per image
+        with any_size, constant otherwise)."""
+        import math
+        from . import ops
         mv = self.mv
-        h, w = image.shape[-2:]
         out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo,
                                 encoder_done=encoder_done, semantic=self.semantic)
         labels = None
         if self.semantic is not None:
-            import math
-            from . import ops
             r = ops.bilinear_resize(out["sem_seg"], height, width)                           # sem_seg_postprocess (:916)
             meta = self.semantic
             if (mv.eval_dataset_id >= 0 and meta.get("entity") == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
                     and mv.stuff_prob_thing > 0):                                            # (:654-663)
                 r[0] = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
             labels = r.argmax(0).to(torch.int16).contiguous()                                # [height, width]
-        if frame is None:
-            boxes = out["det_boxes"].clone()
-            boxes[:, 0::2] = (boxes[:, 0::2] * (width / w)).clamp(0, width)
-            boxes[:, 1::2] = (boxes[:, 1::2] * (height / h)).clamp(0, height)
-        else:
-            boxes = torch.minimum((out["det_boxes"] * frame[:4]).clamp_min(0.0), frame[4:])
-        keep = (out["det_scores"] >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
-        # dropped rows (empty slots, empty boxes after the rescale) carry score -1 in the record, so the 6-column view that
-        # is all-gathered across ranks tells kept from dropped without the keep column
-        score = torch.where(keep, out["det_scores"], torch.full_like(out["det_scores"], -1.0))
-        rec = torch.cat([boxes, score[:, None], out["det_classes"][:, None].float(),
-                         out["det_query"][:, None].float(), keep[:, None].float()], 1)                 # [k, 8]
-        # kept detections first (stable): the host then takes PREFIX views of the pinned buffers instead of gathering
-        # ~1 MB per mask with a boolean index (a 105 MB host copy per image whenever one detection is dropped)
-        order = torch.sort((~keep).to(torch.int8), stable=True)[1]
+        # boxes in the output frame, keep flags, records with the kept detections first (stable) -- the host then takes PREFIX
+        # views of the pinned buffers instead of gathering ~1 MB per mask with a boolean index; dropped rows (empty slots, empty
+        # boxes after the rescale) carry score -1, so the 6-column view that is all-gathered across ranks tells kept from dropped
+        # without the keep column.  One launch (csrc/boxes.hip) + one row gather of the 128 x 128 masks.
+        rec, boxes, order = ops.det_records(out["det_boxes"], out["det_scores"], out["det_classes"], out["det_query"], frame)
         masks128 = out.get("det_masks128")
-        return rec[order].contiguous(), (masks128[order].contiguous() if masks128 is not None else None), boxes[order].contiguous(), labels
+        if masks128 is not None:
+            n = masks128.shape[0]
+            masks128 = ops.gather_rows(masks128.view(n, -1).view(torch.float32), order).view(torch.uint8).view(masks128.shape)
+        return rec, masks128, boxes, labels
 
     def _tail(self, e, b, vit_feat, encoder_done=None):
         height, width = e.size
-        return self._device_part(e.images[b], e.text, height, width, e.prompt, vit_feat,
-                                 e.sgeo[b] if self.any_size else None, e.frame[b] if self.any_size else None, encoder_done)
+        return self._device_part(e.images[b], e.text, height, width, e.frame[b], e.prompt, vit_feat,
+                                 e.sgeo[b] if self.any_size else None, encoder_done)
 
     def _run_entry(self, e):
         """the device work of one step of entry `e` on its static buffers: (ViT of the images) + B tails"""
@@ -278,6 +271,11 @@ class GraphedForward:
             e.size = (S, S)
         else:
             e.images = [im.clone() for im in images]
+            vals = []
+            for im in images:
+                sx, sy = width / im.shape[-1], height / im.shape[-2]
+                vals.append([sx, sy, sx, sy, width, height, width, height])
+            e.frame = torch.tensor(vals, dtype=torch.float32).to(dev)
         if self.pipeline:
             net = mv.backbone.net
             n_tok = (net.img_size // net.patch_size) ** 2

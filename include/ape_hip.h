@@ -97,6 +97,12 @@ int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, float eps, f
  * (the L=1 language side of ape/layers/fuse_helper.py:70-73,160-161). */
 int ape_hip_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out, int ldo,
                  int M, int N, int K, float alpha, void* stream);
+/* the same with the element-wise tails of that language side in the epilogue (layers/fuse_helper.py; reference
+ * fuse_helper.py:224-231: v + gamma_v * delta_v, l + gamma_l * delta_l): out[m][n] = scale[n] * (alpha * x[m,:] . W[n,:] + bias[n])
+ * (scale may be NULL) and, when add / out2 are given, out2[m][n] = add[m][n] + out[m][n]. */
+int ape_hip_gemv_affine(const float* x, int ldx, const void* W, int ldw, int w_dt, const float* bias, float* out, int ldo,
+                        int M, int N, int K, float alpha, const float* scale, const float* add, int ldadd, float* out2, int ldo2,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim: y = (x-mean)/sqrt(var+eps)*w + b  [act]  ; optional y2 = y + add
@@ -216,6 +222,7 @@ int ape_hip_patchify(const float* img, int h, int w, const int32_t* tok2raster, 
 int ape_hip_im2col3x3(const void* x, int ldx, const int32_t* perm, int H, int W, int C, void* out, int ldo, int dt, void* stream);
 int ape_hip_maxpool2x2(const void* x, int ldx, const int32_t* perm, int H, int W, int C, void* out, int ldo, int dt, void* stream);
 int ape_hip_gather_rows(const void* x, int ldx, const int32_t* idx, int n, int C, void* out, int ldo, int dt, void* stream);
+int ape_hip_gather_rows_i64(const void* x, int ldx, const int64_t* idx, int n, int C, void* out, int ldo, int dt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Greedy NMS (torchvision.ops.nms / batched_nms semantics) -- csrc/select.hip.
@@ -237,16 +244,17 @@ int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int32_t* order, 
 /* ---------------------------------------------------------------------------------------------
  * Language side of BiMultiHeadAttention for one text token (ape/layers/fuse_helper.py:89-116,140):
  * out[h,:] = sum_t softmax_t(S[t,h]) * x[t,:]   with the reference's global-max / clamp sequence.
- * S [T, 8] fp32, x [T, C]; workspace ape_hip_vl_pool_workspace_floats(T, C) fp32.  -- csrc/vlpool.hip
+ * S [T, 8] fp32, x [T, C]; workspace ape_hip_vl_pool_workspace_floats(T, C) fp32; sub [C] or NULL is subtracted from every
+ * pooled row (pooling x - sub: the softmax weights sum to one).  -- csrc/vlpool.hip
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_vl_pool_workspace_floats(int T, int C);
-int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace, float* out,
-                    void* stream);
+int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, int T, int C, float* workspace, const float* sub,
+                    float* out, void* stream);
 /* per-head matrix-vector products of the same language side (fuse_helper.py:70-73 v_proj / values_v_proj applied to one
  * pooled vector per head): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n]; x [H, ldx], W [H, N, D], bias [H, N] or
- * NULL, out [H, ldo], fp32.  -- csrc/vlpool.hip */
+ * NULL, out [H, ldo], fp32; out_bf16 [H, ldob] (may be NULL) receives a bf16 copy.  -- csrc/vlpool.hip */
 int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N, int D,
-                      float alpha, void* stream);
+                      float alpha, void* out_bf16, int ldob, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Softmaxes of the DENSE bi-directional attention (L > 1 text tokens: phrase / expression prompts;
@@ -296,6 +304,26 @@ int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, 
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_box_refine(const float* delta, int ldd, const float* ref, const float* vr4, int L, int Q, float eps, float* new_ref,
                        float* ref_in, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Query initialisation of the two-stage decoder (deformable_transformer_vl.py:412-420 get_proposal_pos_embed, :629-645).
+ * query_init: coords [T,4] fp32 unactivated boxes, topk [Q] int64 selected tokens -> reference [Q,4] = sigmoid(coords[topk]),
+ *   pe [Q, 4P] (f32 | bf16) = the sine embedding (dim_t [P], scale = 2 pi), topk32 [Q] int32 copy of the indices (may be NULL).
+ * query_finish: pos [Q, 2E] = pos_trans(pe), pix [Q, E] = pix_trans(output_memory[topk]) (fp32 GEMM outputs) ->
+ *   query_pos = LN_pos(pos)[:, :E], query = LN_pos(pos)[:, E:] + LN_pix(pix), query_sum = query + query_pos, all [Q, E] in
+ *   out_dt (f32 | bf16), E a multiple of 64, <= 512.  -- csrc/boxes.hip
+ * ------------------------------------------------------------------------------------------- */
+/* Detection records of one image (detector_postprocess deformable_detr_segm_vl.py:857-872; detectron2 Boxes.scale / clip /
+ * nonempty): boxes * frame[0:4] clipped to [0, frame[4:8]], keep = score >= 0 and non-empty; rec [k,8] = (box, score | -1, class,
+ * query, keep) with the KEPT rows first (stable partition), boxes_out [k,4] and order [k] (source row of each output row) alike.
+ * frame [8] fp32 on the device = (sx, sy, sx, sy, width, height, width, height).  -- csrc/boxes.hip */
+int ape_hip_det_records(const float* boxes, const float* scores, const int64_t* classes, const int64_t* query, const float* frame,
+                        int k, float* rec, float* boxes_out, int32_t* order, void* stream);
+int ape_hip_query_init(const float* coords, const int64_t* topk, int T, const float* dim_t, int P, float scale, int Q,
+                       float* reference, void* pe, int ldpe, int pe_dt, int32_t* topk32, void* stream);
+int ape_hip_query_finish(const float* pos, int ldpos, const float* pix, int ldpix, int Q, int E, const float* wpos,
+                         const float* bpos, float eps_pos, const float* wpix, const float* bpix, float eps_pix, void* query_pos,
+                         void* query, void* query_sum, int ldo, int out_dt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-image-size constants of the deformable encoder for an (h, w) image inside the S x S pad, written straight into the

@@ -8,6 +8,8 @@ Math is done in float32 on whatever device the inputs live on; outputs are round
 exactly once, like the kernels.
 """
 
+import math
+
 import torch
 import torch.nn.functional as F
 
@@ -76,9 +78,10 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     return x.to(odt)
 
 
-def head_gemv(x, w, bias=None, alpha=1.0):
+def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):
     out = torch.einsum("hd,hnd->hn", x.float(), w.float()) * alpha
-    return out + bias.float().reshape(out.shape) if bias is not None else out
+    out = out + bias.float().reshape(out.shape) if bias is not None else out
+    return (out, out.to(torch.bfloat16)) if bf16_copy else out
 
 
 def row_stats(x, eps):
@@ -88,11 +91,13 @@ def row_stats(x, eps):
     return rstd, -mean * rstd
 
 
-def gemv(x, w, bias=None, alpha=1.0):
+def gemv(x, w, bias=None, alpha=1.0, *, scale=None, add=None):
     y = (x.float() @ w.float().t()) * alpha
     if bias is not None:
         y = y + bias.float()
-    return y
+    if scale is not None:
+        y = y * scale.float()
+    return y if add is None else (y, add.float() + y)
 
 
 def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None, add=None, out2=None):
@@ -308,11 +313,12 @@ def nms_classes(boxes, order, iou_thr, valid=None):
     return keep.to(boxes.device)
 
 
-def vl_pool(scores, x):
+def vl_pool(scores, x, sub=None):
     w = scores.float()
     w = (w - w.max()).clamp(-50000, 50000)
     wl = (w - w.max(dim=0, keepdim=True)[0]).clamp(-50000, 50000).softmax(dim=0)  # over tokens
-    return wl.t() @ x.float()
+    out = wl.t() @ x.float()
+    return out if sub is None else out - sub.float()[None, :]
 
 
 def segment_softmax(scores, nseg, gmax, out_dtype):
@@ -375,6 +381,33 @@ def box_refine(delta, ref, vr4, eps=1e-3):
         x = ref.clamp(min=0, max=1)
         new_ref = (delta + torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))).sigmoid()
     return new_ref, (new_ref[:, None, :] * vr4[None]).contiguous()
+
+
+def det_records(det_boxes, det_scores, det_classes, det_query, frame):
+    boxes = torch.minimum((det_boxes * frame[:4]).clamp_min(0.0), frame[4:])
+    keep = (det_scores >= 0) & ((boxes[:, 2] - boxes[:, 0]) > 0) & ((boxes[:, 3] - boxes[:, 1]) > 0)
+    score = torch.where(keep, det_scores, torch.full_like(det_scores, -1.0))
+    rec = torch.cat([boxes, score[:, None], det_classes[:, None].float(), det_query[:, None].float(), keep[:, None].float()], 1)
+    order = torch.sort((~keep).to(torch.int8), stable=True)[1]
+    return rec[order].contiguous(), boxes[order].contiguous(), order.to(torch.int32)
+
+
+def query_init(coords_unact, topk, dim_t, out_dtype, scale=2 * math.pi):
+    """deformable_transformer_vl.py:412-420, 629-634 for [T,4] unactivated coords and the selected tokens"""
+    coords = coords_unact[topk.long()]
+    pos = (coords.sigmoid() * scale)[:, :, None] / dim_t
+    pe = torch.stack((pos[:, :, 0::2].sin(), pos[:, :, 1::2].cos()), dim=3).flatten(1)
+    return coords.sigmoid(), pe.to(out_dtype).contiguous(), topk.to(torch.int32)
+
+
+def query_finish(pos, pix, norm_pos, norm_pix, out_dtype):
+    """deformable_transformer_vl.py:635-645: pos_trans_norm, split, + pix_trans_norm"""
+    E = pix.shape[1]
+    pt = F.layer_norm(pos.float(), (2 * E,), norm_pos[0].float(), norm_pos[1].float(), norm_pos[2])
+    px = F.layer_norm(pix.float(), (E,), norm_pix[0].float(), norm_pix[1].float(), norm_pix[2])
+    query_pos = pt[:, :E].to(out_dtype).contiguous()
+    query = (pt[:, E:] + px).to(out_dtype).contiguous()
+    return query_pos, query, (query.float() + query_pos.float()).to(out_dtype)
 
 
 # ---- input pipeline / evaluator wire format: the definitions are the libraries the reference calls (Pillow) and the

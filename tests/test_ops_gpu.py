@@ -566,6 +566,83 @@ def test_box_refine(ops):
         assert relerr(got_ref, want_ref) < 1e-6 and relerr(got_in, want_in) < 1e-6
 
 
+def test_language_side_epilogues(ops):
+    """the element-wise tails of the single-token language side inside the small kernels (no tensor-library launches):
+    gemv scale / add, head_gemv bf16 copy, vl_pool subtract"""
+    x, w, b = rnd(1, 2048, seed=1), rnd(256, 2048, scale=1 / 45, seed=2), rnd(256, seed=3)
+    sc, add = rnd(256, seed=4), rnd(1, 256, seed=5)
+    got, got2 = ops.gemv(x, w, b, alpha=0.7, scale=sc, add=add)
+    want, want2 = ref_ops.gemv(x, w, b, alpha=0.7, scale=sc, add=add)
+    assert relerr(got, want) < 2e-5 and relerr(got2, want2) < 2e-5
+    assert torch.equal(got2, add + got)                                    # out2 is add + the ROUNDED out
+    only = ops.gemv(x, w, b, alpha=0.7, scale=sc)
+    assert torch.equal(only, got)
+    g3, g4 = ops.gemv(x, w, None, alpha=-0.125, add=add)
+    w3, w4 = ref_ops.gemv(x, w, None, alpha=-0.125, add=add)
+    assert relerr(g3, w3) < 2e-5 and relerr(g4, w4) < 2e-5
+    xh, wh = rnd(8, 256, seed=6), rnd(8, 256, 256, scale=1 / 16, seed=7)
+    u, uc = ops.head_gemv(xh, wh, bf16_copy=True)
+    assert uc.dtype == torch.bfloat16 and torch.equal(uc, u.to(torch.bfloat16)) and torch.equal(u, ops.head_gemv(xh, wh))
+    T = 5456
+    S, xv, sub = rnd(T, 8, seed=8) * 3.0, rnd(T, 256, dtype=torch.bfloat16, seed=9), rnd(256, seed=10)
+    e = relerr(ops.vl_pool(S, xv, sub), ref_ops.vl_pool(S, xv, sub))
+    assert e < 2e-5, e
+
+
+def test_gather_rows_int64_indices(ops):
+    x = rnd(5000, 256, dtype=torch.bfloat16, seed=1)
+    idx = torch.randint(0, 5000, (900,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    assert torch.equal(ops.gather_rows(x, idx), x[idx])
+    assert torch.equal(ops.gather_rows(x, idx.to(torch.int32)), x[idx])
+    m = torch.randint(0, 255, (100, 128, 128), generator=torch.Generator().manual_seed(3), dtype=torch.uint8).to(DEV)
+    order = torch.randperm(100, generator=torch.Generator().manual_seed(4)).to(torch.int32).to(DEV)
+    got = ops.gather_rows(m.view(100, -1).view(torch.float32), order).view(torch.uint8).view(m.shape)
+    assert torch.equal(got, m[order.long()])                               # byte rows moved as 16-byte pieces: a pure copy
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_query_init_and_finish(ops, dt):
+    """two-stage query initialisation (deformable_transformer_vl.py:412-420, 629-645) in two launches"""
+    from ape_amd.modeling.ape_deta.geometry import dim_t_table
+    T, Q, E = 21824, 900, 256
+    coords = rnd(T, 4, seed=1) * 3.0
+    topk = torch.randint(0, T, (Q,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    dim_t = dim_t_table(128, 10000, DEV)
+    ref, pe, t32 = ops.query_init(coords, topk, dim_t, dt)
+    wref, wpe, wt32 = ref_ops.query_init(coords, topk, dim_t, dt)
+    assert torch.equal(t32, wt32) and pe.dtype == dt and pe.shape == (Q, 512)
+    assert (ref - wref).abs().max().item() < 1e-6
+    # sin / cos of arguments up to 2 pi: device libm vs the tensor library's, a few ulp; bf16 adds one rounding
+    assert (pe.float() - wpe.float()).abs().max().item() < (1e-5 if dt == torch.float32 else 8e-3)
+    pos, pix = rnd(Q, 2 * E, seed=3) * 2.0 + 0.3, rnd(Q, E, seed=4) * 1.5 - 0.2
+    npos = (rnd(2 * E, seed=5) + 1.0, rnd(2 * E, seed=6), 1e-5)
+    npix = (rnd(E, seed=7) + 1.0, rnd(E, seed=8), 1e-5)
+    got = ops.query_finish(pos, pix, npos, npix, dt)
+    want = ref_ops.query_finish(pos, pix, npos, npix, dt)
+    for g, w, name in zip(got, want, ("query_pos", "query", "query + query_pos")):
+        e = relerr(g, w)
+        print(f"query_finish {name} {dt}: {e:.3e}")
+        assert g.dtype == dt and e < TOL[dt], (name, e)
+    assert torch.equal(got[2], (got[1].float() + got[0].float()).to(dt))   # from the rounded outputs, like the decoder's expression
+
+
+@pytest.mark.parametrize("k", [1, 100, 300, 1000, 2500])
+def test_det_records(ops, k):
+    """boxes to the output frame + clip + keep + kept-first stable partition in one launch vs the tensor-level definition"""
+    g = torch.Generator().manual_seed(k)
+    b = torch.rand(k, 4, generator=g) * 900.0
+    b[:, 2:] = b[:, :2] + torch.rand(k, 2, generator=g) * 300.0 - 20.0          # some empty boxes (x2 <= x1)
+    scores = torch.rand(k, generator=g)
+    scores[torch.rand(k, generator=g) < 0.2] = -1.0                            # empty slots
+    classes = torch.randint(0, 1203, (k,), generator=g)
+    query = torch.randint(0, 900, (k,), generator=g)
+    frame = torch.tensor([0.75, 0.6, 0.75, 0.6, 640.0, 480.0, 640.0, 480.0])
+    args = [t.to(DEV) for t in (b, scores, classes, query, frame)]
+    rec, boxes, order = ops.det_records(*args)
+    wrec, wboxes, worder = ref_ops.det_records(*args)
+    assert torch.equal(order, worder) and torch.equal(rec, wrec) and torch.equal(boxes, wboxes)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_gemm_folded_layernorm(ops, dtype):
     """row_stats + gemm(rownorm=...) == LayerNorm(h) @ W^T + b  (the SwiGLU sub-LN folded into the down projection)"""
