@@ -45,6 +45,10 @@ CASES = {
     # f4: APE-L_A -- the plain (non-VL) model family of scripts/eval_APE-L_A.sh at full size, and a small copy of it
     "L_A_coco80": ("L_A", 0, 2, (1024, 1024), 80, 3),
     "small_A": ("small_A", 1, 4, (416, 512), 9, 5),
+    # config 2 with a REAL photograph (demo/examples/*.jpg): the reference's demo image, decoded, BGR -> RGB, resized by
+    # Pillow exactly as ape/engine/defaults.py:213-222 does (ResizeShortestEdge(1024, 1024): 394 x 700 -> 576 x 1024).  The JPEG
+    # bytes (42 KB) travel inside the fixture; the tests decode them with the same library.
+    "L_D_jpeg": ("L_D_coco", 0, "jpeg:Pisa.jpg", (576, 1024), 80, 3),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }
@@ -58,9 +62,25 @@ FULL = ("pred_logits", "pred_boxes", "topk_proposals", "det_boxes", "det_scores"
         "init_reference", "enc_class")
 
 
+def jpeg_model_input(data, hw):
+    """file bytes -> the model's `image` input as the reference's predictor builds it (defaults.py:213-222): decode, RGB, Pillow
+    bilinear resize of the uint8 image (detectron2 ResizeTransform.apply_image), float32 CHW"""
+    import io
+
+    import numpy as np
+    from PIL import Image
+    rgb = Image.open(io.BytesIO(bytes(data))).convert("RGB")
+    h, w = hw
+    return torch.from_numpy(np.asarray(rgb.resize((w, h), Image.BILINEAR)).astype("float32").transpose(2, 0, 1).copy())
+
+
 def make_inputs(case):
     cfg, wseed, iseed, (h, w), K, tseed = CASES[case][:6]
-    image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
+    if isinstance(iseed, str) and iseed.startswith("jpeg:"):
+        with open(os.path.join("/root/reference/demo/examples", iseed[5:]), "rb") as fh:
+            image = jpeg_model_input(fh.read(), (h, w))
+    else:
+        image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
     text = torch.randn(K, 1024, generator=torch.Generator().manual_seed(tseed))
     return cfg, wseed, image, text
 
@@ -96,6 +116,9 @@ def main():
             with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
                 json.dump(spec, fh)
         gold = {"case": CASES[case], "stages": {}, "full": {}}
+        if isinstance(CASES[case][2], str):
+            with open(os.path.join("/root/reference/demo/examples", CASES[case][2][5:]), "rb") as fh:
+                gold["jpeg"] = torch.frombuffer(bytearray(fh.read()), dtype=torch.uint8).clone()
         big = cfg.startswith("L_D") or cfg in ("Ti", "L_A")
         for k, v in S.items():
             if torch.is_tensor(v):

@@ -20,7 +20,15 @@ def load_golden(case):
 
 def case_inputs(gold):
     cfg, wseed, iseed, (h, w), K, tseed = gold["case"][:6]
-    image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
+    if "jpeg" in gold:                     # a real photograph: the file bytes travel in the fixture (tests/golden/make_golden.py)
+        import io
+
+        import numpy as np
+        from PIL import Image
+        rgb = Image.open(io.BytesIO(gold["jpeg"].numpy().tobytes())).convert("RGB")
+        image = torch.from_numpy(np.asarray(rgb.resize((w, h), Image.BILINEAR)).astype("float32").transpose(2, 0, 1).copy())
+    else:
+        image = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(iseed)).float()
     text = torch.randn(K, 1024, generator=torch.Generator().manual_seed(tseed))
     return cfg, wseed, image, text
 

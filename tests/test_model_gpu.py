@@ -347,7 +347,7 @@ def _ld_mask_sign_mismatch(stages, out, gold):
     return bad / max((~tie).float().sum().item(), 1.0), len(rows)
 
 
-@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80"])
+@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg"])
 def test_L_D_fp32_matches_reference(case):
     """T1 at the benchmarked sizes: fp32 HIP kernels vs the reference run; north_star tolerance 1e-3 on logits / boxes,
     identical argmax masks"""
@@ -433,7 +433,26 @@ import teacher_forced as TF
 R_PATH = ("p2", "memory", "pred_logits", "pred_boxes")
 
 
-@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80"])
+def test_predictor_input_pipeline_on_the_real_photograph():
+    """demo/examples/Pisa.jpg through ape_amd.engine.DefaultPredictor.preprocess (upload of the ORIGINAL BGR bytes + the resize
+    kernel) == the model input the reference's predictor builds on the host (decode, RGB, Pillow resize, float CHW: the image the
+    `L_D_jpeg` fixture was generated from) -- bit exact"""
+    import io
+
+    import numpy as np
+    from PIL import Image
+    from ape_amd.engine import DefaultPredictor
+    gold = U.load_golden("L_D_jpeg")
+    _, _, image, _ = U.case_inputs(gold)
+    rgb = np.asarray(Image.open(io.BytesIO(gold["jpeg"].numpy().tobytes())).convert("RGB"))
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])                                 # what cv2.imread hands the predictor
+    pred = DefaultPredictor(model=torch.nn.Linear(1, 1).to(DEV), short_edge_length=1024, max_size=1024, input_format="RGB")
+    got = pred.preprocess(bgr)
+    assert tuple(got.shape) == tuple(image.shape) == (3, 576, 1024)
+    assert torch.equal(got.cpu(), image)
+
+
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg"])
 def test_L_D_bf16_pipeline(case):
     model, image, text, gold = M.build_model(case, DEV, torch.bfloat16)
     mv = model.model_vision

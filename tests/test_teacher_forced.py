@@ -51,7 +51,7 @@ def test_stage_tap_teacher_forcing_on_the_host_model(fake_ops):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_1536_sseg", "L_A_coco80"])
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_padded", "L_D_1536_sseg", "L_A_coco80", "L_D_jpeg"])
 def test_L_D_bf16_teacher_forced(case):
     """every stage of the bf16 HIP pipeline, fed the fp32 pipeline's input, is inside the tolerance derived from bf16's 8
     significant bits and the number of roundings on its path (teacher_forced.ROUNDINGS) -- at the benchmarked sizes"""
