@@ -64,6 +64,8 @@ SIGNATURES = {
     "ape_hip_gemv_affine": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                     c_float, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "ape_hip_layernorm": (c_int, [POINTER(LayerNormArgs), c_void_p]),
+    "ape_hip_postnorm_residual": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_int, c_int,
+                                          c_int, c_int, c_void_p]),
     "ape_hip_groupnorm_workspace_floats": (c_int, [c_int, c_int]),
     "ape_hip_groupnorm": (c_int, [POINTER(GroupNormArgs), c_void_p]),
     "ape_hip_ms_deform_attn_forward": (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64), c_void_p, c_void_p,

@@ -43,6 +43,9 @@ __device__ __forceinline__ int swz_rows(int row, int c, int chunks_per_row) {
 // for the permuted rows (bank-group check: 16 distinct 16-byte slots per ds_read_b128 lane group).
 __device__ __forceinline__ int kperm_row(int i, int rho) { return 32 * (i >> 1) + 8 * (rho >> 2) + 4 * (i & 1) + (rho & 3); }
 __device__ __forceinline__ int kperm_swz(int row) { return ((row >> 1) & 1) | ((row >> 2) & 6); }
+// head dimension 128 (ViT-e: 112 padded): K rows are 256 bytes = 16 chunks = one full row of LDS banks, so the 16 rows a
+// ds_read_b128 lane group touches (kappa(i, 0..15): bits 0, 1, 3, 4 of the row vary) must land in 16 different chunk columns
+__device__ __forceinline__ int kperm_swz16(int row) { return (((row >> 3) & 3) << 2) | (row & 3); }
 // max over the 4 lanes l, l^16, l^32, l^48 that share a query: two VALU lane swaps (gfx950) instead of two LDS round trips
 __device__ __forceinline__ float quad_rows_max(float v) {
   const unsigned u = __float_as_uint(v);
@@ -57,6 +60,7 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
 template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1>
 __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p) {
+  static_assert(HD == 32 || HD == 64 || (HD == 128 && PERM), "head dimension 32 / 64 / 128 (128: permuted key order only)");
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
   constexpr int DT = HD / 16;       // output d tiles
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
   // nothing for the compiler to spill: the register-staged version kept the prefetched tile in scratch and waited for
   // every global load right after issuing it).  The LDS destination of an instruction is lane-linear (64 x 16 B), so the
   // XOR swizzle of swz_rows() is applied to the per-lane SOURCE chunk instead.
-  constexpr int PER = HD * 8 / 256;  // instructions per wave per operand: 2 (HD=64) or 1 (HD=32)
+  constexpr int PER = HD * 8 / 256;  // instructions per wave per operand: 4 (HD=128), 2 (HD=64) or 1 (HD=32)
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
   // per-lane source positions as 32-bit element offsets from wave-uniform bases (64-bit per-lane pointers cost twice the registers)
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
     const int slot = (wave * PER + i) * 64 + lane;
     {
       const int row = slot / KC, cp = slot % KC;
-      const int c = KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
+      const int c = KC == 16 ? (cp ^ kperm_swz16(row)) : KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
       krow[i] = row;
       kcol[i] = c * 8;
     }
@@ -157,7 +161,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const int krow_ = PERM ? kperm_row(i, frow) : i * 16 + frow;
-        const int koff = (PERM && KC == 8) ? krow_ * 64 + (((ks * 4 + fq) ^ kperm_swz(krow_)) << 3) : swz_rows(krow_, ks * 4 + fq, KC);
+        const int koff = KC == 16 ? krow_ * 128 + (((ks * 4 + fq) ^ kperm_swz16(krow_)) << 3)
+                       : (PERM && KC == 8) ? krow_ * 64 + (((ks * 4 + fq) ^ kperm_swz(krow_)) << 3) : swz_rows(krow_, ks * 4 + fq, KC);
         const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[koff]));
 #pragma unroll
         for (int u = 0; u < QT; ++u) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][i], 0, 0, 0);
@@ -343,7 +348,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
 static int attention_launch(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int B, int N,
                             int bstride, int H, int HD, float scale, int dt, int causal, void* stream) {
   APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
-  APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64), "ape_hip_attention: bad shape (HD must be 32 or 64)");
+  APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64 || HD == 128), "ape_hip_attention: bad shape (HD must be 32, 64 or 128)");
   APE_CHECK_ARG(bstride >= N, "ape_hip_attention: batch stride %d < N %d", bstride, N);
   AttnParams p;
   p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H; p.bstride = bstride;
@@ -364,6 +369,9 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
       APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
       if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true>), grid, dim3(256), 0, s, p);
+    } else if (HD == 128) {           // ViT-e (head width 112 zero-padded to 128 by the packing)
+      if (big) hipLaunchKernelGGL((attn_bf16_kernel<128, 2>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((attn_bf16_kernel<128, 1>), grid, dim3(256), 0, s, p);
     } else if (natural) {
       if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false>), grid, dim3(256), 0, s, p); }
       else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false>), grid, dim3(256), 0, s, p); }
@@ -375,7 +383,8 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
     }
     else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
   } else {
-    if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
+    if (HD == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
+    else if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
   }
   APE_CHECK_LAUNCH("ape_hip_attention");

@@ -390,3 +390,91 @@ extern "C" int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, f
   APE_CHECK_LAUNCH("ape_hip_row_stats");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Post-norm residual step of the EVA-CLIP "postnorm" blocks (ViT-e; ape/modeling/backbone/vit_eva_clip.py:505-523 with
+// postnorm=True):  x <- x + LayerNorm(t)  on the fp32 residual stream, in place, plus the copy of the new stream in the GEMM
+// operand type that the next linear reads (the stream is not normalised in this block flavour, so it stays fp32; the copy saves
+// a cast launch).  t == NULL: only the copy (start of the stack).  One wave per row, the row of t in registers; C % 4 == 0,
+// C <= 2048.
+// ------------------------------------------------------------------------------------------
+template <typename TT, typename TC, int NV4>
+__global__ __launch_bounds__(256) void postnorm_residual_kernel(const TT* __restrict__ t, int ldt, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float eps, float* __restrict__ stream,
+                                                                int lds, TC* __restrict__ copy, int ldc, int M, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* xs = stream + (size_t)row * lds;
+  TC* cp = copy != nullptr ? copy + (size_t)row * ldc : nullptr;
+  if (t == nullptr) {
+    for (int c = lane * 4; c < C; c += 256) {
+      float v[4];
+      ld4<float>(xs + c, v);
+      st4<TC>(cp + c, v);
+    }
+    return;
+  }
+  const TT* tr = t + (size_t)row * ldt;
+  const float invC = 1.f / (float)C;
+  float v[NV4][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) ld4<TT>(tr + c, v[i]);
+    else { v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f; }
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) * invC;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mean; q = fmaf(d, d, q); }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= C) continue;
+    float w4[4], b4[4], x4[4];
+    ld4<float>(w + c, w4);
+    ld4<float>(b + c, b4);
+    ld4<float>(xs + c, x4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x4[r] += (v[i][r] - mean) * rstd * w4[r] + b4[r];
+    st4<float>(xs + c, x4);
+    if (cp != nullptr) st4<TC>(cp + c, x4);
+  }
+}
+
+template <typename TT, typename TC>
+static void launch_postnorm(const void* t, int ldt, const float* w, const float* b, float eps, float* stream, int lds, void* copy, int ldc,
+                            int M, int C, hipStream_t s) {
+  const dim3 grid(ceil_div(M, 4)), block(256);
+  if (C <= 256) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 1>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else if (C <= 512) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 2>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else if (C <= 1024) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 4>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 8>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+}
+
+extern "C" int ape_hip_postnorm_residual(const void* t, int ldt, int t_dt, const float* w, const float* b, float eps, float* stream,
+                                         int lds, void* copy, int ldc, int copy_dt, int M, int C, void* stream_) {
+  APE_CHECK_ARG(stream && M > 0 && C > 0 && C % 4 == 0 && C <= 2048 && lds % 4 == 0, "ape_hip_postnorm_residual: C %% 4 == 0, C <= 2048");
+  APE_CHECK_ARG(t != nullptr || copy != nullptr, "ape_hip_postnorm_residual: nothing to do");
+  APE_CHECK_ARG(t == nullptr || (w && b && ldt % 4 == 0 && ((uintptr_t)t) % 16 == 0), "ape_hip_postnorm_residual: t / w / b");
+  APE_CHECK_ARG(copy == nullptr || (ldc % 4 == 0 && ((uintptr_t)copy) % 8 == 0), "ape_hip_postnorm_residual: copy alignment");
+  APE_CHECK_ARG(((uintptr_t)stream) % 16 == 0, "ape_hip_postnorm_residual: stream alignment");
+  hipStream_t s = (hipStream_t)stream_;
+  const bool tb = t_dt == APE_DT_BF16, cb = copy_dt == APE_DT_BF16;
+  if (tb && cb) launch_postnorm<bf16_t, bf16_t>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  else if (tb) launch_postnorm<bf16_t, float>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  else if (cb) launch_postnorm<float, bf16_t>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  else launch_postnorm<float, float>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  APE_CHECK_LAUNCH("ape_hip_postnorm_residual");
+  return 0;
+}

@@ -61,56 +61,125 @@ class SwiGLU(nn.Module):
         self.w3 = nn.Linear(hidden_features, in_features)
 
 
+class Mlp(nn.Module):
+    """fc1 -> GELU -> (ffn_ln) -> fc2 (vit_eva_clip.py:67-98): the MLP of the non-SwiGLU configurations (ViT-e)"""
+
+    def __init__(self, in_features, hidden_features, norm_layer, subln=False):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.ffn_ln = norm_layer(hidden_features) if subln else nn.Identity()
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+def padded_head_dim(hd):
+    """the flash-attention kernel's head widths: 32 / 64 / 128; narrower heads are zero-padded by the weight packing (zero q / k
+    columns add nothing to the scores, zero v columns produce zero outputs that meet zero columns of the out projection)"""
+    for w in (32, 64, 128):
+        if hd <= w:
+            return w
+    raise ValueError(f"ape_amd ViT: head width {hd} > 128")
+
+
 class Attention(nn.Module):
-    def __init__(self, dim, num_heads, rope, norm_layer):
+    def __init__(self, dim, num_heads, rope, norm_layer, subln=True, qkv_bias=True):
         super().__init__()
         self.num_heads = num_heads
-        self.q_proj = nn.Linear(dim, dim, bias=False)
-        self.k_proj = nn.Linear(dim, dim, bias=False)
-        self.v_proj = nn.Linear(dim, dim, bias=False)
-        self.q_bias = nn.Parameter(torch.zeros(dim))
-        self.v_bias = nn.Parameter(torch.zeros(dim))
-        self.inner_attn_ln = norm_layer(dim)
+        self.subln = subln
+        if subln:
+            self.q_proj = nn.Linear(dim, dim, bias=False)
+            self.k_proj = nn.Linear(dim, dim, bias=False)
+            self.v_proj = nn.Linear(dim, dim, bias=False)
+        else:
+            self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.q_bias = self.v_bias = None
+        self.inner_attn_ln = norm_layer(dim) if subln else nn.Identity()
         self.proj = nn.Linear(dim, dim)
         self.rope = rope
 
+    def qkv_weights(self):
+        """(Wq, Wk, Wv [E, E], q bias, v bias [E] or None) of either parameterisation (vit_eva_clip.py:236-260)"""
+        if self.subln:
+            wq, wk, wv = self.q_proj.weight, self.k_proj.weight, self.v_proj.weight
+        else:
+            E = self.qkv.weight.shape[1]
+            wq, wk, wv = self.qkv.weight[:E], self.qkv.weight[E:2 * E], self.qkv.weight[2 * E:]
+        return wq.detach().float(), wk.detach().float(), wv.detach().float(), self.q_bias, self.v_bias
+
 
 class Block(nn.Module):
-    def __init__(self, dim, num_heads, mlp_ratio, norm_layer, window_size, rope):
+    def __init__(self, dim, num_heads, mlp_ratio, norm_layer, window_size, rope, postnorm=False, subln=True, naiveswiglu=True,
+                 qkv_bias=True):
         super().__init__()
         self.norm1 = norm_layer(dim)
-        self.attn = Attention(dim, num_heads, rope, norm_layer)
+        self.attn = Attention(dim, num_heads, rope, norm_layer, subln=subln, qkv_bias=qkv_bias)
         self.norm2 = norm_layer(dim)
-        self.mlp = SwiGLU(dim, int(dim * mlp_ratio), norm_layer, subln=True)
+        hidden = int(dim * mlp_ratio)
+        self.mlp = SwiGLU(dim, hidden, norm_layer, subln=subln) if naiveswiglu else Mlp(dim, hidden, norm_layer, subln=subln)
         self.window_size = window_size
+        self.postnorm, self.subln, self.naiveswiglu = postnorm, subln, naiveswiglu
         attach_cache(self)
 
     def packed(self, dt):
         def build(dt):
             a, m = self.attn, self.mlp
-            E = a.q_proj.weight.shape[0]
-            hid = m.w1.weight.shape[0]
-            hid_pad = round_up(hid, 64)
-            n12 = 2 * hid_pad          # zero (gate, up) rows beyond 2*hid: the fused SwiGLU epilogue writes exact zeros into the
-            w12 = torch.zeros((n12, E), dtype=torch.float32, device=m.w1.weight.device)   # K padding of the down projection
-            w12[0:2 * hid:2] = m.w1.weight.detach().float()
-            w12[1:2 * hid:2] = m.w2.weight.detach().float()
-            b12 = torch.zeros((n12,), dtype=torch.float32, device=w12.device)
-            b12[0:2 * hid:2] = m.w1.bias.detach().float()
-            b12[1:2 * hid:2] = m.w2.bias.detach().float()
-            return dict(
-                wqk=pack_matrix(torch.cat([a.q_proj.weight, a.k_proj.weight], 0), dt),
-                bqk=torch.cat([a.q_bias.detach().float(), torch.zeros_like(a.q_bias, dtype=torch.float32)]).contiguous(),
-                wv=pack_matrix(a.v_proj.weight, dt), bv=f32(a.v_bias),
-                wproj=pack_matrix(a.proj.weight, dt), bproj=f32(a.proj.bias),
-                w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=hid_pad,
-                w3=pack_matrix(m.w3.weight, dt, kpad=64), b3=f32(m.w3.bias),
-                **self._folded_subln(m, dt),
+            wq, wk, wv, qb, vb = a.qkv_weights()
+            E = wq.shape[1]
+            nh = a.num_heads
+            hd = E // nh
+            hdp = padded_head_dim(hd)
+            dev = wq.device
+
+            def pad_heads(w):                      # [nh * hd, ...] -> [nh * hdp, ...], zero rows behind every head
+                if hdp == hd:
+                    return w
+                out = torch.zeros((nh, hdp) + tuple(w.shape[1:]), dtype=torch.float32, device=dev)
+                out[:, :hd] = w.reshape((nh, hd) + tuple(w.shape[1:]))
+                return out.reshape((nh * hdp,) + tuple(w.shape[1:]))
+
+            zeros = torch.zeros(E, dtype=torch.float32, device=dev)
+            qb = qb.detach().float() if qb is not None else zeros
+            vb = vb.detach().float() if vb is not None else zeros
+            wproj = a.proj.weight.detach().float()
+            if hdp != hd:                          # zero COLUMNS of the out projection where the attention output is padding
+                wproj = pad_heads(wproj.t().contiguous()).t().contiguous()
+            P = dict(
+                hd=hd, hdp=hdp, Ep=nh * hdp,
+                wqk=pack_matrix(torch.cat([pad_heads(wq), pad_heads(wk)], 0), dt),
+                bqk=torch.cat([pad_heads(qb), torch.zeros(nh * hdp, dtype=torch.float32, device=dev)]).contiguous(),
+                wv=pack_matrix(pad_heads(wv), dt), bv=pad_heads(vb).contiguous(),
+                wproj=pack_matrix(wproj, dt), bproj=f32(a.proj.bias),
                 n1=(f32(self.norm1.weight), f32(self.norm1.bias), self.norm1.eps),
-                n2=(f32(self.norm2.weight), f32(self.norm2.bias), self.norm2.eps),
-                nin=(f32(a.inner_attn_ln.weight), f32(a.inner_attn_ln.bias), a.inner_attn_ln.eps),
-                nffn=(f32(m.ffn_ln.weight), f32(m.ffn_ln.bias), m.ffn_ln.eps),
-            )
+                n2=(f32(self.norm2.weight), f32(self.norm2.bias), self.norm2.eps))
+            if self.subln:
+                P["nin"] = (f32(a.inner_attn_ln.weight), f32(a.inner_attn_ln.bias), a.inner_attn_ln.eps)
+                P["nffn"] = (f32(m.ffn_ln.weight), f32(m.ffn_ln.bias), m.ffn_ln.eps)
+            if self.naiveswiglu:
+                hid = m.w1.weight.shape[0]
+                hid_pad = round_up(hid, 64)
+                n12 = 2 * hid_pad          # zero (gate, up) rows beyond 2*hid: the fused SwiGLU epilogue writes exact zeros into the
+                w12 = torch.zeros((n12, E), dtype=torch.float32, device=dev)   # K padding of the down projection
+                w12[0:2 * hid:2] = m.w1.weight.detach().float()
+                w12[1:2 * hid:2] = m.w2.weight.detach().float()
+                b12 = torch.zeros((n12,), dtype=torch.float32, device=dev)
+                b12[0:2 * hid:2] = m.w1.bias.detach().float()
+                b12[1:2 * hid:2] = m.w2.bias.detach().float()
+                P.update(w12=pack_matrix(w12, dt), b12=b12, hid=hid, hid_pad=hid_pad,
+                         w3=pack_matrix(m.w3.weight, dt, kpad=64), b3=f32(m.w3.bias), **self._folded_subln(m, dt))
+            else:
+                hid = m.fc1.weight.shape[0]
+                hid_pad = round_up(hid, 64)
+                w1 = torch.zeros((hid_pad, E), dtype=torch.float32, device=dev)     # zero rows: gelu(0) = 0 exactly in the K padding
+                w1[:hid] = m.fc1.weight.detach().float()
+                b1 = torch.zeros((hid_pad,), dtype=torch.float32, device=dev)
+                b1[:hid] = m.fc1.bias.detach().float()
+                P.update(w1=pack_matrix(w1, dt), b1=b1, hid=hid, hid_pad=hid_pad,
+                         w2=pack_matrix(m.fc2.weight, dt, kpad=64), b2=f32(m.fc2.bias))
+            return P
         return self._pack.get(self, dt, build)
 
     @staticmethod
@@ -126,33 +195,63 @@ class Block(nn.Module):
         return dict(w3f=w3f, c1=w3f.float().sum(dim=1).contiguous(),                 # row sums of the ROUNDED folded weight
                     c2=(w3 @ b + m.w3.bias.detach().float()).contiguous())
 
-    def forward_tokens(self, x, dt, rope, nwin, ntok_win, vt_buf, last=False, images=1):
-        """x [images * N, E] fp32 residual stream (window-major per image). rope = (cos, sin, rows); nwin = windows of ALL
-        images.  Returns the new stream."""
-        P = self.packed(dt)
-        E = x.shape[1]
+    def _attention(self, xn, P, rope, nwin, ntok_win, vt_buf, images):
+        """the attention branch on the normalised (pre-norm) or raw (post-norm) tokens xn [rows, E] -> [rows, Ep]"""
         nh = self.attn.num_heads
-        hd = E // nh
-        xn = ops.layernorm(x, P["n1"][0], P["n1"][1], P["n1"][2], out_dtype=dt)
+        hd, hdp, Ep = P["hd"], P["hdp"], P["Ep"]
         # V^T on a parallel graph branch: two M = 4096 GEMMs fill the chip better together than one after the other
         vjob = ops.fork(lambda: ops.gemm(xn, P["wv"], P["bv"], trans_out=True, out=vt_buf))
-        qk = ops.gemm(xn, P["wqk"], P["bqk"], rope=(rope[0], rope[1], rope[2], hd, 2 * E))
+        if rope is not None:
+            qk = ops.gemm(xn, P["wqk"], P["bqk"], rope=(rope[0], rope[1], rope[2], hd, 2 * Ep))
+        else:
+            qk = ops.gemm(xn, P["wqk"], P["bqk"])
         vt = vjob.join()
         if self.window_size > 0:
-            o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=nwin, n=ntok_win, heads=nh, head_dim=hd, scale=hd ** -0.5)
+            o = ops.attention(qk[:, :Ep], qk[:, Ep:], vt, batch=nwin, n=ntok_win, heads=nh, head_dim=hdp, scale=hd ** -0.5)
         else:
-            o = ops.attention(qk[:, :E], qk[:, E:], vt, batch=images, n=x.shape[0] // images, heads=nh, head_dim=hd, scale=hd ** -0.5)
-        o = ops.layernorm(o, P["nin"][0], P["nin"][1], P["nin"][2], out_dtype=dt)
+            o = ops.attention(qk[:, :Ep], qk[:, Ep:], vt, batch=images, n=xn.shape[0] // images, heads=nh, head_dim=hdp, scale=hd ** -0.5)
+        if self.subln:
+            o = ops.layernorm(o, P["nin"][0], P["nin"][1], P["nin"][2], out_dtype=xn.dtype)
+        return o
+
+    def _mlp(self, xn, P, dt, residual, out_dtype):
+        """the MLP branch: residual + mlp(xn) (residual None: mlp(xn) alone) in out_dtype"""
+        hbuf = torch.empty((xn.shape[0], P["hid_pad"]), dtype=dt, device=xn.device)
+        if self.naiveswiglu:
+            ops.gemm(xn, P["w12"], P["b12"], act=ops.ACT_SWIGLU, out=hbuf)
+            if "w3f" in P:
+                stats = ops.row_stats(hbuf[:, :P["hid"]], P["nffn"][2])
+                return ops.gemm(hbuf, P["w3f"], P["c2"], residual=residual, rownorm=(stats[0], stats[1], P["c1"]), out_dtype=out_dtype)
+            if self.subln:
+                hbuf = ops.layernorm(hbuf[:, :P["hid"]], P["nffn"][0], P["nffn"][1], P["nffn"][2], out_dtype=dt, cpad=P["hid_pad"])
+            return ops.gemm(hbuf, P["w3"], P["b3"], residual=residual, out_dtype=out_dtype)
+        ops.gemm(xn, P["w1"], P["b1"], act=ops.ACT_GELU, out=hbuf)
+        if self.subln:
+            hbuf = ops.layernorm(hbuf[:, :P["hid"]], P["nffn"][0], P["nffn"][1], P["nffn"][2], out_dtype=dt, cpad=P["hid_pad"])
+        return ops.gemm(hbuf, P["w2"], P["b2"], residual=residual, out_dtype=out_dtype)
+
+    def forward_tokens(self, x, dt, rope, nwin, ntok_win, vt_buf, last=False, images=1):
+        """pre-norm block (vit_eva_clip.py:519-523): x [images * N, E] fp32 residual stream (window-major per image).
+        rope = (cos, sin, rows) or None; nwin = windows of ALL images.  Returns the new stream."""
+        P = self.packed(dt)
+        xn = ops.layernorm(x, P["n1"][0], P["n1"][1], P["n1"][2], out_dtype=dt)
+        o = self._attention(xn, P, rope, nwin, ntok_win, vt_buf, images)
         x = ops.gemm(o, P["wproj"], P["bproj"], residual=x, out_dtype=torch.float32)
         xn = ops.layernorm(x, P["n2"][0], P["n2"][1], P["n2"][2], out_dtype=dt)
-        hbuf = torch.empty((x.shape[0], P["hid_pad"]), dtype=dt, device=x.device)
-        ops.gemm(xn, P["w12"], P["b12"], act=ops.ACT_SWIGLU, out=hbuf)
-        if "w3f" in P:
-            stats = ops.row_stats(hbuf[:, :P["hid"]], P["nffn"][2])
-            return ops.gemm(hbuf, P["w3f"], P["c2"], residual=x, rownorm=(stats[0], stats[1], P["c1"]),
-                            out_dtype=dt if last else torch.float32)
-        hn = ops.layernorm(hbuf[:, :P["hid"]], P["nffn"][0], P["nffn"][1], P["nffn"][2], out_dtype=dt, cpad=P["hid_pad"])
-        return ops.gemm(hn, P["w3"], P["b3"], residual=x, out_dtype=dt if last else torch.float32)
+        return self._mlp(xn, P, dt, x, dt if last else torch.float32)
+
+    def forward_tokens_postnorm(self, x32, xb, dt, rope, nwin, ntok_win, vt_buf, images=1):
+        """post-norm block (vit_eva_clip.py:505-517): x += norm1(attn(x)); x += norm2(mlp(x)).  x32: the fp32 residual stream,
+        updated IN PLACE; xb: the same values in the GEMM operand type (x32 itself in fp32 mode).  Returns the new xb."""
+        P = self.packed(dt)
+        cdt = None if dt == torch.float32 else dt
+        o = self._attention(xb, P, rope, nwin, ntok_win, vt_buf, images)
+        t = ops.gemm(o, P["wproj"], P["bproj"], out_dtype=torch.float32)
+        xb = ops.postnorm_residual(x32, t, P["n1"], copy_dtype=cdt)
+        xb = x32 if xb is None else xb
+        t = self._mlp(xb, P, dt, None, torch.float32)
+        xb = ops.postnorm_residual(x32, t, P["n2"], copy_dtype=cdt)
+        return x32 if xb is None else xb
 
 
 def window_major_order(ht, wt, ws):
@@ -189,24 +288,31 @@ class ViT(Backbone):
                  window_size=0, window_block_indexes=(), residual_block_indexes=(), use_act_checkpoint=False,
                  pretrain_img_size=224, pretrain_use_cls_token=True, out_feature="last_feat", xattn=False, frozen_stages=-1):
         super().__init__()
-        # the HIP path implements the EVA-02-CLIP configuration of APE-L_D (vitl_eva02_clip.py:9-48); other
-        # combinations of these switches are reference features outside the hot path
-        assert rope and naiveswiglu and subln and qkv_bias and use_abs_pos and not postnorm and init_values is None, \
-            "ape_amd ViT: only the rope + sub-LN + SwiGLU + pre-norm configuration is implemented"
-        assert len(residual_block_indexes) == 0 and patch_size == 16 and intp_freq
+        # the HIP path implements the EVA-02-CLIP configurations of the APE configs: rope + sub-LN + SwiGLU + pre-norm (ViT-L,
+        # vitl_eva02_clip.py:9-48) and packed-qkv + GELU MLP + post-norm without rope (ViT-e, vite_eva02_clip_1024.py:9-49)
+        assert use_abs_pos and init_values is None, "ape_amd ViT: absolute position embedding, no layer scale (every APE config)"
+        assert len(residual_block_indexes) == 0 and patch_size == 16
+        assert not rope or intp_freq, "ape_amd ViT: rope tables are interpolated to the token grid (intp_freq=True) in the APE configs"
         assert (img_size // patch_size) % window_size == 0, "token grid must be a multiple of the window size"
+        assert embed_dim <= 2048 or not postnorm, "ape_amd ViT: the post-norm residual kernel holds rows of <= 2048 channels"
         self.pretrain_use_cls_token = pretrain_use_cls_token
         self.img_size, self.patch_size, self.embed_dim, self.window_size = img_size, patch_size, embed_dim, window_size
+        self.postnorm = postnorm
         self.patch_embed = PatchEmbed(in_chans=in_chans, embed_dim=embed_dim)
         num_patches = (pretrain_img_size // patch_size) ** 2
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + (1 if pretrain_use_cls_token else 0), embed_dim))
         half_head_dim = embed_dim // num_heads // 2
         hw = img_size // patch_size
-        self.rope_win = VisionRotaryEmbeddingFast(half_head_dim, pt_seq_len=pt_hw_seq_len, ft_seq_len=window_size)
-        self.rope_glb = VisionRotaryEmbeddingFast(half_head_dim, pt_seq_len=pt_hw_seq_len, ft_seq_len=hw)
+        if rope:
+            assert padded_head_dim(2 * half_head_dim) == 2 * half_head_dim, "ape_amd ViT: rope needs a head width of 32 / 64 / 128"
+            self.rope_win = VisionRotaryEmbeddingFast(half_head_dim, pt_seq_len=pt_hw_seq_len, ft_seq_len=window_size)
+            self.rope_glb = VisionRotaryEmbeddingFast(half_head_dim, pt_seq_len=pt_hw_seq_len, ft_seq_len=hw)
+        else:
+            self.rope_win = self.rope_glb = None
         self.blocks = nn.ModuleList([
             Block(embed_dim, num_heads, mlp_ratio, norm_layer, window_size if i in window_block_indexes else 0,
-                  self.rope_win if i in window_block_indexes else self.rope_glb) for i in range(depth)])
+                  self.rope_win if i in window_block_indexes else self.rope_glb, postnorm=postnorm, subln=subln,
+                  naiveswiglu=naiveswiglu, qkv_bias=qkv_bias) for i in range(depth)])
         self._out_feature_channels = {out_feature: embed_dim}
         self._out_feature_strides = {out_feature: patch_size}
         self._out_features = [out_feature]
@@ -236,8 +342,9 @@ class ViT(Backbone):
             w = self.patch_embed.proj.weight
             return dict(
                 hw=hw, t2r=t2r, r2t=r2t, pos=pos, wpe=pack_matrix(w.reshape(w.shape[0], -1), dt), bpe=f32(self.patch_embed.proj.bias),
-                rope_win=(f32(self.rope_win.freqs_cos), f32(self.rope_win.freqs_sin), self.window_size ** 2),
-                rope_glb=(f32(self.rope_glb.freqs_cos)[t2r.long()].contiguous(), f32(self.rope_glb.freqs_sin)[t2r.long()].contiguous(), hw * hw),
+                rope_win=None if self.rope_win is None else (f32(self.rope_win.freqs_cos), f32(self.rope_win.freqs_sin), self.window_size ** 2),
+                rope_glb=None if self.rope_glb is None else (f32(self.rope_glb.freqs_cos)[t2r.long()].contiguous(),
+                                                             f32(self.rope_glb.freqs_sin)[t2r.long()].contiguous(), hw * hw),
             )
         return self._pack.get(self, dt, build)
 
@@ -265,7 +372,17 @@ class ViT(Backbone):
             pos = P[("pos", B)]
         x = tap(stages, "vit_embed", ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32))
         nwin = (hw // self.window_size) ** 2 * B
-        vt_buf = torch.zeros((self.embed_dim, round_up(B * n, 64)), dtype=dt, device=x.device)
+        Ep = self.blocks[0].packed(dt)["Ep"]
+        vt_buf = torch.zeros((Ep, round_up(B * n, 64)), dtype=dt, device=x.device)
+        if self.postnorm:
+            x32 = x
+            xb = x32 if dt == torch.float32 else ops.postnorm_residual(x32, None, None, copy_dtype=dt)
+            for i, blk in enumerate(self.blocks):
+                rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
+                xb = blk.forward_tokens_postnorm(x32, xb, dt, rope, nwin, self.window_size ** 2, vt_buf, images=B)
+                if stages is not None:
+                    stages[f"vit_blk{i}"] = x32.clone()          # the stream is updated in place: record a copy
+            return xb
         for i, blk in enumerate(self.blocks):
             rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
             x = blk.forward_tokens(x, dt, rope, nwin, self.window_size ** 2, vt_buf, last=(i == len(self.blocks) - 1), images=B)

@@ -41,6 +41,13 @@ SIZES = {
                     dec_layers=2, num_queries=300, topk_eval=50, backbone="eva02", subln=True, global_every=3, vl=False),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500),
+    # APE on ViT-e (ape_deta_vite_eva02_clip_vlf_lsj1024_cp_16x4_1080k_mdl_fsdp.py:24,65-66; vite_eva02_clip_1024.py:9-49): 64
+    # post-norm blocks of width 1792 = 16 heads x 112 (zero-padded to the attention kernel's 128), packed qkv, GELU MLP, no rope,
+    # every fourth block global, 9 + 9 DETA layers; small_E keeps the head width and a layer count other than 6
+    "E_D": dict(img_size=1024, embed_dim=1792, depth=64, num_heads=16, window_size=32, pretrain_img_size=224, enc_layers=9,
+                dec_layers=9, num_queries=900, topk_eval=300, backbone="clip_e", global_every=4),
+    "small_E": dict(img_size=512, embed_dim=224, depth=4, num_heads=2, window_size=16, pretrain_img_size=224, enc_layers=3,
+                    dec_layers=3, num_queries=300, topk_eval=50, backbone="clip_e", global_every=4),
 }
 
 
@@ -78,6 +85,13 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
                             window_block_indexes=[i for i in range(c.depth) if i % getattr(c, "global_every", 3) != getattr(c, "global_every", 3) - 1],
                             residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
                             subln=getattr(c, "subln", False), swiglu=not getattr(c, "subln", False), naiveswiglu=getattr(c, "subln", False))
+    elif getattr(c, "backbone", "eva_clip") == "clip_e":      # ViT-e: configs/common/backbone/vite_eva02_clip_1024.py:9-49
+        ge = getattr(c, "global_every", 4)
+        net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.4,
+                  window_size=c.window_size, mlp_ratio=8.571428571428571, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                  window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
+                  out_feature="last_feat", use_act_checkpoint=True, xattn=True, pretrain_img_size=c.pretrain_img_size,
+                  pretrain_use_cls_token=True, postnorm=True)
     else:
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads,
                   drop_path_rate=0.4, window_size=c.window_size, mlp_ratio=4 * 2 / 3, qkv_bias=True,

@@ -261,6 +261,28 @@ def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None
     return (out, out2) if add is not None else out
 
 
+def postnorm_residual(stream, t, norm, copy_dtype=None):
+    """Post-norm residual step (vit_eva_clip.py:505-523, postnorm=True): stream += LayerNorm(t) IN PLACE (stream fp32 [M, C]);
+    returns the new stream in `copy_dtype` (None: no copy).  t None: only the copy.  norm = (weight, bias, eps)."""
+    _dev(stream, t)
+    _rowmajor(stream, "stream")
+    if stream.dtype != torch.float32:
+        raise TypeError("ape_amd.ops.postnorm_residual: the residual stream is float32")
+    M, C = stream.shape
+    copy = torch.empty((M, C), dtype=copy_dtype, device=stream.device) if copy_dtype is not None else None
+    w = b = None
+    eps = 0.0
+    if t is not None:
+        _rowmajor(t, "t")
+        if tuple(t.shape) != (M, C):
+            raise ValueError("ape_amd.ops.postnorm_residual: t must match the stream")
+        w, b, eps = _f32vec(norm[0], "w"), _f32vec(norm[1], "b"), float(norm[2])
+    rc = _lib.load().ape_hip_postnorm_residual(_p(t), _ld(t) if t is not None else 0, _dt(t) if t is not None else 0, _p(w), _p(b), eps,
+                                               _p(stream), _ld(stream), _p(copy), C, _dt(copy) if copy is not None else 0, M, C, _stream())
+    _lib.check(rc, "ape_hip_postnorm_residual")
+    return copy
+
+
 def groupnorm(x, w, b, groups, eps, *, act=ACT_NONE, add=None, out=None, out_dtype=None):
     """GroupNorm over a token-major map x[HW, C]: y = act(GN(x) * w + b + add)."""
     _dev(x, w, b, add, out)

@@ -126,6 +126,12 @@ typedef struct ApeLayerNormArgs {
 } ApeLayerNormArgs;
 int ape_hip_layernorm(const ApeLayerNormArgs* args, void* stream);
 
+/* Post-norm residual step (ape/modeling/backbone/vit_eva_clip.py:505-523 with postnorm=True, the ViT-e blocks):
+ * stream[m,:] += LayerNorm(t[m,:]) * w + b on the fp32 residual stream [M, C] IN PLACE, and (copy != NULL) the new stream in
+ * copy_dt (f32 | bf16) for the next linear.  t == NULL: only the copy.  C % 4 == 0, C <= 2048.  -- csrc/norm.hip */
+int ape_hip_postnorm_residual(const void* t, int ldt, int t_dt, const float* w, const float* b, float eps, float* stream, int lds,
+                              void* copy, int ldc, int copy_dt, int M, int C, void* hip_stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm(G) on a token-major map x[HW, C] (NHWC): y = act(GN(x)*w + b + add)

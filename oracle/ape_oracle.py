@@ -229,6 +229,40 @@ class ApeOracle:
         hidden = F.silu(F.linear(h, w12[:hid], b12[:hid])) * F.linear(h, w12[hid:], b12[hid:])
         return x + self.lin(hidden, pre + "mlp.w3")
 
+    # --------------------------------------------------------------------------------------------
+    # ViT-e (configs/common/backbone/vite_eva02_clip_1024.py:9-49: the SAME classes of vit_eva_clip.py with subln=False,
+    # naiveswiglu=False, rope=False, postnorm=True): packed qkv with q_bias / v_bias (Attention :250-262), no rotary embedding,
+    # Mlp fc1 -> GELU -> fc2 (:67-98), and the post-norm residual order of Block :505-517:
+    #     x = x + norm1(attn(x));  x = x + norm2(mlp(x))
+    # --------------------------------------------------------------------------------------------
+    def vit_attention_packed(self, x, i):
+        pre = f"backbone.net.blocks.{i}.attn."
+        B, H, W, C = x.shape
+        N = H * W
+        x = x.reshape(B, N, C)
+        nh = self.num_heads_vit
+        q_bias, v_bias = self.p(pre + "q_bias"), self.p(pre + "v_bias")
+        qkv = F.linear(x, self.p(pre + "qkv.weight"), torch.cat((q_bias, torch.zeros_like(v_bias), v_bias)))
+        qkv = qkv.reshape(B, N, 3, nh, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        att = ((q * q.shape[-1] ** -0.5) @ k.transpose(-2, -1)).softmax(dim=-1)          # == scaled_dot_product_attention (:264-266)
+        o = (att @ v).permute(0, 2, 1, 3).reshape(B, N, -1)
+        return self.lin(o, pre + "proj").view(B, H, W, C)
+
+    def vit_block_postnorm(self, x, i):
+        pre = f"backbone.net.blocks.{i}."
+        shortcut = x
+        if i in self.win_blocks:
+            H, W = x.shape[1], x.shape[2]
+            xw = window_partition(x, self.ws)
+            xw = self.vit_attention_packed(xw, i)
+            x = window_unpartition(xw, self.ws, H, W)
+        else:
+            x = self.vit_attention_packed(x, i)
+        x = shortcut + self.ln(x, pre + "norm1", 1e-6)
+        h = self.lin(F.gelu(self.lin(x, pre + "mlp.fc1")), pre + "mlp.fc2")
+        return x + self.ln(h, pre + "norm2", 1e-6)
+
     def abs_pos(self, hw):
         """get_abs_pos (utils_eva02.py:158-187): drop cls, bicubic resize to the token grid"""
         pos = self.p("backbone.net.pos_embed")[:, 1:]
@@ -249,7 +283,8 @@ class ApeOracle:
         import time
         for i in range(self.depth):
             t0 = time.perf_counter()
-            x = self.vit_block_eva02(x, i) if self.cfg.get("backbone") == "eva02" else self.vit_block(x, i)
+            kind = self.cfg.get("backbone")
+            x = self.vit_block_eva02(x, i) if kind == "eva02" else self.vit_block_postnorm(x, i) if kind == "clip_e" else self.vit_block(x, i)
             self._tick("vit_win_block" if i in self.win_blocks else "vit_glb_block", t0)
             self.stages[f"vit_block{i}"] = x
         return x.permute(0, 3, 1, 2)

@@ -31,6 +31,14 @@ CONFIGS = {
                 enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300, backbone="eva02", subln=True, global_every=6, vl=False),
     "small_A": dict(img_size=512, embed_dim=256, depth=6, num_heads=4, window_size=16, pretrain_img_size=224,
                     enc_layers=2, dec_layers=2, num_queries=300, topk_eval=50, backbone="eva02", subln=True, global_every=3, vl=False),
+    # APE with the ViT-e backbone (configs/.../ape_deta_vite_eva02_clip_vlf_lsj1024_cp_16x4_1080k_mdl_fsdp.py:24,65-66 +
+    # configs/common/backbone/vite_eva02_clip_1024.py:9-49): EVA-02-CLIP ViT-e -- 64 post-norm blocks of width 1792 (16 heads of
+    # 112), packed qkv, GELU MLP (ratio 8.5714), no rope, every fourth block global -- in front of a 9 + 9 layer DETA; and a small
+    # copy that keeps the head width of 112 and a layer count other than 6
+    "E_D": dict(img_size=1024, embed_dim=1792, depth=64, num_heads=16, window_size=32, pretrain_img_size=224,
+                enc_layers=9, dec_layers=9, num_queries=900, topk_eval=300, backbone="clip_e", global_every=4),
+    "small_E": dict(img_size=512, embed_dim=224, depth=4, num_heads=2, window_size=16, pretrain_img_size=224,
+                    enc_layers=3, dec_layers=3, num_queries=300, topk_eval=50, backbone="clip_e", global_every=4),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500, spec="L_D"),
 }

@@ -122,6 +122,12 @@ def layernorm(x, w, b, eps, *, out=None, out_dtype=None, act=ACT_NONE, cpad=None
     return out, out2
 
 
+def postnorm_residual(stream, t, norm, copy_dtype=None):
+    if t is not None:
+        stream += F.layer_norm(t.float(), (t.shape[1],), norm[0].float(), norm[1].float(), norm[2])
+    return stream.to(copy_dtype) if copy_dtype is not None else None
+
+
 def groupnorm(x, w, b, groups, eps, *, act=ACT_NONE, add=None, out=None, out_dtype=None):
     HW, C = x.shape
     y = F.group_norm(x.float().t().reshape(1, C, HW), groups, w.float(), b.float(), eps).reshape(C, HW).t()

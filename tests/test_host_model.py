@@ -269,6 +269,52 @@ def test_eva02_subln_backbone_matches_reference_golden(fake_ops):
     assert e < 1e-5
 
 
+def _vite_case(device, dtype):
+    """the ViT-e configuration of vit_eva_clip.ViT (post-norm, packed qkv, GELU MLP, no rope, head width 112) at reduced size +
+    the reference run's outputs (tests/golden/make_vite_golden.py)"""
+    import os
+    from functools import partial
+    import torch.nn as nn
+    from ape_amd.modeling.backbone import vit_eva_clip
+    from oracle import weights
+    gold = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vite_small.pt"), weights_only=False)
+    net = vit_eva_clip.ViT(norm_layer=partial(nn.LayerNorm, eps=1e-6), drop_path_rate=0.0, **gold["cfg"])
+    own = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert own == dict((k, v) for k, v in gold["spec"]), sorted(set(own) ^ set(dict(gold["spec"])))[:6]      # checkpoint-key contract
+    net.load_state_dict(weights.make_state_dict(gold["spec"], gold["wseed"]), strict=False)
+    net.compute_dtype = dtype
+    image = torch.randint(0, 256, (3, 256, 256), generator=torch.Generator().manual_seed(gold["iseed"])).float()
+    return net.to(device), image.to(device), gold
+
+
+def test_vite_backbone_matches_reference_golden(fake_ops):
+    """the ViT-e flavour of the EVA-02-CLIP ViT (vite_eva02_clip_1024.py:9-49) vs the reference's own ViT, fp32: the
+    host composition (head width 112 zero-padded to the attention kernel's 128, post-norm residual step, window-major token
+    order) and the oracle's restatement of the same blocks, per block and at the output"""
+    from oracle.ape_oracle import ApeOracle
+    net, image, gold = _vite_case("cpu", torch.float32)
+    stages = {}
+    feat = net.forward_tokens(image, (120.0, 120.0, 120.0), (60.0, 60.0, 60.0), stages=stages)     # [256, 224] window-major order
+    r2t = net.packed(torch.float32)["r2t"].long()
+    ref = gold["last_feat"].reshape(224, -1).t()
+    e = U.relerr(feat[r2t], ref)
+    for i, want in gold["blocks"].items():
+        e = max(e, U.relerr(stages[f"vit_blk{i}"][r2t], want.reshape(-1, 224)))
+    print(f"ViT-e (post-norm / packed qkv / GELU MLP) backbone vs reference run: {e:.2e}")
+    assert e < 1e-5
+    # the oracle's restatement of the same blocks
+    cfg = dict(num_heads=2, depth=4, window_size=8, global_every=4, num_queries=1, enc_layers=0, dec_layers=0, topk_eval=1, img_size=256,
+               backbone="clip_e")
+    from oracle import weights
+    sd = {"backbone.net." + k: v for k, v in weights.make_state_dict(gold["spec"], gold["wseed"]).items()}
+    orc = ApeOracle(cfg, sd, prefix="")
+    x = ((image - 120.0) / 60.0)[None]
+    got = orc.vit(x)[0]
+    eo = U.relerr(got, gold["last_feat"])
+    print(f"oracle ViT-e blocks vs reference run: {eo:.2e}")
+    assert eo < 1e-5
+
+
 def test_fp16_model_runs_through_the_module_edge(fake_ops):
     """the reference evaluates with model.to(torch.float16) (tools/train_net.py:642): parameters and inputs arrive as fp16,
     the HIP path stores bf16 / computes fp32 behind an explicit cast at the module edge, results come back like the
@@ -328,6 +374,41 @@ def test_plain_family_state_dict_contract_and_host_pipeline(fake_ops):
     res = model([{"image": image, "height": image.shape[1], "width": image.shape[2], "text_features": text}])[0]["instances"]
     gi = gold["instances"]
     assert U.match_detections(res.pred_boxes, res.scores, res.pred_classes, gi["pred_boxes"], gi["scores"], gi["pred_classes"]) >= 0.97
+
+
+def test_vite_model_state_dict_contract_and_host_pipeline(fake_ops):
+    """APE on ViT-e (ape_deta_vite_eva02_clip_vlf_lsj1024_cp_16x4_1080k_mdl_fsdp.py): state-dict names / shapes of the
+    full-size model (64 blocks of width 1792, 9 + 9 layers) follow the reference's parameterisation; the host composition at
+    reduced size (head width 112, 3 + 3 layers) vs the oracle and the reference-generated fixture"""
+    from ape_amd.modeling.build import build_ape
+
+    with torch.device("meta"):
+        big = build_ape("E_D")
+    sd = big.state_dict()
+    assert sd["model_vision.backbone.net.blocks.63.attn.qkv.weight"].shape == (3 * 1792, 1792)
+    assert sd["model_vision.backbone.net.blocks.0.mlp.fc1.weight"].shape == (15360, 1792)
+    assert any(k.startswith("model_vision.transformer.decoder.layers.8.") for k in sd) and "model_vision.transformer.encoder.vl_layers.8.b_attn.gamma_v" in sd
+    assert not any(k.startswith(("model_vision.transformer.decoder.layers.9.", "model_vision.transformer.encoder.layers.9.")) for k in sd)
+    assert not any("rope" in k or "q_proj" in k or "inner_attn_ln" in k for k in sd)
+    model, orc, image, text, gold = M.build_pair("small_E")
+    own = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert own == {k: list(v) for k, v in U.load_spec("small_E")}                        # == the reference model's state_dict()
+    mv = model.model_vision
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    for k in ("p2", "p4", "p6", "enc_input", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact"):
+        b = M.token_major(k, orc.stages[k])
+        assert U.relerr(stages[k].reshape(b.shape), b) < 2e-4, k
+    assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance, vs the reference run
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
 
 
 def test_graph_retirement_is_bounded(monkeypatch):

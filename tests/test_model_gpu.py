@@ -26,7 +26,7 @@ def _run(case, dtype):
     return model, orc, image.cuda(), text.cuda(), gold, image, text
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E"])
 def test_fp32_pipeline_matches_oracle_and_reference(case):
     """T1: every HIP kernel in its fp32 instantiation; tolerance = north_star's 1e-3 on logits / boxes"""
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.float32)
@@ -70,7 +70,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
     assert mm < 2e-3
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A"])
+@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E"])
 def test_bf16_pipeline(case):
     """bf16 storage + MFMA, fp32 accumulate on the small models (all prompt modes): (a) every stage, fed the fp32 pipeline's
     input (teacher forcing), is inside the tolerance derived from bf16's 8 significant bits (tests/teacher_forced.py); (b) the
@@ -236,6 +236,20 @@ def test_eva02_subln_backbone_on_gpu():
         feat = net.forward_tokens(image, (120.0, 120.0, 120.0), (60.0, 60.0, 60.0))
         e = U.relerr(feat.float().cpu(), gold["last_feat"].reshape(128, -1).t())
         print(f"[eva02 sub-LN backbone {dt}] last_feat vs reference run: {e:.2e}")
+        assert e < tol
+
+
+def test_vite_backbone_on_gpu():
+    """the ViT-e configuration (post-norm, packed qkv, GELU MLP, head width 112 -> the 128-wide flash-attention kernel) on the HIP
+    kernels vs the reference run: fp32 kernels <= 1e-3 (north_star's tolerance), bf16 reported and bounded"""
+    from test_host_model import _vite_case
+
+    for dt, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        net, image, gold = _vite_case("cuda", dt)
+        feat = net.forward_tokens(image, (120.0, 120.0, 120.0), (60.0, 60.0, 60.0))
+        r2t = net.packed(dt)["r2t"].long()
+        e = U.relerr(feat[r2t].float().cpu(), gold["last_feat"].reshape(224, -1).t())
+        print(f"[ViT-e backbone {dt}] last_feat vs reference run: {e:.2e}")
         assert e < tol
 
 

@@ -346,7 +346,8 @@ def poisoned_vt(E, batch, stride, n, dtype, seed):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("B,N,H,HD", [(4, 1024, 16, 64), (1, 4096, 16, 64), (1, 900, 8, 32), (2, 200, 3, 64), (1, 77, 2, 32)])
+@pytest.mark.parametrize("B,N,H,HD", [(4, 1024, 16, 64), (1, 4096, 16, 64), (1, 900, 8, 32), (2, 200, 3, 64), (1, 77, 2, 32),
+                                      (1, 4096, 16, 128), (4, 1024, 16, 128), (3, 70, 2, 128)])     # 128: ViT-e (112 zero-padded)
 def test_attention(ops, dtype, B, N, H, HD):
     if dtype == torch.float32 and N > 2048:
         pytest.skip("f32 validation kernel: keep the case small")
@@ -587,6 +588,27 @@ def test_language_side_epilogues(ops):
     S, xv, sub = rnd(T, 8, seed=8) * 3.0, rnd(T, 256, dtype=torch.bfloat16, seed=9), rnd(256, seed=10)
     e = relerr(ops.vl_pool(S, xv, sub), ref_ops.vl_pool(S, xv, sub))
     assert e < 2e-5, e
+
+
+@pytest.mark.parametrize("C", [224, 1792, 2048])
+@pytest.mark.parametrize("tdt,cdt", [(torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16), (torch.float32, None)])
+def test_postnorm_residual(ops, C, tdt, cdt):
+    """x <- x + LayerNorm(t) on the fp32 stream in place + the copy in the GEMM operand type (ViT-e post-norm blocks)"""
+    M = 1037
+    x = rnd(M, C, seed=1) * 3.0
+    t = (rnd(M, C, seed=2) * 2.0 + 0.4).to(tdt)
+    norm = (rnd(C, seed=3) + 1.0, rnd(C, seed=4), 1e-6)
+    want = x.clone()
+    wcopy = ref_ops.postnorm_residual(want, t, norm, copy_dtype=cdt)
+    got = x.clone()
+    copy = ops.postnorm_residual(got, t, norm, copy_dtype=cdt)
+    assert relerr(got, want) < 2e-5
+    if cdt is None:
+        assert copy is None
+    else:
+        assert copy.dtype == cdt and torch.equal(copy, got.to(cdt))
+    only = ops.postnorm_residual(got, None, None, copy_dtype=torch.bfloat16)      # t = None: only the copy
+    assert torch.equal(only, got.to(torch.bfloat16))
 
 
 def test_gather_rows_int64_indices(ops):

@@ -15,7 +15,8 @@ FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order
 
 # small_A: the plain (non-VL) family of APE-L_A/B/C -- DeformableDETRSegm on DeformableDetrTransformer, no neck, no fusion, no
 # ambiguous heads, the EVA-02 MIM ViT with sub-LN (fixture produced by the reference's deformable_detr_segm.py / deformable_transformer.py)
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A"])
+# small_E: APE on the ViT-e backbone (post-norm blocks, packed qkv, GELU MLP, head width 112) with 3 + 3 layers
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
