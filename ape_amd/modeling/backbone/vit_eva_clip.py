@@ -375,13 +375,20 @@ class ViT(Backbone):
         Ep = self.blocks[0].packed(dt)["Ep"]
         vt_buf = torch.zeros((Ep, round_up(B * n, 64)), dtype=dt, device=x.device)
         if self.postnorm:
-            x32 = x
-            xb = x32 if dt == torch.float32 else ops.postnorm_residual(x32, None, None, copy_dtype=dt)
+            # the fp32 stream is updated IN PLACE by the post-norm residual kernel: with taps, work on a private copy (a forced
+            # tensor belongs to the teacher) and record copies
+            x32 = x.clone() if stages is not None else x
+            cdt = None if dt == torch.float32 else dt
+            xb = x32 if cdt is None else ops.postnorm_residual(x32, None, None, copy_dtype=cdt)
             for i, blk in enumerate(self.blocks):
                 rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
                 xb = blk.forward_tokens_postnorm(x32, xb, dt, rope, nwin, self.window_size ** 2, vt_buf, images=B)
                 if stages is not None:
-                    stages[f"vit_blk{i}"] = x32.clone()          # the stream is updated in place: record a copy
+                    rec = x32.clone()
+                    forced = tap(stages, f"vit_blk{i}", rec)
+                    if forced is not rec:                            # teacher forcing: the next block starts from the teacher's stream
+                        x32 = forced.float().clone()
+                        xb = x32 if cdt is None else ops.postnorm_residual(x32, None, None, copy_dtype=cdt)
             return xb
         for i, blk in enumerate(self.blocks):
             rope = P["rope_win"] if blk.window_size > 0 else P["rope_glb"]
