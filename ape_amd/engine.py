@@ -82,6 +82,14 @@ class DefaultPredictor:
         raw = self._upload(original_image)
         return ops.resize_bilinear_u8(raw, newh, neww, float_chw=True, flip=self.input_format == "RGB")
 
+    def preprocess_mask(self, mask_prompt, newh, neww):
+        """(:226-228) the prompt mask goes through the SAME transform as the image: ResizeTransform.apply_image on the uint8 mask
+        = Pillow's bilinear resize of a single-channel image -- here the resize kernel on three copies of the channel.
+        uint8 [H, W] (host) -> float32 [newh, neww] on the device"""
+        from . import ops
+        m = np.ascontiguousarray(np.repeat(np.asarray(mask_prompt, dtype=np.uint8)[:, :, None], 3, axis=2))
+        return ops.resize_bilinear_u8(self._upload(m), newh, neww, float_chw=True)[0].contiguous()
+
     @torch.no_grad()
     def __call__(self, original_image, text_prompt=None, mask_prompt=None):
         """original_image: np.ndarray [H, W, 3] uint8 in BGR order (cv2.imread) -> predictions dict of the model"""
@@ -91,5 +99,5 @@ class DefaultPredictor:
             inputs["prompt"] = "text"
             inputs["text_prompt"] = text_prompt
         if mask_prompt is not None:
-            raise NotImplementedError("ape_amd DefaultPredictor: mask prompts are outside the inference hot path")
+            inputs["mask_prompt"] = self.preprocess_mask(mask_prompt, *inputs["image"].shape[-2:])
         return self.model([inputs])[0]

@@ -16,6 +16,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import ops
 from ...layers import VisionLanguageAlign
@@ -323,8 +324,23 @@ class DeformableDETRSegmVL(nn.Module):
         return val
 
     # ------------------------------------------------------------------ the hot path, one image
+    def mask_prompt_tokens(self, mask_prompt, geo):
+        """deformable_detr_segm_vl.py:394-414: the [h, w] prompt mask, zero-padded into the square canvas (all-255 when empty),
+        resampled bilinearly to every feature level and thresholded at non-zero -> bool [T] over the flattened levels"""
+        S = self.backbone.padding_constraints.get("square_size", 0)
+        m = mask_prompt.to(dtype=torch.float32)
+        h, w = m.shape[-2:]
+        side = max(S, h, w) if S > 0 else None
+        if side is not None:
+            m = F.pad(m, (0, side - w, 0, side - h))
+        if float(m.sum()) == 0:
+            m = torch.full_like(m, 255.0)
+        flat = [F.interpolate(m[None, None], size=(int(H), int(W)), mode="bilinear")[0, 0].to(torch.bool).reshape(-1) for H, W in geo.shapes]
+        return torch.cat(flat)
+
     def forward_single(self, image, text_feats, forced_topk=None, stages=None, with_masks=True, prompt="name", instance=True,
-                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None, geo=None, encoder_done=None):
+                       semantic=None, detector_columns=None, panoptic=False, vit_feat=None, geo=None, encoder_done=None,
+                       mask_prompt=None):
         """image [3,h,w] fp32 0..255 (device), text_feats [K, D_l] -> dict of device tensors (fixed shapes).
         encoder_done: optional torch.cuda.Event recorded on the current stream as soon as the encoder memory exists (the runtime
         orders the next step's ViT behind it, runtime.GraphedForward late_vit).
@@ -333,7 +349,8 @@ class DeformableDETRSegmVL(nn.Module):
         vit_feat: this image's rows of a batched ViT pass (backbone.net.forward_tokens on a list of images);
         geo: a geometry.StaticGeometry loaded with the constants of the REAL image size while `image` is the full square canvas
         (pixels outside the image = the per-channel mean, i.e. exact zeros after normalisation) -- the size-agnostic form a
-        captured graph needs (runtime.GraphedForward(any_size=True)); instance branch only."""
+        captured graph needs (runtime.GraphedForward(any_size=True)); instance branch only.
+        mask_prompt: [h, w] mask (non-zero = prompted region, :394-414): only encoder tokens inside it become proposals."""
         dt = self.compute_dtype
         P = self.packed(dt)
         h, w = image.shape[-2:]
@@ -387,7 +404,8 @@ class DeformableDETRSegmVL(nn.Module):
             if want_masks or semantic is not None or panoptic:
                 mask_job.append(ops.fork(lambda: mask_features(memory)))
 
-        tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages, after_encoder=after_encoder)
+        tr = self.transformer.forward_tokens(src, geo, l0, dt, forced_topk, stages, after_encoder=after_encoder,
+                                             mask_prompt=None if mask_prompt is None else self.mask_prompt_tokens(mask_prompt, geo))
         self.transformer_time = time.perf_counter() - t0
         t0 = time.perf_counter()
         # last decoder level only feeds inference (:519-524); "name" mode classifies against the RAW text bank (:446)
@@ -542,8 +560,9 @@ class DeformableDETRSegmVL(nn.Module):
             if self.select_box_nums_for_evaluation_list is not None:
                 self.test_topk_per_image = self.select_box_nums_for_evaluation_list[dataset_id]
             self.preprocess_time = time.perf_counter() - t0
+            mp = inp.get("mask_prompt")
             out = self.forward_single(image, feats, prompt=prompt, instance=do_inst, semantic=meta, detector_columns=cols,
-                                      panoptic=do_pan)
+                                      panoptic=do_pan, mask_prompt=None if mp is None else mp.to(self.device))
             h, w = image.shape[-2:]
             height, width = inp.get("height", h), inp.get("width", w)
             res = {}

@@ -210,7 +210,7 @@ class DeformableDetrTransformerVL(nn.Module):
         return geo._lvl_pos[key]
 
     # ------------------------------------------------------------------ forward (:422-699), batch 1
-    def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None, after_encoder=None):
+    def forward_tokens(self, src, geo, l, dt, forced_topk=None, stages=None, after_encoder=None, mask_prompt=None):
         """src [T,256] neck output (token-major, levels concatenated), l [1, l_dim] fp32 fusion token(s).
         after_encoder(memory): hook called as soon as the encoder memory exists (the caller forks the mask-feature branch
         there, so that it runs next to the latency-bound selection + decoder)."""
@@ -221,7 +221,14 @@ class DeformableDetrTransformerVL(nn.Module):
         if after_encoder is not None:
             after_encoder(memory)
         # gen_encoder_output_proposals (:321-369): rows of padded / out-of-range anchors enter enc_output as zeros
-        om = ops.gemm(memory, P["wenc"], P["benc"], rowmask=geo.invalid_u8, mask_mode=ops.MASK_ZERO_INPUT)
+        invalid, anchors = geo.invalid_u8, geo.proposals
+        if mask_prompt is not None:
+            # mask prompt (:356-358, 364-365): tokens outside the prompted region are no proposals -- anchors +inf, memory rows zero.
+            # A per-request preprocessing step (not in the captured steady-state path): tensor-level
+            outside = ~mask_prompt.reshape(-1).to(device=memory.device, dtype=torch.bool)
+            invalid = (invalid.reshape(-1).bool() | outside).to(torch.uint8).reshape(invalid.shape).contiguous()
+            anchors = anchors.masked_fill(outside[:, None], float("inf")).contiguous()
+        om = ops.gemm(memory, P["wenc"], P["benc"], rowmask=invalid, mask_mode=ops.MASK_ZERO_INPUT)
         om = tap(stages, "output_memory", ops.layernorm(om, *P["nenc"], out_dtype=dt))
         E = self.embed_dim
         T = om.shape[0]
@@ -237,7 +244,7 @@ class DeformableDetrTransformerVL(nn.Module):
         # anchors, and produce the clamped corner boxes the proposal NMS works on -- one kernel (csrc/topk.hip)
         if stages is not None:
             cls2, d = tap(stages, "enc_cls2", cls2), tap(stages, "enc_delta8", d)
-        enc_class, enc_coord, xyxy = ops.enc_finalize(cls2, d, geo.proposals)
+        enc_class, enc_coord, xyxy = ops.enc_finalize(cls2, d, anchors)
         if stages is not None:
             stages["query_l"] = l_out
             enc_class, enc_coord = tap(stages, "enc_class", enc_class), tap(stages, "enc_coord_unact", enc_coord)

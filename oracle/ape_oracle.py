@@ -399,7 +399,7 @@ class ApeOracle:
         return ref[:, :, None] * valid_ratios[:, None]
 
     # a13 (deformable_transformer_vl.py:321-369)
-    def gen_proposals(self, memory, mask_flat, spatial_shapes):
+    def gen_proposals(self, memory, mask_flat, spatial_shapes, mask_prompt_flat=None):
         N = memory.shape[0]
         proposals, level_ids = [], []
         cur = 0
@@ -420,6 +420,9 @@ class ApeOracle:
         prop = torch.log(prop / (1 - prop))
         prop = prop.masked_fill(mask_flat.unsqueeze(-1), float("inf")).masked_fill(~valid, float("inf"))
         om = memory.masked_fill(mask_flat.unsqueeze(-1), 0.0).masked_fill(~valid, 0.0)
+        if mask_prompt_flat is not None:                 # (:356-358, 364-365) tokens outside the prompted region are no proposals
+            prop = prop.masked_fill(~mask_prompt_flat.unsqueeze(-1), float("inf"))
+            om = om.masked_fill(~mask_prompt_flat.unsqueeze(-1), 0.0)
         om = self.ln(self.lin(om, "transformer.enc_output"), "transformer.enc_output_norm")
         return om, prop, torch.cat(level_ids)
 
@@ -473,7 +476,7 @@ class ApeOracle:
     # --------------------------------------------------------------------------------------------
     # a9-a16: DeformableDetrTransformerVL.forward (deformable_transformer_vl.py:422-699)
     # --------------------------------------------------------------------------------------------
-    def transformer(self, feats, masks, pos_embeds, query_l, forced_topk=None):
+    def transformer(self, feats, masks, pos_embeds, query_l, forced_topk=None, masks_prompt=None):
         S = self.stages
         spatial_shapes = [(f.shape[2], f.shape[3]) for f in feats]
         feat = torch.cat([f.flatten(2).transpose(1, 2) for f in feats], 1)
@@ -503,7 +506,8 @@ class ApeOracle:
         S["memory"], S["query_l"] = memory, l
 
         # two-stage proposals (:495-533)
-        om, props, level_ids = self.gen_proposals(memory, mask, spatial_shapes)
+        mpf = None if masks_prompt is None else torch.cat([m.flatten(1) for m in masks_prompt], 1)      # (:465-470)
+        om, props, level_ids = self.gen_proposals(memory, mask, spatial_shapes, mpf)
         nd = self.dec_layers
         cls = self.lin(om, f"transformer.decoder.class_embed.{nd}")
         box = self.mlp(om, f"transformer.decoder.bbox_embed.{nd}") + props
@@ -683,7 +687,7 @@ class ApeOracle:
 
     @torch.no_grad()
     def forward(self, image, text_feats, height=None, width=None, forced_topk=None, with_masks=True, prompt="name",
-                phrase_bank=256, semantic=None, detector_columns=None, panoptic=None, name_fusion_text=False):
+                phrase_bank=256, semantic=None, detector_columns=None, panoptic=None, name_fusion_text=False, mask_prompt=None):
         """prompt="phrase" (also "expression" with text_feature_reduce_before_fusion): the text bank, zero-padded to
         the phrase-bank size (:304-327 with text_feature_bank + text_feature_bank_reset), is FUSED with the vision
         tokens in the encoder and the fused tokens are the classifier's vocabulary (:356-358, 448)."""
@@ -717,8 +721,14 @@ class ApeOracle:
         for f in ml_feats:
             masks.append(F.interpolate(img_mask[None], size=f.shape[-2:]).to(torch.bool).squeeze(0))
             pos.append(tp.position_embedding_sine(masks[-1]))
+        masks_prompt = None
+        if mask_prompt is not None:                      # deformable_detr_segm_vl.py:394-414
+            mp, _ = tp.pad_to_square(mask_prompt.float()[None], self.cfg["img_size"])
+            if mp.sum() == 0:
+                mp[...] = 255
+            masks_prompt = [F.interpolate(mp[None], size=f.shape[-2:], mode="bilinear").to(torch.bool).squeeze(0) for f in ml_feats]
         (inter, init_ref, inter_ref, enc_class, enc_coord, anchors, memory, l_out,
-         spatial_shapes) = self.transformer(ml_feats, masks, pos, fusion, forced_topk)
+         spatial_shapes) = self.transformer(ml_feats, masks, pos, fusion, forced_topk, masks_prompt)
         S["inter_states"], S["inter_references"], S["init_reference"] = inter, inter_ref, init_ref
         mask_feat = self.mask_features(memory, fpn["p2"], spatial_shapes)
         S["mask_features"] = mask_feat

@@ -40,7 +40,7 @@ def spec_of(model):
 
 
 def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name", semantic=None,
-                  eval_dataset=False, panoptic_configs=None):
+                  eval_dataset=False, panoptic_configs=None, mask_prompt=None):
     """returns (stages dict, instances dict, spec).  prompt="phrase": class names with a space, which the reference
     routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337)."""
     cfg = CONFIGS[cfg_name]
@@ -129,6 +129,8 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
         if not eval_dataset:
             inputs.update(prompt="text", text_prompt=",".join((f"c {i}" if prompt == "phrase" else f"c{i}")
                                                                 for i in range(text_feats.shape[0])))
+        if mask_prompt is not None:                    # the predictor's inputs["mask_prompt"] (ape/engine/defaults.py:226-228)
+            inputs["mask_prompt"] = mask_prompt
         with torch.no_grad():
             out = model([inputs])[0]
     finally:

@@ -25,6 +25,9 @@ CASES = {
     "small_padded": ("small", 0, 2, (384, 512), 10, 3),
     # phrase prompt: the 6 class tokens + 250 zero bank slots are fused densely with the vision tokens
     "tiny_phrase": ("tiny", 2, 7, (224, 256), 6, 8, "phrase"),
+    # mask prompt (deformable_detr_segm_vl.py:394-414, deformable_transformer_vl.py:356-365): only tokens inside the prompted
+    # rectangle may become proposals
+    "tiny_maskprompt": ("tiny", 1, 5, (200, 144), 7, 6, "name", None, None, "mask"),
     # semantic branch on (a22): 10 classes = 6 things + ("things", 4 stuff) -> 5 semantic channels; output resized x1.5
     "tiny_semantic": ("tiny", 3, 9, (208, 240), 10, 4, "name", "semantic"),
     # evaluation-dataset mode (set_eval_dataset): names from the metadata, detector on the 6 thing columns, semantic AND
@@ -87,6 +90,16 @@ def make_inputs(case):
     return cfg, wseed, image, text
 
 
+def case_mask_prompt(case, hw):
+    """the prompt mask of a "mask" case: a rectangle over the middle of the image, 255 inside (what a user paints in the demo)"""
+    if len(case) <= 9 or case[9] != "mask":
+        return None
+    h, w = hw
+    m = torch.zeros(h, w)
+    m[h // 5: (3 * h) // 5, w // 4: (3 * w) // 4] = 255.0
+    return m
+
+
 def fingerprint(t, nsamp=512):
     t = t.detach()
     flat = t.reshape(-1)
@@ -106,14 +119,15 @@ def main():
             continue
         cfg, wseed, image, text = make_inputs(case)
         prompt = CASES[case][6] if len(CASES[case]) > 6 else "name"
-        sem = (BIG_SEMANTIC_META if cfg.startswith("L_D") else SEMANTIC_META) if len(CASES[case]) > 7 else None
+        sem = (BIG_SEMANTIC_META if cfg.startswith("L_D") else SEMANTIC_META) if len(CASES[case]) > 7 and CASES[case][7] else None
         h, w = image.shape[-2:]
         out_hw = ((h, w) if cfg.startswith("L_D") else (int(1.5 * h), int(1.5 * w))) if sem else (None, None)
-        pan = len(CASES[case]) > 8
+        pan = len(CASES[case]) > 8 and bool(CASES[case][8])
+        mask_prompt = case_mask_prompt(CASES[case], image.shape[-2:])
         if pan:
             sem = dict(sem, thing_dataset_id_to_contiguous_id={i + 1: i for i in range(len(sem["thing_classes"]))})
         S, inst, spec, _ = rr.run_reference(cfg, wseed, image, text, prompt=prompt, semantic=sem, height=out_hw[0], width=out_hw[1],
-                                            eval_dataset=pan, panoptic_configs=PANOPTIC_CFG if pan else None)
+                                            eval_dataset=pan, panoptic_configs=PANOPTIC_CFG if pan else None, mask_prompt=mask_prompt)
         if spec_name(cfg) == cfg:
             with open(os.path.join(HERE, f"state_spec_{cfg}.json"), "w") as fh:
                 json.dump(spec, fh)

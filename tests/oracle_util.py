@@ -33,6 +33,17 @@ def case_inputs(gold):
     return cfg, wseed, image, text
 
 
+def case_mask_prompt(gold, hw):
+    """the prompt mask of a "mask" case (tests/golden/make_golden.py case_mask_prompt): a rectangle over the middle of the image"""
+    case = gold["case"]
+    if len(case) <= 9 or case[9] != "mask":
+        return None
+    h, w = hw
+    m = torch.zeros(h, w)
+    m[h // 5: (3 * h) // 5, w // 4: (3 * w) // 4] = 255.0
+    return m
+
+
 def case_prompt(gold):
     return gold["case"][6] if len(gold["case"]) > 6 else "name"
 

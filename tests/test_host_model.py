@@ -411,6 +411,39 @@ def test_vite_model_state_dict_contract_and_host_pipeline(fake_ops):
     assert frac >= 0.97
 
 
+def test_mask_prompt_restricts_the_proposals(fake_ops):
+    """deformable_detr_segm_vl.py:394-414 / deformable_transformer_vl.py:356-365: with a mask prompt only encoder tokens inside
+    the prompted region may become proposals (anchors +inf, memory rows zero elsewhere) -- vs the reference-generated fixture, through
+    forward_single and through the batched-inputs forward the predictor calls"""
+    model, orc, image, text, gold = M.build_pair("tiny_maskprompt")
+    mp = U.case_mask_prompt(gold, image.shape[-2:])
+    mv = model.model_vision
+    stages = {}
+    out = mv.forward_single(image, text, stages=stages, mask_prompt=mp)
+    # the prompted region leaves 280 < 300 candidates after the NMS, so the selection falls back to the plain top-300 by logit
+    # (:600-606) -- 130 tokens inside the region plus 170 of the ~5000 masked tokens, which all carry the SAME logit (their memory
+    # rows are zero).  Which of those exact ties the reference run picked is decided by its BLAS (the last rows of each thread's
+    # chunk differ by an ulp): compare the tokens inside the region, and require everything else to be a masked token
+    inside = mv.mask_prompt_tokens(mp, out["geo"]).cpu()
+    ours, ref = set(stages["topk_proposals"].tolist()), set(gold["full"]["topk_proposals"][0].tolist())
+    assert {t for t in ours if inside[t]} == {t for t in ref if inside[t]} and len({t for t in ours if inside[t]}) >= 100
+    assert not any(bool(inside[t]) for t in ours ^ ref)
+    plain = {}
+    mv.forward_single(image, text, stages=plain)
+    assert M.set_overlap(plain["topk_proposals"], gold["full"]["topk_proposals"][0]) < 0.9          # the prompt matters
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages, mask_prompt=mp)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+    res = model([{"image": image, "height": image.shape[1], "width": image.shape[2], "text_features": text, "mask_prompt": mp}])[0]["instances"]
+    gi = gold["instances"]
+    assert U.match_detections(res.pred_boxes, res.scores, res.pred_classes, gi["pred_boxes"], gi["scores"], gi["pred_classes"]) >= 0.97
+
+
 def test_graph_retirement_is_bounded(monkeypatch):
     """captured graphs are parked, never destroyed (ROCm 7.2: destroying one breaks later captures) -- but the parked HBM is
     accounted and capped: exceeding APE_GRAPH_RETIRE_LIMIT_GB raises with instructions instead of creeping to an out-of-memory"""

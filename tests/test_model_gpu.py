@@ -26,15 +26,17 @@ def _run(case, dtype):
     return model, orc, image.cuda(), text.cuda(), gold, image, text
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt"])
 def test_fp32_pipeline_matches_oracle_and_reference(case):
     """T1: every HIP kernel in its fp32 instantiation; tolerance = north_star's 1e-3 on logits / boxes"""
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.float32)
     prompt = U.case_prompt(gold)           # tiny_phrase: dense multi-token fusion (phrase / expression prompts)
+    mp = U.case_mask_prompt(gold, image_c.shape[-2:])      # tiny_maskprompt: proposals restricted to the prompted region
+    mpd = None if mp is None else mp.cuda()
     mv = model.model_vision
     stages = {}
-    mv.forward_single(image, text, stages=stages, prompt=prompt)
-    orc.forward(image_c, text_c, prompt=prompt)
+    mv.forward_single(image, text, stages=stages, prompt=prompt, mask_prompt=mpd)
+    orc.forward(image_c, text_c, prompt=prompt, mask_prompt=mp)
     O = orc.stages
     for k in ("p2", "p4", "p6", "enc0_fused_v", "enc0_fused_l", "memory", "query_l", "output_memory", "enc_class", "enc_coord_unact"):
         if O.get(k) is None:
@@ -45,10 +47,12 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
         assert e < 3e-4, k
     ov = M.set_overlap(stages["topk_proposals"].cpu(), gold["full"]["topk_proposals"][0])
     print(f"[fp32 {case}] proposal overlap with the reference run: {ov:.4f}")
-    assert ov >= 0.99
+    # mask prompt: the fall-back list ends in exact ties among the masked tokens, which the reference run breaks by BLAS noise
+    # (tests/test_host_model.py::test_mask_prompt_restricts_the_proposals): the tokens inside the region must agree
+    assert ov >= (0.99 if mp is None else 0.93)
     ref_topk = gold["full"]["topk_proposals"][0]
     stages = {}
-    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages, prompt=prompt)
+    out = mv.forward_single(image, text, forced_topk=ref_topk.cuda(), stages=stages, prompt=prompt, mask_prompt=mpd)
     el = U.relerr(stages["pred_logits"].cpu(), gold["full"]["pred_logits"][0])
     eb = U.relerr(stages["pred_boxes"].cpu(), gold["full"]["pred_boxes"][0])
     print(f"[fp32 {case}] pred_logits {el:.2e} pred_boxes {eb:.2e} (vs reference fixture)")
@@ -57,7 +61,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
                               gold["full"]["det_boxes"], gold["full"]["det_scores"], gold["full"]["det_classes"])
     print(f"[fp32 {case}] detections reproduced: {frac:.3f}")
     assert frac >= 0.97
-    orc.forward(image_c, text_c, forced_topk=ref_topk[None], prompt=prompt)
+    orc.forward(image_c, text_c, forced_topk=ref_topk[None], prompt=prompt, mask_prompt=mp)
     # masks are compared per (query, class) pair: two detections with near-equal scores may swap places
     ours = {(int(q), int(c)): i for i, (q, c) in enumerate(zip(out["det_query"].cpu(), out["det_classes"].cpu()))}
     pairs = [(ours[(int(q), int(c))], j) for j, (q, c) in enumerate(zip(orc.stages["det_query"], orc.stages["det_classes"]))
@@ -464,6 +468,11 @@ def test_predictor_input_pipeline_on_the_real_photograph():
     got = pred.preprocess(bgr)
     assert tuple(got.shape) == tuple(image.shape) == (3, 576, 1024)
     assert torch.equal(got.cpu(), image)
+    # a mask prompt takes the same transform (defaults.py:226-228): Pillow's bilinear resize of the single-channel uint8 mask
+    m = np.zeros(rgb.shape[:2], dtype=np.uint8)
+    m[80:250, 150:520] = 255
+    want = torch.from_numpy(np.asarray(Image.fromarray(m).resize((1024, 576), Image.BILINEAR)).astype("float32"))
+    assert torch.equal(pred.preprocess_mask(m, 576, 1024).cpu(), want)
 
 
 @pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg"])

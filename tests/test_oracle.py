@@ -16,7 +16,8 @@ FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order
 # small_A: the plain (non-VL) family of APE-L_A/B/C -- DeformableDETRSegm on DeformableDetrTransformer, no neck, no fusion, no
 # ambiguous heads, the EVA-02 MIM ViT with sub-LN (fixture produced by the reference's deformable_detr_segm.py / deformable_transformer.py)
 # small_E: APE on the ViT-e backbone (post-norm blocks, packed qkv, GELU MLP, head width 112) with 3 + 3 layers
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E"])
+# tiny_maskprompt: a mask prompt restricts the proposals to the prompted region (and drives the selection into its fall-back list)
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
@@ -24,7 +25,8 @@ def test_oracle_matches_reference_golden(case):
     orc = ape_oracle.ApeOracle(CONFIGS[cfg_name], sd)
     ref_topk = gold["full"]["topk_proposals"]
     prompt = U.case_prompt(gold)
-    out = orc.forward(image, text, prompt=prompt)
+    mp = U.case_mask_prompt(gold, image.shape[-2:])
+    out = orc.forward(image, text, prompt=prompt, mask_prompt=mp)
     S = orc.stages
     # stages upstream of the proposal selection: elementwise
     upstream = [k for k in gold["stages"] if k.startswith(("vit_block", "last_feat", "p", "enc", "memory", "query_l",
@@ -35,7 +37,7 @@ def test_oracle_matches_reference_golden(case):
     # the selected proposals: same SET (near-equal scores may swap places between two fp32 implementations)
     assert set(S["topk_proposals"][0].tolist()) == set(ref_topk[0].tolist())
     # downstream with the reference's proposal order injected
-    out = orc.forward(image, text, forced_topk=ref_topk, prompt=prompt)
+    out = orc.forward(image, text, forced_topk=ref_topk, prompt=prompt, mask_prompt=mp)
     S = orc.stages
     for k in ("query_init", "query_pos", "init_reference", "inter_states", "inter_references", "pred_masks"):
         U.check_fingerprint(S[k], gold["stages"][k], 5e-4, k)
