@@ -19,7 +19,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # per-file overrides: the fused FFN keeps 160 accumulator registers per lane next to 64 operand and 64 prefetch registers -- one
 # wave per SIMD owns the whole 512-entry file, so its accumulators belong in the AGPR half (with the VGPR form hipcc shuffles
 # them through v_accvgpr moves between the MFMAs of a batch)
-FILE_FLAGS = {"ffn_fused.hip": ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=0"]}
+# attention: the softmax never produces a NaN (key 0 is visible to every query, masked scores are -inf and only ever meet finite
+# maxima), so fmaxf needs no NaN-quieting: under the default IEEE mode hipcc canonicalises every operand of a max with a
+# `v_max x, x` -- 30 of the ~160 VALU instructions a wave issues per key tile in a VALU-bound kernel
+FILE_FLAGS = {"ffn_fused.hip": ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=0"],
+              "attention.hip": FLAGS + ["-fno-honor-nans", "-mno-amdgpu-ieee"]}
 
 
 def _sources():
