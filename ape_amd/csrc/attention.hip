@@ -377,7 +377,14 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
       else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false>), grid, dim3(256), 0, s, p); }
     } else if (HD == 64) {
       static const bool occ4 = getenv("APE_ATTN_OCC4") != nullptr;       // A/B: cap the 128-query kernel at 128 registers (4 waves per SIMD)
-      if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4>), grid, dim3(256), 0, s, p);
+      // 256 queries per workgroup (4 query tiles per wave: every K / V^T fragment read from LDS feeds four MFMAs) when that still
+      // leaves two workgroups per CU -- the 2-image ViT pass: 2 x 16 heads x 16 blocks (global), 8 windows x 16 heads x 4 blocks
+      const char* qt4_env = getenv("APE_ATTN_QT4");
+      const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : false) && (size_t)ceil_div(N, 256) * H * B >= 512;
+      if (qt4) {
+        grid.x = ceil_div(N, 256);
+        hipLaunchKernelGGL((attn_bf16_kernel<64, 4>), grid, dim3(256), 0, s, p);
+      } else if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4>), grid, dim3(256), 0, s, p);
       else if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p);
       else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p);
     }

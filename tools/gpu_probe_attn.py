@@ -15,7 +15,8 @@ def bench(fn, reps=20):
     return s.elapsed_time(e) / reps * 1e3
 
 bf = torch.bfloat16
-for (B, N, H, HD, name) in [(4, 1024, 16, 64, "ViT windowed"), (1, 4096, 16, 64, "ViT global"), (1, 900, 8, 32, "decoder self-attn"),
+for (B, N, H, HD, name) in [(4, 1024, 16, 64, "ViT windowed"), (1, 4096, 16, 64, "ViT global"), (8, 1024, 16, 64, "ViT windowed, 2 images"),
+                            (2, 4096, 16, 64, "ViT global, 2 images"), (1, 900, 8, 32, "decoder self-attn"),
                             (9, 1024, 16, 64, "ViT windowed 1536^2"), (1, 9216, 16, 64, "ViT global 1536^2")]:
     T = B * N
     q = torch.randn(T, H * HD, device="cuda").to(bf); k = torch.randn(T, H * HD, device="cuda").to(bf)
