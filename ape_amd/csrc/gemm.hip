@@ -705,7 +705,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
     const int rho = (wave * 4 + i) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((rho >> 1) & 7);
     const int idx = rho & 15;
-    wcol[i] = (idx >> 2) * 32 + (rho >> 4) * 4 + (idx & 3);       // chunk column held by ring row rho
+    // chunk column held by ring row rho = 16 j + 4 g + r: 32 (j >> 1) + 8 g + 4 (j & 1) + r -- after D = W A^T lane (m, g) then
+    // owns, for every PAIR of column tiles jp = j >> 1, the 8 consecutive columns 32 jp + 8 g .. + 7, so that one store
+    // instruction (fixed jp) has the four lanes g = 0..3 of a row write 64 (f32: 128) CONTIGUOUS bytes.  (Round 2 gave a lane 32
+    // consecutive columns: every store instruction then touched 64 sectors with one isolated 16-byte piece each, and the
+    // write-bound launches of this kernel sat at ~2 TB/s.)
+    wcol[i] = (rho >> 5) * 32 + (idx >> 2) * 8 + ((rho >> 4) & 1) * 4 + (idx & 3);
     wk[i] = c * 8;
   }
   const int T = nch * 4;
@@ -763,15 +768,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
     mm(3, w1);
   };
 
-  // residual registers of the current chunk: lane owns row mrow[mi], columns n_lane .. n_lane + 31
-  uint4 rres[RES == 0 ? 1 : 2][RES == 2 ? 8 : 4];
+  // residual registers of the current chunk: lane owns row mrow[mi], columns n_lane + 32 q .. + 7 (q = 0..3), n_lane = chunk + 8 fq
+  static_assert(RES != 2, "the f32-residual flavour was never instantiated (register budget); its piece layout is not maintained");
+  uint4 rres[RES == 0 ? 1 : 2][4];
   auto load_res = [&](int n_lane) {
     if (RES == 0) return;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.residual) + ((size_t)mrow[mi] * p.ldr + n_lane) * (RES == 2 ? 4 : 2);
+      const unsigned char* rp = reinterpret_cast<const unsigned char*>(p.residual) + ((size_t)mrow[mi] * p.ldr + n_lane) * 2;
 #pragma unroll
-      for (int q = 0; q < (RES == 2 ? 8 : 4); ++q) rres[RES == 0 ? 0 : mi][q] = *reinterpret_cast<const uint4*>(rp + q * 16);
+      for (int q = 0; q < 4; ++q) rres[RES == 0 ? 0 : mi][q] = *reinterpret_cast<const uint4*>(rp + q * 64);
     }
   };
   // epilogue arithmetic on one accumulator quad (same order as epi_n4_values); rv = residual values or zeros.
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
     }
   };
   auto epilogue_fast = [&](auto mode_tag, int cc) {        // whole chunk in bounds: unconditional 16-byte stores, NE per lane
-    const int ncol = cc * KR_CH + fq * 32;  // relative to nbeg
+    const int ncol = cc * KR_CH + fq * 8;   // relative to nbeg; piece jp covers columns ncol + 32 jp .. + 7
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
       unsigned char* cp = reinterpret_cast<unsigned char*>(p.C) + ((size_t)mrow[mi] * p.ldc + nbeg + ncol) * (OUT_F32 ? 4 : 2);
@@ -809,27 +815,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int j = jp * 2 + h;
-          const float4 b = *reinterpret_cast<const float4*>(sbias + ncol + j * 4);
+          const float4 b = *reinterpret_cast<const float4*>(sbias + ncol + jp * 32 + h * 4);
           float rv[4] = {0.f, 0.f, 0.f, 0.f};
           if (RES == 1) {
             const uint4 u = rres[RES == 0 ? 0 : mi][jp];
             const uint32_t lo = h == 0 ? u.x : u.z, hi = h == 0 ? u.y : u.w;
             rv[0] = __uint_as_float(lo << 16); rv[1] = __uint_as_float(lo & 0xffff0000u);
             rv[2] = __uint_as_float(hi << 16); rv[3] = __uint_as_float(hi & 0xffff0000u);
-          } else if (RES == 2) {
-            const uint4 u = rres[RES == 0 ? 0 : mi][RES == 2 ? j : 0];
-            rv[0] = __uint_as_float(u.x); rv[1] = __uint_as_float(u.y); rv[2] = __uint_as_float(u.z); rv[3] = __uint_as_float(u.w);
           }
           finish(mode_tag, acc[mi][j], b, rv, mi, v[h]);
         }
         if (OUT_F32) {
-          *reinterpret_cast<float4*>(cp + jp * 32) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
-          *reinterpret_cast<float4*>(cp + jp * 32 + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
+          *reinterpret_cast<float4*>(cp + jp * 128) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
+          *reinterpret_cast<float4*>(cp + jp * 128 + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
         } else if (OUT_F16) {
-          *reinterpret_cast<uint4*>(cp + jp * 16) = make_uint4(pack2h(v[0][0], v[0][1]), pack2h(v[0][2], v[0][3]),
+          *reinterpret_cast<uint4*>(cp + jp * 64) = make_uint4(pack2h(v[0][0], v[0][1]), pack2h(v[0][2], v[0][3]),
                                                                pack2h(v[1][0], v[1][1]), pack2h(v[1][2], v[1][3]));
         } else {
-          *reinterpret_cast<uint4*>(cp + jp * 16) = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]),
+          *reinterpret_cast<uint4*>(cp + jp * 64) = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]),
                                                                pack2bf(v[1][0], v[1][1]), pack2bf(v[1][2], v[1][3]));
         }
         __builtin_amdgcn_sched_barrier(0);    // one 8-column piece at a time: keeps the live set small (no spills)
@@ -841,12 +844,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int m = mrow[mi], ncol = cc * KR_CH + fq * 32 + j * 4, n = nbeg + ncol;
+        const int m = mrow[mi], ncol = cc * KR_CH + (j >> 1) * 32 + fq * 8 + (j & 1) * 4, n = nbeg + ncol;
         if (m >= p.M || n >= p.N) continue;          // N % 4 == 0 (launcher), so a quad is all in or all out
         const float4 b = *reinterpret_cast<const float4*>(sbias + ncol);
         float rv[4] = {0.f, 0.f, 0.f, 0.f};
         if (RES == 1) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + (size_t)m * p.ldr + n, rv);
-        if (RES == 2) ld4<float>(reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n, rv);
         float v[4];
         finish(std::integral_constant<int, 2>{}, acc[mi][j], b, rv, mi, v);
         if (OUT_F32) st4<float>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
     // ks = 3: after stage t0+3's request: [t0+4] [t0+5]
     wait_vmcnt<8>();
     __builtin_amdgcn_s_barrier();
-    if (fast) load_res(nbeg + cc * KR_CH + fq * 32);
+    if (fast) load_res(nbeg + cc * KR_CH + fq * 8);
     issue(t0 + 6);
     compute(t0 + 3, 3);
     if (fast) {
