@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       const int rho = 8 * i + (lane >> 3), qp = lane & 7;
       const int q = qp ^ ((rho >> 1) & 7);
       const int ot = rho >> 4, m = rho & 15;
-      const int ch = (m >> 2) * 64 + ot * 4 + (m & 3);
+      // output channel of W2 image row rho = 16 ot + 4 g + r: 32 (ot >> 1) + 8 g + 4 (ot & 1) + r -- a lane then owns, for every
+      // pair of output tiles q = ot >> 1, the 8 consecutive channels 32 q + 8 g .. + 7, so that one epilogue store (fixed q) has
+      // the four lanes g of a token write 64 contiguous bytes (64 consecutive channels per lane left every store instruction
+      // four isolated 16-byte pieces per token; same for the residual loads)
+      const int ch = (ot >> 1) * 32 + (m >> 2) * 8 + (ot & 1) * 4 + (m & 3);
       w2off[j] = (uint32_t)ch * (uint32_t)p.ldw2 + (uint32_t)q * 8u;             // + chunk * 64
     }
   }
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns channels g*64 .. g*64 + 63 of tokens tok[0], tok[1]; 16-byte pieces (ot pair 2q, 2q+1 = 8 channels).
+  // ---- epilogue: lane owns channels 32 q + 8 g .. + 7 (q = 0..7) of its tokens; 16-byte pieces (ot pair 2q, 2q+1 = 8 channels).
   // Optional LayerNorm of the finished row (the post-FFN norm of the transformer layer, detrex BaseTransformerLayer "ffn", "norm"):
   // a token's 256 channels sit in the 4 lanes fm + 16 g, so the statistics are two lane swaps; computed on the fp32 sums (two-pass
   // variance), i.e. without the bf16 rounding a separate LayerNorm launch would read -- and without its 89 MB round trip.
@@ -264,19 +268,19 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int tk = tok[rt] < p.M ? tok[rt] : p.M - 1;
-    const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tk * p.ldr + g * 64 : nullptr;
+    const bf16_t* rp = p.R != nullptr ? p.R + (size_t)tk * p.ldr + g * 8 : nullptr;
     float v[64];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float4 ba = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8);
-      const float4 bb = *reinterpret_cast<const float4*>(sb2 + g * 64 + q * 8 + 4);
+      const float4 ba = *reinterpret_cast<const float4*>(sb2 + q * 32 + g * 8);
+      const float4 bb = *reinterpret_cast<const float4*>(sb2 + q * 32 + g * 8 + 4);
       v[q * 8 + 0] = yacc[2 * q][rt][0] + ba.x; v[q * 8 + 1] = yacc[2 * q][rt][1] + ba.y;
       v[q * 8 + 2] = yacc[2 * q][rt][2] + ba.z; v[q * 8 + 3] = yacc[2 * q][rt][3] + ba.w;
       v[q * 8 + 4] = yacc[2 * q + 1][rt][0] + bb.x; v[q * 8 + 5] = yacc[2 * q + 1][rt][1] + bb.y;
       v[q * 8 + 6] = yacc[2 * q + 1][rt][2] + bb.z; v[q * 8 + 7] = yacc[2 * q + 1][rt][3] + bb.w;
       if (rp != nullptr) {
         float r[8];
-        ld8<bf16_t>(rp + q * 8, r);
+        ld8<bf16_t>(rp + q * 32, r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[q * 8 + e] += r[e];
       }
@@ -292,16 +296,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       const float rstd = rsqrtf(ff_rows_sum(d2) * (1.f / FF_N) + p.ln_eps);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float4 w = *reinterpret_cast<const float4*>(p.ln_w + g * 64 + q * 4);
-        const float4 b = *reinterpret_cast<const float4*>(p.ln_b + g * 64 + q * 4);
+        const float4 w = *reinterpret_cast<const float4*>(p.ln_w + (q >> 1) * 32 + g * 8 + (q & 1) * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.ln_b + (q >> 1) * 32 + g * 8 + (q & 1) * 4);
         v[q * 4 + 0] = fmaf(v[q * 4 + 0] * rstd, w.x, b.x); v[q * 4 + 1] = fmaf(v[q * 4 + 1] * rstd, w.y, b.y);
         v[q * 4 + 2] = fmaf(v[q * 4 + 2] * rstd, w.z, b.z); v[q * 4 + 3] = fmaf(v[q * 4 + 3] * rstd, w.w, b.w);
       }
     }
     if (tok[rt] < p.M) {
-      bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 64;
+      bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 8;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) st8<bf16_t>(yp + q * 8, v + q * 8);
+      for (int q = 0; q < 8; ++q) st8<bf16_t>(yp + q * 32, v + q * 8);
     }
   }
 }

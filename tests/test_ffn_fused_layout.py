@@ -28,10 +28,11 @@ def mfma_16x16x32(a_frag, b_frag, acc):
 
 # ---- LDS images, as the LDS-DMA writes them (lane-linear destination; the swizzle / permutation is on the SOURCE address)
 def w2_channel(rho):
-    """LDS row rho = ot * 16 + m of the W2 chunk holds output channel (m >> 2) * 64 + ot * 4 + (m & 3): after the second MFMA a lane
-    (g = lane >> 4) owns the 64 CONSECUTIVE output channels g * 64 .. g * 64 + 63 of its token"""
+    """LDS row rho = ot * 16 + 4 g + r of the W2 chunk holds output channel 32 (ot >> 1) + 8 g + 4 (ot & 1) + r: after the second MFMA
+    a lane (g = lane >> 4) owns, for every pair of output tiles q = ot >> 1, the 8 CONSECUTIVE channels 32 q + 8 g .. + 7 of its
+    token -- one store instruction then has the four lanes of a token write 64 contiguous bytes"""
     ot, m = rho >> 4, rho & 15
-    return (m >> 2) * 64 + ot * 4 + (m & 3)
+    return (ot >> 1) * 32 + (m >> 2) * 8 + (ot & 1) * 4 + (m & 3)
 
 
 def stage_w1(W1, c):
@@ -118,13 +119,13 @@ def fused_ffn_wave(X32, W1, b1, W2, b2, w2_permuted=False):
                 wf = np.stack([read_w2(i2, ot, kk, lane) for lane in range(64)])
                 for rt in range(2):
                     yacc[ot][rt] = mfma_16x16x32(wf, hb[rt], yacc[ot][rt])
-    # epilogue: yacc[ot][rt][lane][r] = Y[token rt*16 + (lane & 15)][channel g*64 + ot*4 + r]
+    # epilogue: yacc[ot][rt][lane][r] = Y[token rt*16 + (lane & 15)][channel 32 (ot >> 1) + 8 g + 4 (ot & 1) + r]
     Y = np.zeros((32, N_OUT))
     for ot in range(16):
         for rt in range(2):
             for lane in range(64):
                 n, g = lane & 15, lane >> 4
-                ch = g * 64 + ot * 4
+                ch = (ot >> 1) * 32 + g * 8 + (ot & 1) * 4
                 Y[rt * 16 + n, ch: ch + 4] = yacc[ot][rt][lane] + b2[ch: ch + 4] + X32[rt * 16 + n, ch: ch + 4]
     return Y
 
