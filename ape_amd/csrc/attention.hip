@@ -113,7 +113,11 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
     {
       const int row = slot >> 3, cp = slot & 7;
       const int c = cp ^ ((row >> 1) & 7);
-      voff[i] = row * p.ldvt + c * 8;          // < HD * ldvt: 32 bits suffice (ldvt < 2^24)
+      // PERM: LDS row 16 d + 4 g + r of the V^T tile holds channel 32 (d >> 1) + 8 g + 4 (d & 1) + r, so that after O^T = V^T P^T a
+      // lane owns 8 consecutive channels per PAIR of output tiles and one epilogue store has the four lanes of a query write 64
+      // contiguous bytes (channel 16 d + 4 g + r gave 8-byte stores, 32 contiguous bytes per instruction)
+      const int ch = PERM ? (row >> 5) * 32 + ((row >> 2) & 3) * 8 + ((row >> 4) & 1) * 4 + (row & 3) : row;
+      voff[i] = ch * p.ldvt + c * 8;           // < HD * ldvt: 32 bits suffice (ldvt < 2^24)
     }
   }
   auto issue = [&](int t, bf16_t* dst) __attribute__((always_inline)) {
@@ -265,11 +269,21 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
   for (int u = 0; u < QT; ++u) {
     const float inv = 1.f / lacc[u][0];    // every row of the ones-tile holds the full sum over keys for query frow
     if (qrow[u] < N) {
-      bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 4;
+      if (PERM) {
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 8;
 #pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
-        st4<bf16_t>(o + d * 16, v);
+        for (int dp = 0; dp < DT / 2; ++dp) {
+          const float v[8] = {oacc[u][2 * dp][0] * inv, oacc[u][2 * dp][1] * inv, oacc[u][2 * dp][2] * inv, oacc[u][2 * dp][3] * inv,
+                              oacc[u][2 * dp + 1][0] * inv, oacc[u][2 * dp + 1][1] * inv, oacc[u][2 * dp + 1][2] * inv, oacc[u][2 * dp + 1][3] * inv};
+          st8<bf16_t>(o + dp * 32, v);
+        }
+      } else {
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 4;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
+          st4<bf16_t>(o + d * 16, v);
+        }
       }
     }
   }
@@ -357,8 +371,8 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(N, 64), H, B);
   if (dt == APE_DT_BF16) {
-    APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0, "ape_hip_attention(bf16): ld alignment");
-    APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 8 == 0,
+    APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "ape_hip_attention(bf16): ld alignment");
+    APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 16 == 0,
                   "ape_hip_attention(bf16): pointer alignment");
     APE_CHECK_ARG(B == 1 || bstride % 8 == 0, "ape_hip_attention(bf16): batched windows need a batch stride %% 8 == 0");
     // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
