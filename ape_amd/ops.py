@@ -269,6 +269,8 @@ def postnorm_residual(stream, t, norm, copy_dtype=None):
     if stream.dtype != torch.float32:
         raise TypeError("ape_amd.ops.postnorm_residual: the residual stream is float32")
     M, C = stream.shape
+    if copy_dtype not in (None, torch.float32, torch.bfloat16) or (t is not None and t.dtype not in (torch.float32, torch.bfloat16)):
+        raise TypeError("ape_amd.ops.postnorm_residual: t and the copy are float32 or bfloat16")
     copy = torch.empty((M, C), dtype=copy_dtype, device=stream.device) if copy_dtype is not None else None
     w = b = None
     eps = 0.0
