@@ -444,6 +444,56 @@ def test_mask_prompt_restricts_the_proposals(fake_ops):
     assert U.match_detections(res.pred_boxes, res.scores, res.pred_classes, gi["pred_boxes"], gi["scores"], gi["pred_classes"]) >= 0.97
 
 
+def test_forward_path_issues_no_tensor_library_glue(monkeypatch):
+    """between the HIP ops the per-image forward issues (almost) no tensor-library operators -- counted with a
+    TorchDispatchMode over the host model running on the ops' torch definitions (an aten call inside a definition is the op itself,
+    i.e. a HIP kernel on the GPU; an aten call at depth 0 is glue the GPU would launch as a tensor-library kernel).  Left: the
+    zero-fills of the two padded V^T operand buffers."""
+    import collections
+    from torch.utils._python_dispatch import TorchDispatchMode
+    import ape_amd.ops as ops
+    import ref_ops
+
+    no_launch = {"view", "_unsafe_view", "reshape", "expand", "permute", "transpose", "t", "slice", "select", "unsqueeze", "squeeze", "as_strided",
+                 "alias", "detach", "unbind", "split", "split_with_sizes", "chunk", "narrow", "unfold", "_reshape_alias", "empty", "empty_like",
+                 "empty_strided", "new_empty", "new_empty_strided", "size", "stride", "sym_size", "is_pinned", "lift_fresh", "_local_scalar_dense",
+                 "resize_", "set_", "result_type", "item", "is_same_size", "diagonal"}
+    depth = [0]
+
+    def wrap(fn):
+        def inner(*a, **k):
+            depth[0] += 1
+            try:
+                return fn(*a, **k)
+            finally:
+                depth[0] -= 1
+        return inner
+
+    for n in dir(ref_ops):
+        if not n.startswith("_") and callable(getattr(ref_ops, n)) and hasattr(ops, n):
+            monkeypatch.setattr(ops, n, wrap(getattr(ref_ops, n)))
+
+    class Glue(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.kinds = collections.Counter()
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = func.__name__.split(".")[0]
+            if depth[0] == 0 and name not in no_launch:
+                self.kinds[name] += 1
+            return out
+
+    model, image, text, gold = M.build_model("tiny_padded", "cpu", torch.float32)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.bfloat16)
+    mv.forward_single(image, text)                     # packs the weights, builds the per-size caches
+    with Glue() as g:
+        mv.forward_single(image, text)
+    assert sum(g.kinds.values()) <= 3 and set(g.kinds) <= {"zeros", "zero_", "fill_"}, dict(g.kinds)
+
+
 def test_graph_retirement_is_bounded(monkeypatch):
     """captured graphs are parked, never destroyed (ROCm 7.2: destroying one breaks later captures) -- but the parked HBM is
     accounted and capped: exceeding APE_GRAPH_RETIRE_LIMIT_GB raises with instructions instead of creeping to an out-of-memory"""
