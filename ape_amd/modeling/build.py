@@ -48,6 +48,12 @@ SIZES = {
                 dec_layers=9, num_queries=900, topk_eval=300, backbone="clip_e", global_every=4),
     "small_E": dict(img_size=512, embed_dim=224, depth=4, num_heads=2, window_size=16, pretrain_img_size=224, enc_layers=3,
                     dec_layers=3, num_queries=300, topk_eval=50, backbone="clip_e", global_every=4),
+    # APE on the EVA-01-CLIP ViT-g (ape_deta_vitg_eva01_clip_lsj1536_cp_64x90k.py; vitg_eva01_clip_1536.py): packed qkv, GELU MLP, no rope,
+    # pre-norm, 40 blocks of width 1408 = 16 heads x 88 (zero-padded to 128), plain model family
+    "G_A": dict(img_size=1536, embed_dim=1408, depth=40, num_heads=16, window_size=32, pretrain_img_size=224, enc_layers=6,
+                dec_layers=6, num_queries=900, topk_eval=300, backbone="clip_g", global_every=4, vl=False),
+    "small_G": dict(img_size=512, embed_dim=352, depth=4, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=2,
+                    dec_layers=2, num_queries=300, topk_eval=50, backbone="clip_g", global_every=4, vl=False),
 }
 
 
@@ -85,6 +91,13 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
                             window_block_indexes=[i for i in range(c.depth) if i % getattr(c, "global_every", 3) != getattr(c, "global_every", 3) - 1],
                             residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat", use_act_checkpoint=False, xattn=True,
                             subln=getattr(c, "subln", False), swiglu=not getattr(c, "subln", False), naiveswiglu=getattr(c, "subln", False))
+    elif getattr(c, "backbone", "eva_clip") == "clip_g":      # EVA-01-CLIP ViT-g: configs/common/backbone/vitg_eva01_clip_1024.py:9-45
+        ge = getattr(c, "global_every", 4)
+        net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.6,
+                  window_size=c.window_size, mlp_ratio=6144 / 1408, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                  window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
+                  out_feature="last_feat", use_act_checkpoint=True, xattn=True, pretrain_img_size=c.pretrain_img_size,
+                  pretrain_use_cls_token=True)
     elif getattr(c, "backbone", "eva_clip") == "clip_e":      # ViT-e: configs/common/backbone/vite_eva02_clip_1024.py:9-49
         ge = getattr(c, "global_every", 4)
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.4,

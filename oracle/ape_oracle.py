@@ -249,6 +249,22 @@ class ApeOracle:
         o = (att @ v).permute(0, 2, 1, 3).reshape(B, N, -1)
         return self.lin(o, pre + "proj").view(B, H, W, C)
 
+    def vit_block_prenorm_packed(self, x, i):
+        """EVA-01-CLIP ViT-g (vitg_eva01_clip_1024.py:9-45): the pre-norm order of Block :519-523 around the packed-qkv attention and
+        the GELU Mlp -- x = x + attn(norm1(x)); x = x + mlp(norm2(x))"""
+        pre = f"backbone.net.blocks.{i}."
+        shortcut = x
+        x = self.ln(x, pre + "norm1", 1e-6)
+        if i in self.win_blocks:
+            H, W = x.shape[1], x.shape[2]
+            xw = window_partition(x, self.ws)
+            xw = self.vit_attention_packed(xw, i)
+            x = window_unpartition(xw, self.ws, H, W)
+        else:
+            x = self.vit_attention_packed(x, i)
+        x = shortcut + x
+        return x + self.lin(F.gelu(self.lin(self.ln(x, pre + "norm2", 1e-6), pre + "mlp.fc1")), pre + "mlp.fc2")
+
     def vit_block_postnorm(self, x, i):
         pre = f"backbone.net.blocks.{i}."
         shortcut = x
@@ -284,7 +300,8 @@ class ApeOracle:
         for i in range(self.depth):
             t0 = time.perf_counter()
             kind = self.cfg.get("backbone")
-            x = self.vit_block_eva02(x, i) if kind == "eva02" else self.vit_block_postnorm(x, i) if kind == "clip_e" else self.vit_block(x, i)
+            x = (self.vit_block_eva02(x, i) if kind == "eva02" else self.vit_block_postnorm(x, i) if kind == "clip_e"
+                 else self.vit_block_prenorm_packed(x, i) if kind == "clip_g" else self.vit_block(x, i))
             self._tick("vit_win_block" if i in self.win_blocks else "vit_glb_block", t0)
             self.stages[f"vit_block{i}"] = x
         return x.permute(0, 3, 1, 2)

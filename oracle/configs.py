@@ -39,6 +39,13 @@ CONFIGS = {
                 enc_layers=9, dec_layers=9, num_queries=900, topk_eval=300, backbone="clip_e", global_every=4),
     "small_E": dict(img_size=512, embed_dim=224, depth=4, num_heads=2, window_size=16, pretrain_img_size=224,
                     enc_layers=3, dec_layers=3, num_queries=300, topk_eval=50, backbone="clip_e", global_every=4),
+    # APE on the EVA-01-CLIP ViT-g (configs/COCO_InstanceSegmentation/ape_deta/ape_deta_vitg_eva01_clip_lsj1536_cp_64x90k.py +
+    # configs/common/backbone/vitg_eva01_clip_1536.py): the vit_eva_clip classes with packed qkv, GELU MLP (ratio 6144 / 1408), no
+    # rope, PRE-norm, 40 blocks of width 1408 = 16 heads x 88, every fourth block global, under the plain model family (neck = None)
+    "G_A": dict(img_size=1536, embed_dim=1408, depth=40, num_heads=16, window_size=32, pretrain_img_size=224,
+                enc_layers=6, dec_layers=6, num_queries=900, topk_eval=300, backbone="clip_g", global_every=4, vl=False),
+    "small_G": dict(img_size=512, embed_dim=352, depth=4, num_heads=4, window_size=16, pretrain_img_size=224,
+                    enc_layers=2, dec_layers=2, num_queries=300, topk_eval=50, backbone="clip_g", global_every=4, vl=False),
     "L_D_1536": dict(img_size=1536, embed_dim=1024, depth=24, num_heads=16, window_size=32, pretrain_img_size=336,
                      enc_layers=6, dec_layers=6, num_queries=900, topk_eval=500, spec="L_D"),
 }

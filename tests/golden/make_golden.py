@@ -50,6 +50,8 @@ CASES = {
     "small_A": ("small_A", 1, 4, (416, 512), 9, 5),
     # f4: APE on the ViT-e backbone (post-norm blocks, head width 112, 3 + 3 layers) at reduced size
     "small_E": ("small_E", 2, 6, (448, 512), 8, 7),
+    # f4: APE on the EVA-01-CLIP ViT-g backbone (pre-norm, packed qkv, GELU MLP, head width 88) under the plain family, reduced size
+    "small_G": ("small_G", 3, 8, (512, 400), 9, 5),
     # config 2 with a REAL photograph (demo/examples/*.jpg): the reference's demo image, decoded, BGR -> RGB, resized by
     # Pillow exactly as ape/engine/defaults.py:213-222 does (ResizeShortestEdge(1024, 1024): 394 x 700 -> 576 x 1024).  The JPEG
     # bytes (42 KB) travel inside the fixture; the tests decode them with the same library.
@@ -135,7 +137,7 @@ def main():
         if isinstance(CASES[case][2], str):
             with open(os.path.join("/root/reference/demo/examples", CASES[case][2][5:]), "rb") as fh:
                 gold["jpeg"] = torch.frombuffer(bytearray(fh.read()), dtype=torch.uint8).clone()
-        big = cfg.startswith("L_D") or cfg in ("Ti", "L_A", "E_D")
+        big = cfg.startswith("L_D") or cfg in ("Ti", "L_A", "E_D", "G_A")
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)

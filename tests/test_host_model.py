@@ -411,6 +411,40 @@ def test_vite_model_state_dict_contract_and_host_pipeline(fake_ops):
     assert frac >= 0.97
 
 
+def test_vitg_clip_model_state_dict_contract_and_host_pipeline(fake_ops):
+    """APE on the EVA-01-CLIP ViT-g (ape_deta_vitg_eva01_clip_lsj1536_cp_64x90k.py: the vit_eva_clip classes with packed qkv,
+    GELU MLP, no rope, PRE-norm, 40 x 1408 = 16 heads x 88, plain model family): parameterisation of the full-size model, and the host
+    composition at reduced size (head width 88 zero-padded to 128) vs the oracle and the reference-generated fixture"""
+    from ape_amd.modeling.build import build_ape
+
+    with torch.device("meta"):
+        big = build_ape("G_A")
+    sd = big.state_dict()
+    assert sd["model_vision.backbone.net.blocks.39.attn.qkv.weight"].shape == (3 * 1408, 1408)
+    assert sd["model_vision.backbone.net.blocks.0.mlp.fc1.weight"].shape == (6144, 1408)
+    assert not any("rope" in k or "q_proj" in k or "vl_layers" in k or "neck" in k for k in sd)
+    assert type(big.model_vision).__name__ == "DeformableDETRSegm"
+    model, orc, image, text, gold = M.build_pair("small_G")
+    own = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert own == {k: list(v) for k, v in U.load_spec("small_G")}                        # == the reference model's state_dict()
+    mv = model.model_vision
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    for k in ("p2", "p4", "p6", "enc_input", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact"):
+        b = M.token_major(k, orc.stages[k])
+        assert U.relerr(stages[k].reshape(b.shape), b) < 2e-4, k
+    assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance, vs the reference run
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+
+
 def test_mask_prompt_restricts_the_proposals(fake_ops):
     """deformable_detr_segm_vl.py:394-414 / deformable_transformer_vl.py:356-365: with a mask prompt only encoder tokens inside
     the prompted region may become proposals (anchors +inf, memory rows zero elsewhere) -- vs the reference-generated fixture, through

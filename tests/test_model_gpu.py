@@ -26,7 +26,7 @@ def _run(case, dtype):
     return model, orc, image.cuda(), text.cuda(), gold, image, text
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G"])
 def test_fp32_pipeline_matches_oracle_and_reference(case):
     """T1: every HIP kernel in its fp32 instantiation; tolerance = north_star's 1e-3 on logits / boxes"""
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.float32)
@@ -74,7 +74,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
     assert mm < 2e-3
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E"])
+@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "small_G"])
 def test_bf16_pipeline(case):
     """bf16 storage + MFMA, fp32 accumulate on the small models (all prompt modes): (a) every stage, fed the fp32 pipeline's
     input (teacher forcing), is inside the tolerance derived from bf16's 8 significant bits (tests/teacher_forced.py); (b) the

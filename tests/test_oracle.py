@@ -17,7 +17,8 @@ FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order
 # ambiguous heads, the EVA-02 MIM ViT with sub-LN (fixture produced by the reference's deformable_detr_segm.py / deformable_transformer.py)
 # small_E: APE on the ViT-e backbone (post-norm blocks, packed qkv, GELU MLP, head width 112) with 3 + 3 layers
 # tiny_maskprompt: a mask prompt restricts the proposals to the prompted region (and drives the selection into its fall-back list)
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt"])
+# small_G: the plain family on the EVA-01-CLIP ViT-g flavour (pre-norm, packed qkv, GELU MLP, head width 88)
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
