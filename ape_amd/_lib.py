@@ -80,7 +80,7 @@ SIGNATURES = {
                                  c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
     "ape_hip_head_gemv": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int,
-                                  c_void_p]),
+                                  c_int, c_void_p]),
     "ape_hip_attention_strided": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_int, c_float, c_int, c_void_p]),
     "ape_hip_attention_causal": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -129,7 +129,7 @@ SIGNATURES = {
     "ape_hip_det_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "ape_hip_ffn_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "ape_hip_resize_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int]),
     "ape_hip_resize_tile_rows": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "ape_hip_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

@@ -58,7 +58,8 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 
 // QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
-template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1>
+// H = bf16_t | f16_t: storage of q / k / v^T / o and of the probabilities handed to the P.V MFMA.
+template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1, typename H = bf16_t>
 __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p) {
   static_assert(HD == 32 || HD == 64 || (HD == 128 && PERM), "head dimension 32 / 64 / 128 (128: permuted key order only)");
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
   // per key tile off the VALU, which bounds this kernel.
   f32x4_t oacc[QT][DT], lacc[QT];
   float m_run[QT];
-  const uint32_t one2 = 0x3f803f80u;   // (1.0bf16, 1.0bf16)
+  const uint32_t one2 = h16<H>::dt == APE_DT_F16 ? 0x3c003c00u : 0x3f803f80u;   // (1.0, 1.0) in H
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, make_uint4(one2, one2, one2, one2));
 #pragma unroll
   for (int u = 0; u < QT; ++u) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
                        : (PERM && KC == 8) ? krow_ * 64 + (((ks * 4 + fq) ^ kperm_swz(krow_)) << 3) : swz_rows(krow_, ks * 4 + fq, KC);
         const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[koff]));
 #pragma unroll
-        for (int u = 0; u < QT; ++u) sacc[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[u][ks], sacc[u][i], 0, 0, 0);
+        for (int u = 0; u < QT; ++u) sacc[u][i] = h16<H>::mfma(kf, qf[u][ks], sacc[u][i]);
       }
     }
     // keys >= N only exist in the last tile
@@ -226,10 +227,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        pk[u][s2].x = pack2bf(pv[2 * s2][0], pv[2 * s2][1]);
-        pk[u][s2].y = pack2bf(pv[2 * s2][2], pv[2 * s2][3]);
-        pk[u][s2].z = pack2bf(pv[2 * s2 + 1][0], pv[2 * s2 + 1][1]);
-        pk[u][s2].w = pack2bf(pv[2 * s2 + 1][2], pv[2 * s2 + 1][3]);
+        pk[u][s2].x = h16<H>::pack2(pv[2 * s2][0], pv[2 * s2][1]);
+        pk[u][s2].y = h16<H>::pack2(pv[2 * s2][2], pv[2 * s2][3]);
+        pk[u][s2].z = h16<H>::pack2(pv[2 * s2 + 1][0], pv[2 * s2 + 1][1]);
+        pk[u][s2].w = h16<H>::pack2(pv[2 * s2 + 1][2], pv[2 * s2 + 1][3]);
       }
     }
     // O^T[d][query] += Vt[d][key] P^T[key][query]; k-step s covers score tiles 2s, 2s+1.  PERM: their accumulators are keys
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
     for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
       for (int u = 0; u < QT; ++u)
-        lacc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(bf16x8_t, pk[u][s2]), lacc[u], 0, 0, 0);
+        lacc[u] = h16<H>::mfma(ones, __builtin_bit_cast(bf16x8_t, pk[u][s2]), lacc[u]);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const int row = d * 16 + frow;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
         }
 #pragma unroll
         for (int u = 0; u < QT; ++u)
-          oacc[u][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vk), __builtin_bit_cast(bf16x8_t, pk[u][s2]), oacc[u][d], 0, 0, 0);
+          oacc[u][d] = h16<H>::mfma(__builtin_bit_cast(bf16x8_t, vk), __builtin_bit_cast(bf16x8_t, pk[u][s2]), oacc[u][d]);
       }
     }
     __syncthreads();                       // drains this wave's DMA of tile t + 1 (issued a whole tile ago) and releases `cur`
@@ -275,14 +276,14 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
         for (int dp = 0; dp < DT / 2; ++dp) {
           const float v[8] = {oacc[u][2 * dp][0] * inv, oacc[u][2 * dp][1] * inv, oacc[u][2 * dp][2] * inv, oacc[u][2 * dp][3] * inv,
                               oacc[u][2 * dp + 1][0] * inv, oacc[u][2 * dp + 1][1] * inv, oacc[u][2 * dp + 1][2] * inv, oacc[u][2 * dp + 1][3] * inv};
-          st8<bf16_t>(o + dp * 32, v);
+          st8<H>(reinterpret_cast<H*>(o + dp * 32), v);
         }
       } else {
         bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 4;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
-          st4<bf16_t>(o + d * 16, v);
+          st4<H>(reinterpret_cast<H*>(o + d * 16), v);
         }
       }
     }
@@ -359,6 +360,46 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
   }
 }
 
+template <typename H>
+static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, int bstride, int H_, int HD, int causal, hipStream_t s) {
+  const void* Q = p.Q; const void* K = p.K; const void* Vt = p.Vt; void* O = p.O;
+  const int ldq = p.ldq, ldk = p.ldk, ldvt = p.ldvt, ldo = p.ldo;
+  const int nheads = H_;
+  APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "ape_hip_attention(bf16): ld alignment");
+  APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 16 == 0,
+                "ape_hip_attention(bf16): pointer alignment");
+  APE_CHECK_ARG(B == 1 || bstride % 8 == 0, "ape_hip_attention(bf16): batched windows need a batch stride %% 8 == 0");
+  // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
+  const bool big = (size_t)ceil_div(N, 128) * nheads * B >= 512;
+  if (big) grid.x = ceil_div(N, 128);
+  static const bool natural = getenv("APE_ATTN_NATURAL_KEY_ORDER") != nullptr;     // A/B: the round-2 kernel (two b64 V halves, LDS shuffles)
+  if (causal) {
+    APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
+    if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true, true, 1, H>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true, true, 1, H>), grid, dim3(256), 0, s, p);
+  } else if (HD == 128) {           // ViT-e (head width 112 zero-padded to 128 by the packing)
+    if (big) hipLaunchKernelGGL((attn_bf16_kernel<128, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<128, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
+  } else if (natural) {
+    if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
+    else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
+  } else if (HD == 64) {
+    static const bool occ4 = getenv("APE_ATTN_OCC4") != nullptr;       // A/B: cap the 128-query kernel at 128 registers (4 waves per SIMD)
+    // 256 queries per workgroup (4 query tiles per wave: every K / V^T fragment read from LDS feeds four MFMAs) when that still
+    // leaves two workgroups per CU -- the 2-image ViT pass: 2 x 16 heads x 16 blocks (global), 8 windows x 16 heads x 4 blocks
+    const char* qt4_env = getenv("APE_ATTN_QT4");
+    const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : false) && (size_t)ceil_div(N, 256) * nheads * B >= 512;
+    if (qt4) {
+      grid.x = ceil_div(N, 256);
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 4, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    } else if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4, H>), grid, dim3(256), 0, s, p);
+    else if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
+  }
+  else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, true, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, true, 1, H>), grid, dim3(256), 0, s, p); }
+  return 0;
+}
+
 static int attention_launch(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int B, int N,
                             int bstride, int H, int HD, float scale, int dt, int causal, void* stream) {
   APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
@@ -370,39 +411,10 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
   p.causal = causal;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(N, 64), H, B);
-  if (dt == APE_DT_BF16) {
-    APE_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0, "ape_hip_attention(bf16): ld alignment");
-    APE_CHECK_ARG(((uintptr_t)Q) % 16 == 0 && ((uintptr_t)K) % 16 == 0 && ((uintptr_t)Vt) % 16 == 0 && ((uintptr_t)O) % 16 == 0,
-                  "ape_hip_attention(bf16): pointer alignment");
-    APE_CHECK_ARG(B == 1 || bstride % 8 == 0, "ape_hip_attention(bf16): batched windows need a batch stride %% 8 == 0");
-    // 128 queries per workgroup when that still leaves >= 2 workgroups per CU; 64 otherwise (decoder: 900 queries x 8 heads)
-    const bool big = (size_t)ceil_div(N, 128) * H * B >= 512;
-    if (big) grid.x = ceil_div(N, 128);
-    static const bool natural = getenv("APE_ATTN_NATURAL_KEY_ORDER") != nullptr;     // A/B: the round-2 kernel (two b64 V halves, LDS shuffles)
-    if (causal) {
-      APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
-      if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true>), grid, dim3(256), 0, s, p);
-    } else if (HD == 128) {           // ViT-e (head width 112 zero-padded to 128 by the packing)
-      if (big) hipLaunchKernelGGL((attn_bf16_kernel<128, 2>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_bf16_kernel<128, 1>), grid, dim3(256), 0, s, p);
-    } else if (natural) {
-      if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false>), grid, dim3(256), 0, s, p); }
-      else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false>), grid, dim3(256), 0, s, p); }
-    } else if (HD == 64) {
-      static const bool occ4 = getenv("APE_ATTN_OCC4") != nullptr;       // A/B: cap the 128-query kernel at 128 registers (4 waves per SIMD)
-      // 256 queries per workgroup (4 query tiles per wave: every K / V^T fragment read from LDS feeds four MFMAs) when that still
-      // leaves two workgroups per CU -- the 2-image ViT pass: 2 x 16 heads x 16 blocks (global), 8 windows x 16 heads x 4 blocks
-      const char* qt4_env = getenv("APE_ATTN_QT4");
-      const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : false) && (size_t)ceil_div(N, 256) * H * B >= 512;
-      if (qt4) {
-        grid.x = ceil_div(N, 256);
-        hipLaunchKernelGGL((attn_bf16_kernel<64, 4>), grid, dim3(256), 0, s, p);
-      } else if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4>), grid, dim3(256), 0, s, p);
-      else if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((attn_bf16_kernel<64, 1>), grid, dim3(256), 0, s, p);
-    }
-    else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1>), grid, dim3(256), 0, s, p); }
+  if (ape_is16(dt)) {
+    const int rc = dt == APE_DT_F16 ? attention_launch_h16<f16_t>(p, grid, B, N, bstride, H, HD, causal, s)
+                                    : attention_launch_h16<bf16_t>(p, grid, B, N, bstride, H, HD, causal, s);
+    if (rc != 0) return rc;
   } else {
     if (HD == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
     else if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);

@@ -47,6 +47,7 @@ extern "C" int ape_hip_box_refine(const float* delta, int ldd, const float* ref,
 template <typename T> __device__ __forceinline__ float round_to(float v);
 template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
 template <> __device__ __forceinline__ float round_to<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float round_to<f16_t>(float v) { return (float)(f16_t)sat_h(v); }
 
 template <typename TO>
 __global__ __launch_bounds__(256) void query_init_kernel(const float* __restrict__ coords, const int64_t* __restrict__ topk, int T,
@@ -71,12 +72,12 @@ extern "C" int ape_hip_query_init(const float* coords, const int64_t* topk, int 
                                   float* reference, void* pe, int ldpe, int pe_dt, int32_t* topk32, void* stream) {
   APE_CHECK_ARG(coords && topk && dim_t && reference && pe && T > 0 && P > 0 && Q > 0 && ldpe >= 4 * P, "ape_hip_query_init: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (pe_dt == APE_DT_BF16)
-    hipLaunchKernelGGL(query_init_kernel<bf16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (bf16_t*)pe, ldpe, topk32);
+  if (pe_dt == APE_DT_F16) hipLaunchKernelGGL(query_init_kernel<f16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (f16_t*)pe, ldpe, topk32);
+  else if (pe_dt == APE_DT_BF16) hipLaunchKernelGGL(query_init_kernel<bf16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (bf16_t*)pe, ldpe, topk32);
   else if (pe_dt == APE_DT_F32)
     hipLaunchKernelGGL(query_init_kernel<float>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (float*)pe, ldpe, topk32);
   else
-    APE_CHECK_ARG(false, "ape_hip_query_init: pe must be f32 or bf16");
+    APE_CHECK_ARG(false, "ape_hip_query_init: pe must be f32, bf16 or f16");
   APE_CHECK_LAUNCH("ape_hip_query_init");
   return 0;
 }
@@ -135,14 +136,15 @@ extern "C" int ape_hip_query_finish(const float* pos, int ldpos, const float* pi
   APE_CHECK_ARG(E > 0 && E <= 512 && E % 64 == 0 && ldpos >= 2 * E && ldpix >= E && ldo >= E, "ape_hip_query_finish: E must be a multiple of 64, <= 512");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ceil_div(Q, 4)), block(256);
-  if (out_dt == APE_DT_BF16)
-    hipLaunchKernelGGL(query_finish_kernel<bf16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
+  if (out_dt == APE_DT_F16) hipLaunchKernelGGL(query_finish_kernel<f16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
+                       (f16_t*)query_pos, (f16_t*)query, (f16_t*)query_sum, ldo);
+  else if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(query_finish_kernel<bf16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
                        (bf16_t*)query_pos, (bf16_t*)query, (bf16_t*)query_sum, ldo);
   else if (out_dt == APE_DT_F32)
     hipLaunchKernelGGL(query_finish_kernel<float>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
                        (float*)query_pos, (float*)query, (float*)query_sum, ldo);
   else
-    APE_CHECK_ARG(false, "ape_hip_query_finish: outputs must be f32 or bf16");
+    APE_CHECK_ARG(false, "ape_hip_query_finish: outputs must be f32, bf16 or f16");
   APE_CHECK_LAUNCH("ape_hip_query_finish");
   return 0;
 }

@@ -34,7 +34,11 @@ template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p =
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
 template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t* p) { return (float)*p; }
-template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, float v) { *p = (f16_t)v; }
+// every float -> IEEE half store SATURATES at +-65504 (v_med3_f32; a NaN stays a NaN): the half flavour of the pipeline
+// (GEMM operands, activations) must not turn an outlier into an infinity that the next contraction spreads over a row
+#define APE_HALF_MAX 65504.f
+__device__ __forceinline__ float sat_h(float v) { return __builtin_amdgcn_fmed3f(v, -APE_HALF_MAX, APE_HALF_MAX); }
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, float v) { *p = (f16_t)sat_h(v); }
 
 // 4 consecutive elements (p must be aligned to 4 elements)
 template <typename T> __device__ __forceinline__ void ld4(const T* p, float v[4]);
@@ -83,7 +87,7 @@ template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float v
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 // round-to-nearest-even pair conversion (same rule as torch's float -> half cast)
 __device__ __forceinline__ uint32_t pack2h(float a, float b) {
-  const f32x2_t v = {a, b};
+  const f32x2_t v = {sat_h(a), sat_h(b)};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
 }
 template <> __device__ __forceinline__ void ld4<f16_t>(const f16_t* p, float v[4]) {
@@ -95,10 +99,35 @@ template <> __device__ __forceinline__ void st4<f16_t>(f16_t* p, const float v[4
   *reinterpret_cast<uint2*>(p) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
 }
 template <> __device__ __forceinline__ void st8<f16_t>(f16_t* p, const float v[8]) {
-  f16x8_t t;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) t[i] = (f16_t)v[i];
-  *reinterpret_cast<f16x8_t*>(p) = t;
+  *reinterpret_cast<uint4*>(p) = make_uint4(pack2h(v[0], v[1]), pack2h(v[2], v[3]), pack2h(v[4], v[5]), pack2h(v[6], v[7]));
+}
+
+// ---- the two 16-bit flavours of the pipeline: H = bf16_t (8 significant bits, fp32 range) | f16_t (11 bits, the reference's
+// own evaluation dtype: tools/train_net.py:642 model.to(torch.float16)).  Same data movement, same MFMA rate
+// (v_mfma_f32_16x16x32_{bf16,f16}); kernels are templated on H and every 16-bit operand of ONE call has the same H.
+template <typename H> struct h16;
+template <> struct h16<bf16_t> {
+  static constexpr int dt = APE_DT_BF16;
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2bf(a, b); }
+  static __device__ __forceinline__ f32x4_t mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct h16<f16_t> {
+  static constexpr int dt = APE_DT_F16;
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return pack2h(a, b); }
+  static __device__ __forceinline__ f32x4_t mfma(bf16x8_t a, bf16x8_t b, f32x4_t c) {   // fragments travel as raw 16 bytes
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+// two packed 16-bit values -> two floats
+template <typename H> __device__ __forceinline__ void unpack2(uint32_t u, float& a, float& b);
+template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t u, float& a, float& b) {
+  a = __uint_as_float(u << 16); b = __uint_as_float(u & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void unpack2<f16_t>(uint32_t u, float& a, float& b) {
+  const f16x2_t t = __builtin_bit_cast(f16x2_t, u);
+  a = (float)t[0]; b = (float)t[1];
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -132,3 +161,17 @@ void ape_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline bool ape_is16(int dt) { return dt == APE_DT_BF16 || dt == APE_DT_F16; }
+// the 16-bit storage kind of one call: 0 = none of the dtypes is 16-bit, APE_DT_BF16 / APE_DT_F16, -1 = mixed or unknown
+static inline int ape_h16_kind(const int* dts, int n) {
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    const int d = dts[i];
+    if (d == APE_DT_F32) continue;
+    if (!ape_is16(d)) return -1;
+    if (k != 0 && k != d) return -1;
+    k = d;
+  }
+  return k;
+}
+#define APE_H16_KIND(...) ([&]() { const int d__[] = {__VA_ARGS__}; return ape_h16_kind(d__, (int)(sizeof(d__) / sizeof(int))); }())

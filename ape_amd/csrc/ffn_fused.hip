@@ -63,7 +63,8 @@ __device__ __forceinline__ float ff_rows_sum(float v) {
 // RT = 16-row token tiles per wave (2 | 3): a workgroup covers 64 RT rows.  The chunk time is set by the LDS-DMA bytes a CU can keep in
 // flight (one 64 KB chunk ahead: ~2.3 us per chunk whatever the MFMA count, measured), so rows per workgroup is the lever: RT = 3
 // does 1.5 x the MFMAs per streamed weight byte.  One wave per SIMD owns the whole 512-entry register file: RT = 3 uses ~460 of it.
-template <bool W2P, int RT>
+// H = bf16_t | f16_t: the storage type of x / weights / residual / y and of the hidden activation between the two contractions.
+template <bool W2P, int RT, typename H = bf16_t>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sb1 = reinterpret_cast<float*>(smem + 2 * FF_STAGE);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) hacc[ht][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[ks], xf[rt][ks], hacc[ht][rt], 0, 0, 0);
+        for (int rt = 0; rt < RT; ++rt) hacc[ht][rt] = h16<H>::mfma(f[ks], xf[rt][ks], hacc[ht][rt]);
     };
     bf16x8_t hb[2][RT];                                                                 // [kk][rt]: the activations as B operands
     auto act = [&](int ht) __attribute__((always_inline)) {
@@ -211,9 +212,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     auto pack = [&](int kk) __attribute__((always_inline)) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const uint4 u = make_uint4(pack2bf(hacc[2 * kk][rt][0], hacc[2 * kk][rt][1]), pack2bf(hacc[2 * kk][rt][2], hacc[2 * kk][rt][3]),
-                                   pack2bf(hacc[2 * kk + 1][rt][0], hacc[2 * kk + 1][rt][1]),
-                                   pack2bf(hacc[2 * kk + 1][rt][2], hacc[2 * kk + 1][rt][3]));
+        const uint4 u = make_uint4(h16<H>::pack2(hacc[2 * kk][rt][0], hacc[2 * kk][rt][1]), h16<H>::pack2(hacc[2 * kk][rt][2], hacc[2 * kk][rt][3]),
+                                   h16<H>::pack2(hacc[2 * kk + 1][rt][0], hacc[2 * kk + 1][rt][1]),
+                                   h16<H>::pack2(hacc[2 * kk + 1][rt][2], hacc[2 * kk + 1][rt][3]));
         hb[kk][rt] = __builtin_bit_cast(bf16x8_t, u);
       }
     };
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       for (int j = 0; j < 8; ++j)
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
-          yacc[og * 8 + j][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[j], hb[kk][rt], yacc[og * 8 + j][rt], 0, 0, 0);
+          yacc[og * 8 + j][rt] = h16<H>::mfma(f[j], hb[kk][rt], yacc[og * 8 + j][rt]);
     };
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
     // ---- H^T = W1c . x^T (4 hidden tiles x 2 token tiles x 8 k steps), then Y^T += W2c . H^T (k step kk = hidden tiles 2kk, 2kk + 1,
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
       v[q * 8 + 6] = yacc[2 * q + 1][rt][2] + bb.z; v[q * 8 + 7] = yacc[2 * q + 1][rt][3] + bb.w;
       if (rp != nullptr) {
         float r[8];
-        ld8<bf16_t>(rp + q * 32, r);
+        ld8<H>(reinterpret_cast<const H*>(rp + q * 32), r);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[q * 8 + e] += r[e];
       }
@@ -305,15 +306,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnParams p) {
     if (tok[rt] < p.M) {
       bf16_t* yp = p.Y + (size_t)tok[rt] * p.ldy + g * 8;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) st8<bf16_t>(yp + q * 32, v + q * 8);
+      for (int q = 0; q < 8; ++q) st8<H>(reinterpret_cast<H*>(yp + q * 32), v + q * 8);
     }
   }
 }
 
 extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
-                                 const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted,
+                                 const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted, int dt,
                                  const float* ln_weight, const float* ln_bias, float ln_eps, void* stream) {
   APE_CHECK_ARG(X && W1 && b1 && W2 && b2 && Y && M > 0, "ape_hip_ffn_fused: null pointer / empty problem");
+  APE_CHECK_ARG(ape_is16(dt), "ape_hip_ffn_fused: dt must be APE_DT_BF16 or APE_DT_F16 (got %d)", dt);
   APE_CHECK_ARG(K == FF_K && N == FF_N && HID % FF_HC == 0 && HID >= FF_HC && HID <= 4096,
                 "ape_hip_ffn_fused: the kernel is built for 256 -> HID -> 256 with HID %% 64 == 0, HID <= 4096 (got %d -> %d -> %d)", K, HID, N);
   APE_CHECK_ARG(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldy % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
@@ -329,19 +331,24 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
                 "ape_hip_ffn_fused: LayerNorm weight and bias come together, 16-byte aligned");
   p.ln_w = ln_weight; p.ln_b = ln_bias; p.ln_eps = ln_eps;
   const size_t lds = 2 * FF_STAGE + (size_t)(HID + FF_N) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
   // 192-row workgroups once they still give every CU at least one (the weights stream once per workgroup); APE_FFN_RT=2|3 overrides (A/B)
   const char* rt_env = getenv("APE_FFN_RT");
   const int rt = rt_env != nullptr ? atoi(rt_env) : (ceil_div(M, 192) >= 256 ? 3 : 2);
-  if (w2_permuted && rt == 3) hipLaunchKernelGGL((ffn_fused_kernel<true, 3>), dim3(ceil_div(M, 192)), dim3(256), lds, (hipStream_t)stream, p);
-  else if (w2_permuted) hipLaunchKernelGGL((ffn_fused_kernel<true, 2>), dim3(ceil_div(M, 128)), dim3(256), lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((ffn_fused_kernel<false, 2>), dim3(ceil_div(M, 128)), dim3(256), lds, (hipStream_t)stream, p);
+#define FF_LAUNCH(W2P_, RT_, H_)                                                                                              \
+  do {                                                                                                                        \
+    static bool attr__ = false;                                                                                               \
+    if (!attr__) {                                                                                                            \
+      (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<W2P_, RT_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr__ = true;                                                                                                          \
+    }                                                                                                                         \
+    hipLaunchKernelGGL((ffn_fused_kernel<W2P_, RT_, H_>), dim3(ceil_div(M, 64 * RT_)), dim3(256), lds, (hipStream_t)stream, p); \
+  } while (0)
+  if (dt == APE_DT_F16) {
+    if (w2_permuted && rt == 3) FF_LAUNCH(true, 3, f16_t); else if (w2_permuted) FF_LAUNCH(true, 2, f16_t); else FF_LAUNCH(false, 2, f16_t);
+  } else {
+    if (w2_permuted && rt == 3) FF_LAUNCH(true, 3, bf16_t); else if (w2_permuted) FF_LAUNCH(true, 2, bf16_t); else FF_LAUNCH(false, 2, bf16_t);
+  }
+#undef FF_LAUNCH
   APE_CHECK_LAUNCH("ffn_fused_kernel");
   return 0;
 }

@@ -31,7 +31,7 @@ __device__ __forceinline__ int swz128(int row, int c) {  // 128-byte rows (8 chu
   return row * 64 + ((c ^ ((row >> 1) & 7)) << 3);
 }
 
-template <bool TRANS>
+template <bool TRANS, typename H = bf16_t>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][GB_M * GB_K];  // [buf][A|W] 64 KiB
 
@@ -114,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          if (TRANS) acc[i][j] = h16<H>::mfma(af[i], wf[j], acc[i][j]);
+          else acc[i][j] = h16<H>::mfma(wf[j], af[i], acc[i][j]);
         }
     }
   };
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (TRANS) {
         // D[i = m_local = fq*4 + r][j = n_local = frow]
-        epi_m4(p, m0 + wm * 64 + i * 16 + fq * 4, n0 + wn * 64 + j * 16 + frow, v);
+        epi_m4<H>(p, m0 + wm * 64 + i * 16 + fq * 4, n0 + wn * 64 + j * 16 + frow, v);
       } else {
         // D[i = n_local = fq*4 + r][j = m_local = frow]
-        epi_n4(p, m0 + wm * 64 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, v);
+        epi_n4<H>(p, m0 + wm * 64 + i * 16 + frow, n0 + wn * 64 + j * 16 + fq * 4, v);
       }
     }
 }
@@ -164,7 +164,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 // LDS-staged epilogue shared by the MFMA kernels: tile [128 rows][tcols], pitch + 16 B, then 16-byte row chunks
-template <bool TRANS, int TM = 4, int TN = 4>
+template <bool TRANS, int TM = 4, int TN = 4, typename H = bf16_t>
 __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&acc)[TM][TN], unsigned char* smem_raw, int m0, int n0,
                                                  int tid, int wm, int wn, int frow, int fq) {
   constexpr int BM = 32 * TM, BN = 32 * TN;   // block tile; each of the 2x2 waves owns (16*TM) x (16*TN)
@@ -191,7 +191,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&
         const int m = m0 + wm * (16 * TM) + i * 16 + frow, nn = n0 + wn * (16 * TN) + j * 16 + fq * 4;
         if (m >= p.M || nn >= p.N) continue;
         int ocol;
-        epi_n4_values(p, m, nn, v, ocol, cnt);
+        epi_n4_values<H>(p, m, nn, v, ocol, cnt);
         lrow = wm * (16 * TM) + i * 16 + frow; lcol = ocol - ocol0; cnt = swiglu ? 2 : 4;
       }
       unsigned char* dst = tile + lrow * pitch + lcol * esz;
@@ -199,8 +199,8 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&
         if (cnt == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
       } else {
-        if (cnt == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-        else *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+        if (cnt == 4) *reinterpret_cast<uint2*>(dst) = make_uint2(h16<H>::pack2(v[0], v[1]), h16<H>::pack2(v[2], v[3]));
+        else *reinterpret_cast<uint32_t*>(dst) = h16<H>::pack2(v[0], v[1]);
       }
     }
   __syncthreads();
@@ -237,7 +237,7 @@ __device__ __forceinline__ void epilogue_via_lds(const GemmParams& p, f32x4_t (&
 #define GR_STAGES 4
 __device__ __forceinline__ int swz64(int row, int c) { return row * 32 + ((c ^ (((row >> 3) & 1) << 1)) << 3); }
 
-template <bool TRANS, int TM, int TN>
+template <bool TRANS, int TM, int TN, typename H = bf16_t>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams p) {
   constexpr int BM = 32 * TM, BN = 32 * TN;           // 128x128 (TM=TN=4) or 64x64 (TM=TN=2) block tile
   constexpr int STAGE = (BM + BN) * GR_K;              // elements per LDS stage: A [BM][32] | W [BN][32]
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        if (TRANS) acc[i][j] = h16<H>::mfma(af[i], wf[j], acc[i][j]);
+        else acc[i][j] = h16<H>::mfma(wf[j], af[i], acc[i][j]);
       }
   };
   // Opaque "use" of a fragment set: hipcc places the lgkmcnt wait for these registers HERE (before the barrier and
@@ -388,13 +388,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_ring_kernel(const GemmParams
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    epilogue_via_lds<TRANS, TM, TN>(q, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
+    epilogue_via_lds<TRANS, TM, TN, H>(q, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
     return;
   }
-  epilogue_via_lds<TRANS, TM, TN>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
+  epilogue_via_lds<TRANS, TM, TN, H>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
 }
 
 // sum the split-K partial planes and apply the full epilogue; one thread per 4 consecutive columns
+template <typename H = bf16_t>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
   const int ngrp = (p.N + 3) / 4;
   const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -412,10 +413,10 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
       for (int r = 0; r < 4 && n0 + r < p.N; ++r) v[r] += src[s * plane + r];
     }
   }
-  epi_n4(p, m, n0, v);
+  epi_n4<H>(p, m, n0, v);
 }
 
-template <bool TRANS, bool GLDS>
+template <bool TRANS, bool GLDS, typename H = bf16_t>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];   // GEMM_V2_LDS bytes
   bf16_t (*smem)[2][GB_M * GB_K] = reinterpret_cast<bf16_t (*)[2][GB_M * GB_K]>(smem_raw);  // [buf][A|W] 64 KiB
@@ -517,8 +518,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (TRANS) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+          if (TRANS) acc[i][j] = h16<H>::mfma(af[i], wf[j], acc[i][j]);
+          else acc[i][j] = h16<H>::mfma(wf[j], af[i], acc[i][j]);
         }
     }
   };
@@ -535,13 +536,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_v2_kernel(const GemmParams p
     __syncthreads();
   }
 
-  epilogue_via_lds<TRANS>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
+  epilogue_via_lds<TRANS, 4, 4, H>(p, acc, smem_raw, m0, n0, tid, wm, wn, frow, fq);
 }
 
 // ------------------------------------------------------------------------------------------
 // f32 kernel (validation mode): 64x64x16 tile, 256 threads, 4x4 outputs / thread
 // ------------------------------------------------------------------------------------------
-template <bool TRANS>
+template <bool TRANS, typename H = bf16_t>   // H: what a 2-byte output / residual of this fp32-operand launch holds
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
   __shared__ float sA[16][64 + 4];
   __shared__ float sW[16][64 + 4];
@@ -586,11 +587,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
-      epi_m4(p, m0 + ty * 4, n0 + tx * 4 + j, v);
+      epi_m4<H>(p, m0 + ty * 4, n0 + tx * 4 + j, v);
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) epi_n4(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
+    for (int i = 0; i < 4; ++i) epi_n4<H>(p, m0 + ty * 4 + i, n0 + tx * 4, acc[i]);
   }
 }
 
@@ -658,8 +659,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int RES /*0 none, 1 bf16 (2 = f32: compiles, spills, not instantiated)*/, bool OUT_F32, bool OUT_F16 = false /* 2-byte output is IEEE half */>
+template <int RES /*0 none, 1 = 16-bit H (2 = f32: compiles, spills, not instantiated)*/, bool OUT_F32, bool OUT_F16 = false /* 2-byte output is IEEE half */,
+          typename H = bf16_t /* operand / residual storage */>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams p) {
+  typedef typename std::conditional<OUT_F16, f16_t, H>::type HO;             // what a 2-byte output holds
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* ring = reinterpret_cast<bf16_t*>(smem_raw);                     // 4 stages x [128][64] bf16 (swz128 image)
   float* sbias = reinterpret_cast<float*>(smem_raw + 4 * 16384);          // bias of this block's column range
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
-          acc[mi][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[mi][ks * 2 + kk], acc[mi][jb + j], 0, 0, 0);
+          acc[mi][jb + j] = h16<H>::mfma(wf[j], af[mi][ks * 2 + kk], acc[mi][jb + j]);
     };
     bf16x8_t w0[4], w1[4];
     rd(0, w0);
@@ -820,20 +823,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
           if (RES == 1) {
             const uint4 u = rres[RES == 0 ? 0 : mi][jp];
             const uint32_t lo = h == 0 ? u.x : u.z, hi = h == 0 ? u.y : u.w;
-            rv[0] = __uint_as_float(lo << 16); rv[1] = __uint_as_float(lo & 0xffff0000u);
-            rv[2] = __uint_as_float(hi << 16); rv[3] = __uint_as_float(hi & 0xffff0000u);
+            unpack2<H>(lo, rv[0], rv[1]);
+            unpack2<H>(hi, rv[2], rv[3]);
           }
           finish(mode_tag, acc[mi][j], b, rv, mi, v[h]);
         }
         if (OUT_F32) {
           *reinterpret_cast<float4*>(cp + jp * 128) = make_float4(v[0][0], v[0][1], v[0][2], v[0][3]);
           *reinterpret_cast<float4*>(cp + jp * 128 + 16) = make_float4(v[1][0], v[1][1], v[1][2], v[1][3]);
-        } else if (OUT_F16) {
-          *reinterpret_cast<uint4*>(cp + jp * 64) = make_uint4(pack2h(v[0][0], v[0][1]), pack2h(v[0][2], v[0][3]),
-                                                               pack2h(v[1][0], v[1][1]), pack2h(v[1][2], v[1][3]));
         } else {
-          *reinterpret_cast<uint4*>(cp + jp * 64) = make_uint4(pack2bf(v[0][0], v[0][1]), pack2bf(v[0][2], v[0][3]),
-                                                               pack2bf(v[1][0], v[1][1]), pack2bf(v[1][2], v[1][3]));
+          *reinterpret_cast<uint4*>(cp + jp * 64) = make_uint4(h16<HO>::pack2(v[0][0], v[0][1]), h16<HO>::pack2(v[0][2], v[0][3]),
+                                                               h16<HO>::pack2(v[1][0], v[1][1]), h16<HO>::pack2(v[1][2], v[1][3]));
         }
         __builtin_amdgcn_sched_barrier(0);    // one 8-column piece at a time: keeps the live set small (no spills)
       }
@@ -848,12 +848,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
         if (m >= p.M || n >= p.N) continue;          // N % 4 == 0 (launcher), so a quad is all in or all out
         const float4 b = *reinterpret_cast<const float4*>(sbias + ncol);
         float rv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (RES == 1) ld4<bf16_t>(reinterpret_cast<const bf16_t*>(p.residual) + (size_t)m * p.ldr + n, rv);
+        if (RES == 1) ld4<H>(reinterpret_cast<const H*>(p.residual) + (size_t)m * p.ldr + n, rv);
         float v[4];
         finish(std::integral_constant<int, 2>{}, acc[mi][j], b, rv, mi, v);
         if (OUT_F32) st4<float>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v);
-        else if (OUT_F16) st4<f16_t>(reinterpret_cast<f16_t*>(p.C) + (size_t)m * p.ldc + n, v);
-        else st4<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, v);
+        else st4<HO>(reinterpret_cast<HO*>(p.C) + (size_t)m * p.ldc + n, v);
       }
   };
 
@@ -906,23 +905,132 @@ static thread_local const char* g_last_gemm_kernel = "";
 extern "C" const char* ape_hip_gemm_last_kernel(void) { return g_last_gemm_kernel; }
 #define LAUNCH_GEMM(NAME, KERNEL, GRID, LDS) do { g_last_gemm_kernel = NAME; hipLaunchKernelGGL(KERNEL, GRID, dim3(256), LDS, s, p); } while (0)
 
+// 16-bit operand launches (H = bf16_t | f16_t): tile selection is the same for both flavours
+template <typename H>
+static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
+  APE_CHECK_ARG(p.K % 8 == 0, "ape_hip_gemm(bf16): K=%d must be a multiple of 8 (pad the operands)", p.K);
+  APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
+  APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
+  const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);
+  const int nblk64 = ceil_div(p.M, 64) * ceil_div(p.N, 64);
+  static const int force_v1 = getenv("APE_GEMM_V1") ? atoi(getenv("APE_GEMM_V1")) : 0;
+  static const int no_glds = getenv("APE_GEMM_NOGLDS") ? atoi(getenv("APE_GEMM_NOGLDS")) : 0;
+  const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+  // v2's LDS-staged epilogue writes 16-byte chunks of output rows
+  const bool v2_ok = !force_v1 && ((size_t)p.ldc * esz) % 16 == 0 && ((uintptr_t)p.C) % 16 == 0 &&
+                     (p.act != APE_ACT_SWIGLU || p.N % 4 == 0);
+  const bool glds = v2_ok && !no_glds && p.K % GB_K == 0;
+  static const int no_ring = getenv("APE_GEMM_NORING") ? atoi(getenv("APE_GEMM_NORING")) : 0;
+  const char* ring_env = getenv("APE_GEMM_RING");     // read per call so a probe can flip it
+  const int use_ring_always = ring_env ? atoi(ring_env) : 0;
+  const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
+  if (p.tile64 == 3 || p.tile64 == 4) {
+    // 256 x 256 / 256 x 128 eight-wave tiles with the counted-wait pipeline (gemm_p8.hip); falls back when unsupported
+    const char* st_env = getenv("APE_GEMM_P8_STAGGER");
+    const int stagger = st_env ? atoi(st_env) : 1;
+    const char* name = ape_gemm_p8_launch(p, p.tile64 == 3 ? 256 : 128, stagger, s);
+    if (name != nullptr) {
+      g_last_gemm_kernel = name;
+      return 0;
+    }
+    p.tile64 = 0;
+  }
+  constexpr bool HF = h16<H>::dt == APE_DT_F16;
+  APE_CHECK_ARG(HF || v2_ok || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output needs 16-byte aligned output rows");
+  if (v2_ok) {
+    static bool attr_done = false;
+    if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<true, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
+      attr_done = true;
+    }
+    const char* nk_env = getenv("APE_GEMM_NOKRES");     // read per call so a probe can flip it
+    const int no_kres = nk_env ? atoi(nk_env) : 0;
+    const bool kres = !no_kres && !no_glds && p.K == 256 && p.rowscale == nullptr && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
+                      p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr && p.splitk <= 1 && p.ldc % 8 == 0 &&
+                      (p.residual == nullptr || (p.res_dt == h16<H>::dt && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
+    APE_CHECK_ARG(HF || kres || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output is only produced by the K == 256 kernel (disabled by the environment?)");
+    if (kres) {
+      static bool kattr = false;
+      if (!kattr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
+        kattr = true;
+      }
+      const int mblk = ceil_div(p.M, KR_BM);
+      const int nch = ceil_div(p.N, KR_CH);
+      int ysplit = ceil_div(nch, KR_MAXN / KR_CH);                  // bias slab in LDS holds KR_MAXN columns
+      while (mblk * ysplit < 512 && ysplit * 2 <= nch) ysplit *= 2;   // few row blocks: spread the column chunks as well
+      const dim3 grid(mblk, ysplit);
+      const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
+      const bool of32 = p.out_dt == APE_DT_F32;
+      if (!HF && p.out_dt == APE_DT_F16) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false, true>", (gemm_bf16_kres_kernel<0, false, true, H>), grid, KR_LDS);
+      else if (!res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false>", (gemm_bf16_kres_kernel<0, false, false, H>), grid, KR_LDS);
+      else if (res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<1, false>", (gemm_bf16_kres_kernel<1, false, false, H>), grid, KR_LDS);
+      else if (!res) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, true>", (gemm_bf16_kres_kernel<0, true, false, H>), grid, KR_LDS);
+      else LAUNCH_GEMM("gemm_bf16_kres_kernel<1, true>", (gemm_bf16_kres_kernel<1, true, false, H>), grid, KR_LDS);
+    } else if (p.splitk > 1) {
+      APE_CHECK_ARG(ring && !p.trans_out && p.workspace != nullptr && p.act != APE_ACT_SWIGLU,
+                    "ape_hip_gemm: split-K needs bf16, K %% 32 == 0, no trans_out / SwiGLU, and a workspace");
+      APE_CHECK_ARG(p.N % 4 == 0 && ((uintptr_t)p.workspace) % 16 == 0, "ape_hip_gemm: split-K needs N %% 4 == 0 and an aligned workspace");
+      if (p.tile64 == 2) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2, H>), dim3(ceil_div(p.M, 128) * ceil_div(p.N, 64), p.splitk), GEMM_T128x64_LDS);
+      else if (p.tile64) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2, H>), dim3(nblk64, p.splitk), GEMM_T64_LDS);
+      else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4, H>), dim3(nblk, p.splitk), GEMM_V2_LDS);
+      const size_t groups = (size_t)p.M * ((p.N + 3) / 4);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<H>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
+    } else if (ring && p.tile64 == 2 && !p.trans_out) {
+      // 128 x 64 tiles: twice the workgroups of a 128 x 128 tiling at 3/4 of its operand traffic per flop
+      const int nblk_mn = ceil_div(p.M, 128) * ceil_div(p.N, 64);
+      LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2, H>), dim3(nblk_mn), GEMM_T128x64_LDS);
+    } else if (ring && p.tile64) {
+      if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 2, 2>", (gemm_bf16_ring_kernel<true, 2, 2, H>), dim3(nblk64), GEMM_T64_LDS);
+      else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2, H>), dim3(nblk64), GEMM_T64_LDS);
+    } else if (ring && (use_ring_always || nblk < 64)) {
+      if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 4, 4>", (gemm_bf16_ring_kernel<true, 4, 4, H>), dim3(nblk), GEMM_V2_LDS);
+      else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4, H>), dim3(nblk), GEMM_V2_LDS);
+    } else if (p.trans_out) {
+      if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<true, true>", (gemm_bf16_v2_kernel<true, true, H>), dim3(nblk), GEMM_V2_LDS);
+      else LAUNCH_GEMM("gemm_bf16_v2_kernel<true, false>", (gemm_bf16_v2_kernel<true, false, H>), dim3(nblk), GEMM_V2_LDS);
+    } else {
+      if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<false, true>", (gemm_bf16_v2_kernel<false, true, H>), dim3(nblk), GEMM_V2_LDS);
+      else LAUNCH_GEMM("gemm_bf16_v2_kernel<false, false>", (gemm_bf16_v2_kernel<false, false, H>), dim3(nblk), GEMM_V2_LDS);
+    }
+  } else if (p.trans_out) LAUNCH_GEMM("gemm_bf16_kernel<true>", (gemm_bf16_kernel<true, H>), dim3(nblk), 0);
+  else LAUNCH_GEMM("gemm_bf16_kernel<false>", (gemm_bf16_kernel<false, H>), dim3(nblk), 0);
+  return 0;
+}
+
 extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(a != nullptr, "ape_hip_gemm: null args");
   ApeGemmArgs p = *a;
   APE_CHECK_ARG(p.A && p.W && p.C, "ape_hip_gemm: null pointer");
   APE_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "ape_hip_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
-  APE_CHECK_ARG(p.in_dt == APE_DT_F32 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: bad in_dt %d", p.in_dt);
+  APE_CHECK_ARG(p.in_dt == APE_DT_F32 || ape_is16(p.in_dt), "ape_hip_gemm: bad in_dt %d", p.in_dt);
+  // one 16-bit storage type per launch (operands, residual, output); the single exception is the bf16 flavour's IEEE-half
+  // output of the K = 256 kernel checked below
+  APE_CHECK_ARG(p.residual == nullptr || p.res_dt == APE_DT_F32 || (ape_is16(p.res_dt) && (p.in_dt == APE_DT_F32 || p.res_dt == p.in_dt)),
+                "ape_hip_gemm: a 16-bit residual must have the operands' 16-bit type (in_dt %d, res_dt %d)", p.in_dt, p.res_dt);
+  APE_CHECK_ARG(p.in_dt != APE_DT_F16 || p.out_dt != APE_DT_BF16, "ape_hip_gemm: f16 operands produce f32 or f16 outputs");
+  APE_CHECK_ARG(p.in_dt != APE_DT_F32 || p.residual == nullptr || !ape_is16(p.res_dt) || !ape_is16(p.out_dt) || p.res_dt == p.out_dt,
+                "ape_hip_gemm: 16-bit residual and output of an f32 launch must share a type");
   APE_CHECK_ARG(p.out_dt == APE_DT_F32 || p.out_dt == APE_DT_BF16 || p.out_dt == APE_DT_F16, "ape_hip_gemm: bad out_dt %d", p.out_dt);
   // IEEE-half output exists for one kernel: the K = 256 register-resident GEMM without residual (the deformable attention's
   // offset / logit projection over the encoder tokens, which is bound by the bytes it writes)
-  APE_CHECK_ARG(p.out_dt != APE_DT_F16 || (p.in_dt == APE_DT_BF16 && p.K == 256 && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
+  APE_CHECK_ARG(p.out_dt != APE_DT_F16 || p.in_dt != APE_DT_BF16 || (p.K == 256 && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
                                            p.residual == nullptr && p.rowscale == nullptr && p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr &&
                                            p.splitk <= 1 && p.ldc % 8 == 0 && ((uintptr_t)p.C) % 16 == 0 && p.tile64 != 3 && p.tile64 != 4),
                 "ape_hip_gemm: f16 output needs bf16 inputs, K == 256, M >= 2048, N %% 8 == 0, no residual / transpose / rope / split-K");
   APE_CHECK_ARG(p.act != APE_ACT_SWIGLU || (p.N % 4 == 0 && !p.trans_out), "ape_hip_gemm: swiglu needs N%%4==0, no transpose");
   APE_CHECK_ARG(!p.trans_out || (p.residual == nullptr && p.rope_cos == nullptr && p.rowmask == nullptr),
                 "ape_hip_gemm: transposed output supports bias/act only");
-  APE_CHECK_ARG(p.splitk <= 1 || p.in_dt == APE_DT_BF16, "ape_hip_gemm: split-K is implemented for the bf16 kernel only");
+  APE_CHECK_ARG(p.splitk <= 1 || ape_is16(p.in_dt), "ape_hip_gemm: split-K is implemented for the 16-bit kernels only");
   APE_CHECK_ARG(p.rope_cos == nullptr || (p.rope_sin != nullptr && p.rope_rows > 0 && p.rope_hd > 0 && p.rope_hd % 4 == 0),
                 "ape_hip_gemm: bad rope args");
   APE_CHECK_ARG((p.rowscale == nullptr) == (p.rowshift == nullptr) && (p.rowscale == nullptr) == (p.colvec == nullptr),
@@ -939,107 +1047,19 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
       (p.rope_hd & (p.rope_hd - 1)) == 0 && (p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)) vec |= 4;
   p.vec_ok = vec;
   hipStream_t s = (hipStream_t)stream;
-  if (p.in_dt == APE_DT_BF16) {
-    APE_CHECK_ARG(p.K % 8 == 0, "ape_hip_gemm(bf16): K=%d must be a multiple of 8 (pad the operands)", p.K);
-    APE_CHECK_ARG(p.lda % 8 == 0 && p.ldw % 8 == 0, "ape_hip_gemm(bf16): lda/ldw must be multiples of 8");
-    APE_CHECK_ARG(((uintptr_t)p.A) % 16 == 0 && ((uintptr_t)p.W) % 16 == 0, "ape_hip_gemm(bf16): A/W must be 16-byte aligned");
-    const int nblk = ceil_div(p.M, GB_M) * ceil_div(p.N, GB_N);
-    const int nblk64 = ceil_div(p.M, 64) * ceil_div(p.N, 64);
-    static const int force_v1 = getenv("APE_GEMM_V1") ? atoi(getenv("APE_GEMM_V1")) : 0;
-    static const int no_glds = getenv("APE_GEMM_NOGLDS") ? atoi(getenv("APE_GEMM_NOGLDS")) : 0;
-    const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
-    // v2's LDS-staged epilogue writes 16-byte chunks of output rows
-    const bool v2_ok = !force_v1 && ((size_t)p.ldc * esz) % 16 == 0 && ((uintptr_t)p.C) % 16 == 0 &&
-                       (p.act != APE_ACT_SWIGLU || p.N % 4 == 0);
-    const bool glds = v2_ok && !no_glds && p.K % GB_K == 0;
-    static const int no_ring = getenv("APE_GEMM_NORING") ? atoi(getenv("APE_GEMM_NORING")) : 0;
-    const char* ring_env = getenv("APE_GEMM_RING");     // read per call so a probe can flip it
-    const int use_ring_always = ring_env ? atoi(ring_env) : 0;
-    const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
-    if (p.tile64 == 3 || p.tile64 == 4) {
-      // 256 x 256 / 256 x 128 eight-wave tiles with the counted-wait pipeline (gemm_p8.hip); falls back when unsupported
-      const char* st_env = getenv("APE_GEMM_P8_STAGGER");
-      const int stagger = st_env ? atoi(st_env) : 1;
-      const char* name = ape_gemm_p8_launch(p, p.tile64 == 3 ? 256 : 128, stagger, s);
-      if (name != nullptr) {
-        g_last_gemm_kernel = name;
-        APE_CHECK_LAUNCH("ape_hip_gemm");
-        return 0;
-      }
-      p.tile64 = 0;
+  if (ape_is16(p.in_dt)) {
+    const int rc = p.in_dt == APE_DT_F16 ? gemm_launch_h16<f16_t>(p, s) : gemm_launch_h16<bf16_t>(p, s);
+    if (rc != 0) return rc;
+    if (p.in_dt == APE_DT_F16) {             // the f16 instantiations report as gemm_f16_*
+      static thread_local char nm[96];
+      const char* src = g_last_gemm_kernel;
+      if (strncmp(src, "gemm_bf16_", 10) == 0) { snprintf(nm, sizeof(nm), "gemm_f16_%s", src + 10); g_last_gemm_kernel = nm; }
     }
-    APE_CHECK_ARG(v2_ok || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output needs 16-byte aligned output rows");
-    if (v2_ok) {
-      static bool attr_done = false;
-      if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<true, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-        attr_done = true;
-      }
-      const char* nk_env = getenv("APE_GEMM_NOKRES");     // read per call so a probe can flip it
-      const int no_kres = nk_env ? atoi(nk_env) : 0;
-      const bool kres = !no_kres && !no_glds && p.K == 256 && p.rowscale == nullptr && p.M >= 2048 && p.N >= 64 && p.N % 8 == 0 && !p.trans_out &&
-                        p.act != APE_ACT_SWIGLU && p.rope_cos == nullptr && p.splitk <= 1 && p.ldc % 8 == 0 &&
-                        (p.residual == nullptr || (p.res_dt == APE_DT_BF16 && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
-      APE_CHECK_ARG(kres || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output is only produced by the K == 256 kernel (disabled by the environment?)");
-      if (kres) {
-        static bool kattr = false;
-        if (!kattr) {
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-          (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-          kattr = true;
-        }
-        const int mblk = ceil_div(p.M, KR_BM);
-        const int nch = ceil_div(p.N, KR_CH);
-        int ysplit = ceil_div(nch, KR_MAXN / KR_CH);                  // bias slab in LDS holds KR_MAXN columns
-        while (mblk * ysplit < 512 && ysplit * 2 <= nch) ysplit *= 2;   // few row blocks: spread the column chunks as well
-        const dim3 grid(mblk, ysplit);
-        const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
-        const bool of32 = p.out_dt == APE_DT_F32;
-        if (p.out_dt == APE_DT_F16) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false, true>", (gemm_bf16_kres_kernel<0, false, true>), grid, KR_LDS);
-        else if (!res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false>", (gemm_bf16_kres_kernel<0, false>), grid, KR_LDS);
-        else if (res && !of32) LAUNCH_GEMM("gemm_bf16_kres_kernel<1, false>", (gemm_bf16_kres_kernel<1, false>), grid, KR_LDS);
-        else if (!res) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, true>", (gemm_bf16_kres_kernel<0, true>), grid, KR_LDS);
-        else LAUNCH_GEMM("gemm_bf16_kres_kernel<1, true>", (gemm_bf16_kres_kernel<1, true>), grid, KR_LDS);
-      } else if (p.splitk > 1) {
-        APE_CHECK_ARG(ring && !p.trans_out && p.workspace != nullptr && p.act != APE_ACT_SWIGLU,
-                      "ape_hip_gemm: split-K needs bf16, K %% 32 == 0, no trans_out / SwiGLU, and a workspace");
-        APE_CHECK_ARG(p.N % 4 == 0 && ((uintptr_t)p.workspace) % 16 == 0, "ape_hip_gemm: split-K needs N %% 4 == 0 and an aligned workspace");
-        if (p.tile64 == 2) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2>), dim3(ceil_div(p.M, 128) * ceil_div(p.N, 64), p.splitk), GEMM_T128x64_LDS);
-        else if (p.tile64) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64, p.splitk), GEMM_T64_LDS);
-        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk, p.splitk), GEMM_V2_LDS);
-        const size_t groups = (size_t)p.M * ((p.N + 3) / 4);
-        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
-      } else if (ring && p.tile64 == 2 && !p.trans_out) {
-        // 128 x 64 tiles: twice the workgroups of a 128 x 128 tiling at 3/4 of its operand traffic per flop
-        const int nblk_mn = ceil_div(p.M, 128) * ceil_div(p.N, 64);
-        LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 2>", (gemm_bf16_ring_kernel<false, 4, 2>), dim3(nblk_mn), GEMM_T128x64_LDS);
-      } else if (ring && p.tile64) {
-        if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 2, 2>", (gemm_bf16_ring_kernel<true, 2, 2>), dim3(nblk64), GEMM_T64_LDS);
-        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2>), dim3(nblk64), GEMM_T64_LDS);
-      } else if (ring && (use_ring_always || nblk < 64)) {
-        if (p.trans_out) LAUNCH_GEMM("gemm_bf16_ring_kernel<true, 4, 4>", (gemm_bf16_ring_kernel<true, 4, 4>), dim3(nblk), GEMM_V2_LDS);
-        else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4>), dim3(nblk), GEMM_V2_LDS);
-      } else if (p.trans_out) {
-        if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<true, true>", (gemm_bf16_v2_kernel<true, true>), dim3(nblk), GEMM_V2_LDS);
-        else LAUNCH_GEMM("gemm_bf16_v2_kernel<true, false>", (gemm_bf16_v2_kernel<true, false>), dim3(nblk), GEMM_V2_LDS);
-      } else {
-        if (glds) LAUNCH_GEMM("gemm_bf16_v2_kernel<false, true>", (gemm_bf16_v2_kernel<false, true>), dim3(nblk), GEMM_V2_LDS);
-        else LAUNCH_GEMM("gemm_bf16_v2_kernel<false, false>", (gemm_bf16_v2_kernel<false, false>), dim3(nblk), GEMM_V2_LDS);
-      }
-    } else if (p.trans_out) LAUNCH_GEMM("gemm_bf16_kernel<true>", gemm_bf16_kernel<true>, dim3(nblk), 0);
-    else LAUNCH_GEMM("gemm_bf16_kernel<false>", gemm_bf16_kernel<false>, dim3(nblk), 0);
   } else {
     const int nblk = ceil_div(p.M, 64) * ceil_div(p.N, 64);
-    if (p.trans_out) LAUNCH_GEMM("gemm_f32_kernel<true>", gemm_f32_kernel<true>, dim3(nblk), 0);
-    else LAUNCH_GEMM("gemm_f32_kernel<false>", gemm_f32_kernel<false>, dim3(nblk), 0);
+    const bool hf = p.out_dt == APE_DT_F16 || (p.residual != nullptr && p.res_dt == APE_DT_F16);
+    if (p.trans_out) { if (hf) LAUNCH_GEMM("gemm_f32_kernel<true>", (gemm_f32_kernel<true, f16_t>), dim3(nblk), 0); else LAUNCH_GEMM("gemm_f32_kernel<true>", (gemm_f32_kernel<true, bf16_t>), dim3(nblk), 0); }
+    else { if (hf) LAUNCH_GEMM("gemm_f32_kernel<false>", (gemm_f32_kernel<false, f16_t>), dim3(nblk), 0); else LAUNCH_GEMM("gemm_f32_kernel<false>", (gemm_f32_kernel<false, bf16_t>), dim3(nblk), 0); }
   }
   APE_CHECK_LAUNCH("ape_hip_gemm");
   return 0;
@@ -1050,7 +1070,10 @@ static int launch_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt
                        void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int nblk = ceil_div(N, 4);
-  if (w_dt == APE_DT_BF16)
+  if (w_dt == APE_DT_F16)
+    hipLaunchKernelGGL(gemv_kernel<f16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const f16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
+                       scale, add, ldadd, out2, ldo2);
+  else if (w_dt == APE_DT_BF16)
     hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
                        scale, add, ldadd, out2, ldo2);
   else

@@ -28,6 +28,8 @@ __device__ __forceinline__ void store_n(T* dst, const float* v, int cnt, bool ve
 // 4 = RoPE tables 16-byte aligned, power-of-two head dim, rope_rows >= M or a power of two (masks replace the modulo).
 // For short-K GEMMs (the ViT at M = 4096) this code is as long as the main loop, so it is written for few VALU ops:
 // vector loads for bias / RoPE / residual, uniform conditions tested once per quad.
+// H = the 16-bit storage type of the launch (bf16_t | f16_t): what a 2-byte residual / output holds.
+template <typename H = bf16_t>
 __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0, float v[4], int& ocol, int& cnt) {
   const bool masked = p.rowmask != nullptr && p.rowmask[m] != 0;
   const bool full = n0 + 3 < p.N;
@@ -112,8 +114,8 @@ __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0
       const float* rp = reinterpret_cast<const float*>(p.residual) + roff;
       if (vec && cnt == 4) ld4<float>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = rp[r];
     } else {
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + roff;
-      if (vec && cnt == 4) ld4<bf16_t>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = bf2f(rp[r]);
+      const H* rp = reinterpret_cast<const H*>(p.residual) + roff;
+      if (vec && cnt == 4) ld4<H>(rp, rv); else for (int r = 0; r < cnt; ++r) rv[r] = ldf<H>(rp + r);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] += rv[r];
@@ -125,15 +127,16 @@ __device__ __forceinline__ void epi_n4_values(const GemmParams& p, int m, int n0
 }
 
 // direct (register -> global) epilogue: 4 consecutive output columns of row m
+template <typename H = bf16_t>
 __device__ __forceinline__ void epi_n4(const GemmParams& p, int m, int n0, float v[4]) {
   if (m >= p.M || n0 >= p.N) return;
   int ocol, cnt;
-  epi_n4_values(p, m, n0, v, ocol, cnt);
+  epi_n4_values<H>(p, m, n0, v, ocol, cnt);
   const bool vec = (p.vec_ok & 1) != 0 && cnt == 4;
   const size_t off = (size_t)m * p.ldc + ocol;
   if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, vec);
-  else if (cnt == 2 && (p.vec_ok & 1)) *reinterpret_cast<uint32_t*>(reinterpret_cast<bf16_t*>(p.C) + off) = pack2bf(v[0], v[1]);
-  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, vec);
+  else if (cnt == 2 && (p.vec_ok & 1)) *reinterpret_cast<uint32_t*>(reinterpret_cast<H*>(p.C) + off) = h16<H>::pack2(v[0], v[1]);
+  else store_n<H>(reinterpret_cast<H*>(p.C) + off, v, cnt, vec);
 }
 
 __device__ __forceinline__ void epi_m4_values(const GemmParams& p, int n, float v[4]) {
@@ -143,13 +146,14 @@ __device__ __forceinline__ void epi_m4_values(const GemmParams& p, int n, float 
 }
 
 // transposed output C^T[n][m0..m0+3]  (bias by n, activation, no residual/rope/mask)
+template <typename H = bf16_t>
 __device__ __forceinline__ void epi_m4(const GemmParams& p, int m0, int n, float v[4]) {
   if (n >= p.N || m0 >= p.M) return;
   epi_m4_values(p, n, v);
   const int cnt = (p.M - m0) < 4 ? (p.M - m0) : 4;
   const size_t off = (size_t)n * p.ldc + m0;
   if (p.out_dt == APE_DT_F32) store_n<float>(reinterpret_cast<float*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
-  else store_n<bf16_t>(reinterpret_cast<bf16_t*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
+  else store_n<H>(reinterpret_cast<H*>(p.C) + off, v, cnt, (p.vec_ok & 1) != 0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -182,7 +186,7 @@ template <int W> __device__ __forceinline__ void ldrow_f32(const float* src, flo
   }
 }
 
-template <int W, bool ROPE, bool NORM, int ACT>
+template <int W, bool ROPE, bool NORM, int ACT, typename H = bf16_t>
 __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb, float (&v)[W]) {
   if (NORM) {
     const float rs = p.rowscale[m], sh = p.rowshift[m];
@@ -239,11 +243,11 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
 #pragma unroll
       for (int e = 0; e < W; ++e) v[e] += r[e];
     } else {
-      const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.residual) + roff;
+      const H* rp = reinterpret_cast<const H*>(p.residual) + roff;
 #pragma unroll
       for (int e = 0; e < W / 8; ++e) {
         float r[8];
-        ld8<bf16_t>(rp + e * 8, r);
+        ld8<H>(rp + e * 8, r);
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[e * 8 + q] += r[q];
       }
@@ -252,23 +256,23 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
 }
 
 // store NV values (NV % 4 == 0) starting at column ocol of row m; 16-byte pieces when the address allows
-template <int NV>
+template <int NV, typename H = bf16_t>
 __device__ __forceinline__ void store_row(const GemmParams& p, int m, int ocol, const float* o) {
   if (p.out_dt == APE_DT_F32) {
     float* dst = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + ocol;
 #pragma unroll
     for (int e = 0; e < NV / 4; ++e) *reinterpret_cast<float4*>(dst + e * 4) = make_float4(o[e * 4], o[e * 4 + 1], o[e * 4 + 2], o[e * 4 + 3]);
   } else {
-    bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + ocol;
+    H* dst = reinterpret_cast<H*>(p.C) + (size_t)m * p.ldc + ocol;
     if (NV % 8 == 0) {
 #pragma unroll
       for (int e = 0; e < NV / 8; ++e)
-        *reinterpret_cast<uint4*>(dst + e * 8) = make_uint4(pack2bf(o[e * 8], o[e * 8 + 1]), pack2bf(o[e * 8 + 2], o[e * 8 + 3]),
-                                                            pack2bf(o[e * 8 + 4], o[e * 8 + 5]), pack2bf(o[e * 8 + 6], o[e * 8 + 7]));
+        *reinterpret_cast<uint4*>(dst + e * 8) = make_uint4(h16<H>::pack2(o[e * 8], o[e * 8 + 1]), h16<H>::pack2(o[e * 8 + 2], o[e * 8 + 3]),
+                                                            h16<H>::pack2(o[e * 8 + 4], o[e * 8 + 5]), h16<H>::pack2(o[e * 8 + 6], o[e * 8 + 7]));
     } else {
 #pragma unroll
       for (int e = 0; e < NV / 4; ++e)
-        *reinterpret_cast<uint2*>(dst + e * 4) = make_uint2(pack2bf(o[e * 4], o[e * 4 + 1]), pack2bf(o[e * 4 + 2], o[e * 4 + 3]));
+        *reinterpret_cast<uint2*>(dst + e * 4) = make_uint2(h16<H>::pack2(o[e * 4], o[e * 4 + 1]), h16<H>::pack2(o[e * 4 + 2], o[e * 4 + 3]));
     }
   }
 }

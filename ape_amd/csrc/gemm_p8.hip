@@ -48,7 +48,7 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool STAGGER>
+template <int BN, bool STAGGER, typename H = bf16_t>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < TNH; ++j)
           acc[ha * 4 + i][hb * TNH + j] =
-              __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[hb][j][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH + j], 0, 0, 0);
+              h16<H>::mfma(wf[hb][j][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH + j]);
     __builtin_amdgcn_s_setprio(0);
   };
   auto barrier = [&]() __attribute__((always_inline)) {
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[4 * j + r] = acc[i][j][r];
-        epi_row_fast<W, ROPE, NORM, ACT>(p, m, nb, o);
-        if (ACT == EPI_ACT_SWIGLU) store_row<W / 2>(p, m, nb >> 1, o);
-        else store_row<W>(p, m, nb, o);
+        epi_row_fast<W, ROPE, NORM, ACT, H>(p, m, nb, o);
+        if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, nb >> 1, o);
+        else store_row<W, H>(p, m, nb, o);
       }
     }
   };
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          epi_n4(p, m, nb + 4 * j, v);
+          epi_n4<H>(p, m, nb + 4 * j, v);
         }
       }
     }
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
 // launcher (called from ape_hip_gemm in gemm.hip).  Returns the kernel symbol, or nullptr when the problem does not fit.
 // ------------------------------------------------------------------------------------------
 static bool p8_supported(const ApeGemmArgs& p) {
-  if (p.in_dt != APE_DT_BF16 || p.K % P8_BK != 0 || p.K < P8_BK) return false;
+  if (!ape_is16(p.in_dt) || p.K % P8_BK != 0 || p.K < P8_BK) return false;
   if (p.splitk > 1 || p.rowscale != nullptr && p.trans_out) return false;
   const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
   if (((uintptr_t)p.C) % 16 != 0 || ((size_t)p.ldc * esz) % 16 != 0) return false;
@@ -300,21 +300,26 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     p.trans_out = 0;
     p.vec_ok = (p.vec_ok & ~2) | P8_BIAS_BY_ROW;
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-    attr_done = true;
-  }
   const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
+  const bool f16 = p.in_dt == APE_DT_F16;
+  const char* name = nullptr;
+#define P8_LAUNCH(BN_, ST_, H_, LDS_, NAME_)                                                                            \
+  do {                                                                                                                  \
+    static bool attr__ = false;                                                                                         \
+    if (!attr__) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<BN_, ST_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
+      attr__ = true;                                                                                                    \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(tiles), dim3(512), LDS_, s, p);                        \
+    name = NAME_;                                                                                                       \
+  } while (0)
   if (bn == 256) {
-    if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true>), dim3(tiles), dim3(512), 131072, s, p); return "gemm_bf16_p8_kernel<256, true>"; }
-    hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, false>), dim3(tiles), dim3(512), 131072, s, p);
-    return "gemm_bf16_p8_kernel<256, false>";
+    if (stagger) { if (f16) P8_LAUNCH(256, true, f16_t, 131072, "gemm_f16_p8_kernel<256, true>"); else P8_LAUNCH(256, true, bf16_t, 131072, "gemm_bf16_p8_kernel<256, true>"); }
+    else { if (f16) P8_LAUNCH(256, false, f16_t, 131072, "gemm_f16_p8_kernel<256, false>"); else P8_LAUNCH(256, false, bf16_t, 131072, "gemm_bf16_p8_kernel<256, false>"); }
+  } else {
+    if (stagger) { if (f16) P8_LAUNCH(128, true, f16_t, 98304, "gemm_f16_p8_kernel<128, true>"); else P8_LAUNCH(128, true, bf16_t, 98304, "gemm_bf16_p8_kernel<128, true>"); }
+    else { if (f16) P8_LAUNCH(128, false, f16_t, 98304, "gemm_f16_p8_kernel<128, false>"); else P8_LAUNCH(128, false, bf16_t, 98304, "gemm_bf16_p8_kernel<128, false>"); }
   }
-  if (stagger) { hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, true>), dim3(tiles), dim3(512), 98304, s, p); return "gemm_bf16_p8_kernel<128, true>"; }
-  hipLaunchKernelGGL((gemm_bf16_p8_kernel<128, false>), dim3(tiles), dim3(512), 98304, s, p);
-  return "gemm_bf16_p8_kernel<128, false>";
+#undef P8_LAUNCH
+  return name;
 }

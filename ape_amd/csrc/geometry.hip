@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void geometry_kernel(const GeoParams p) {
     const float a = (c < p.npf ? yn : xn) / p.dim_t[i];
     const float v = ((i & 1) ? cosf(a) : sinf(a)) + p.level_embeds[l * C + c];
     if (p.lp_dt == APE_DT_F32) reinterpret_cast<float*>(p.lvl_pos)[(size_t)t * C + c] = v;
+    else if (p.lp_dt == APE_DT_F16) stf<f16_t>(reinterpret_cast<f16_t*>(p.lvl_pos) + (size_t)t * C + c, v);
     else reinterpret_cast<bf16_t*>(p.lvl_pos)[(size_t)t * C + c] = f2bf(v);
   }
   // ---- encoder reference points: ((x + 0.5) / (vr_w * W), (y + 0.5) / (vr_h * H)) * valid_ratios[l']
@@ -111,7 +112,7 @@ extern "C" int ape_hip_geometry(int S, int h, int w, int L, const int* level_hw 
   APE_CHECK_ARG(L >= 1 && L <= 8 && S > 0 && h > 0 && w > 0 && h <= S && w <= S, "ape_hip_geometry: bad sizes (L=%d S=%d h=%d w=%d)", L, S, h, w);
   APE_CHECK_ARG(level_hw && dim_t && level_embeds && lvl_pos && mask_u8 && mask_bool && invalid_u8 && enc_ref && proposals &&
                     valid_ratios && vr4 && box_scale, "ape_hip_geometry: null pointer");
-  APE_CHECK_ARG(lvl_pos_dt == APE_DT_F32 || lvl_pos_dt == APE_DT_BF16, "ape_hip_geometry: lvl_pos dtype %d", lvl_pos_dt);
+  APE_CHECK_ARG(lvl_pos_dt == APE_DT_F32 || ape_is16(lvl_pos_dt), "ape_hip_geometry: lvl_pos dtype %d", lvl_pos_dt);
   GeoParams p;
   memset(&p, 0, sizeof(p));
   p.L = L; p.S = S; p.h = h; p.w = w; p.npf = npf; p.offset = offset; p.eps = eps; p.scale = scale;

@@ -79,7 +79,8 @@ extern "C" int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, i
   APE_CHECK_ARG(logits && out && h0 > 0 && w0 > 0 && S > 0 && n > 0, "ape_hip_mask_upsample_bits: bad args");
   const size_t total = (size_t)n * S * ((S + 15) / 16);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (dt == APE_DT_BF16) hipLaunchKernelGGL(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
+  if (dt == APE_DT_F16) hipLaunchKernelGGL(mask_upsample_bits_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)logits, ldl, h0, w0, S, n, out);
+  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
   else hipLaunchKernelGGL(mask_upsample_bits_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, ldl, h0, w0, S, n, out);
   APE_CHECK_LAUNCH("ape_hip_mask_upsample_bits");
   return 0;
@@ -237,12 +238,14 @@ extern "C" int ape_hip_mask_upsample_sigmoid(const void* logits, int ldl, int in
   const size_t total = (size_t)crop_h * crop_w * ((n + 3) / 4);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  switch (in_dt * 2 + out_dt) {
-    case 0: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, float>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); break;
-    case 1: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, bf16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); break;
-    case 2: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); break;
-    case 3: hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); break;
-    default: ape_set_error("ape_hip_mask_upsample_sigmoid: bad dtypes"); return -1;
+  const int hk = APE_H16_KIND(in_dt, out_dt);
+  if (hk < 0) { ape_set_error("ape_hip_mask_upsample_sigmoid: dtypes must be f32 or ONE 16-bit type (in %d, out %d)", in_dt, out_dt); return -1; }
+  const int key = (ape_is16(in_dt) ? 2 : 0) + (ape_is16(out_dt) ? 1 : 0);
+  if (key == 0) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, float>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); }
+  else if (hk == APE_DT_F16) {
+    if (key == 1) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, f16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); }
+  } else {
+    if (key == 1) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, bf16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); }
   }
   APE_CHECK_LAUNCH("ape_hip_mask_upsample_sigmoid");
   return 0;

@@ -457,6 +457,7 @@ static int msda_fused_launch(const void* value, int ldv, int v_dt, const int64_t
   else if (v_dt == APE_DT_BF16 && out_dt == APE_DT_F32) rc = launch_msda<bf16_t, float, true>(p, B, L, s);
   else if (v_dt == APE_DT_F16 && out_dt == APE_DT_BF16) rc = launch_msda<f16_t, bf16_t, true>(p, B, L, s);    // half values (production)
   else if (v_dt == APE_DT_F16 && out_dt == APE_DT_F32) rc = launch_msda<f16_t, float, true>(p, B, L, s);
+  else if (v_dt == APE_DT_F16 && out_dt == APE_DT_F16) rc = launch_msda<f16_t, f16_t, true>(p, B, L, s);      // the f16 flavour of the pipeline
   else if (v_dt == APE_DT_F32 && out_dt == APE_DT_F32) rc = launch_msda<float, float, true>(p, B, L, s);
   else { ape_set_error("msda_fused: unsupported dtype combination v=%d out=%d", v_dt, out_dt); return -1; }
   if (rc) return rc;

@@ -146,18 +146,24 @@ extern "C" int ape_hip_layernorm(const ApeLayerNormArgs* a, void* stream) {
   APE_CHECK_ARG((a->add == nullptr) == (a->y2 == nullptr), "ape_hip_layernorm: add and y2 go together");
   const ApeLayerNormArgs p = *a;
   hipStream_t s = (hipStream_t)stream;
-  const int key = p.x_dt * 4 + p.y_dt * 2 + (p.add ? p.add_dt : p.y_dt);
-  switch (key) {
-    case 0: launch_ln<float, float, float>(p, s); break;
-    case 1: launch_ln<float, float, bf16_t>(p, s); break;
-    case 2: launch_ln<float, bf16_t, float>(p, s); break;
-    case 3: launch_ln<float, bf16_t, bf16_t>(p, s); break;
-    case 4: launch_ln<bf16_t, float, float>(p, s); break;
-    case 5: launch_ln<bf16_t, float, bf16_t>(p, s); break;
-    case 6: launch_ln<bf16_t, bf16_t, float>(p, s); break;
-    case 7: launch_ln<bf16_t, bf16_t, bf16_t>(p, s); break;
-    default: ape_set_error("ape_hip_layernorm: bad dtypes"); return -1;
+  // one 16-bit storage type per call (bf16 | f16); key bits: x, y, add are 16-bit
+  const int add_dt = p.add ? p.add_dt : p.y_dt;
+  const int hk = APE_H16_KIND(p.x_dt, p.y_dt, add_dt);
+  if (hk < 0) { ape_set_error("ape_hip_layernorm: dtypes must be f32 or ONE 16-bit type (x %d, y %d, add %d)", p.x_dt, p.y_dt, add_dt); return -1; }
+  const int key = (ape_is16(p.x_dt) ? 4 : 0) + (ape_is16(p.y_dt) ? 2 : 0) + (ape_is16(add_dt) ? 1 : 0);
+#define APE_NORM_CASES(H_)                                      \
+  switch (key) {                                                \
+    case 0: launch_ln<float, float, float>(p, s); break;        \
+    case 1: launch_ln<float, float, H_>(p, s); break;           \
+    case 2: launch_ln<float, H_, float>(p, s); break;           \
+    case 3: launch_ln<float, H_, H_>(p, s); break;              \
+    case 4: launch_ln<H_, float, float>(p, s); break;           \
+    case 5: launch_ln<H_, float, H_>(p, s); break;              \
+    case 6: launch_ln<H_, H_, float>(p, s); break;              \
+    default: launch_ln<H_, H_, H_>(p, s); break;                \
   }
+  if (hk == APE_DT_F16) { APE_NORM_CASES(f16_t) } else { APE_NORM_CASES(bf16_t) }
+#undef APE_NORM_CASES
   APE_CHECK_LAUNCH("ape_hip_layernorm");
   return 0;
 }
@@ -334,18 +340,24 @@ extern "C" int ape_hip_groupnorm(const ApeGroupNormArgs* a, void* stream) {
                 "ape_hip_groupnorm: need C <= 256, G <= 64, C %% G == 0");
   const ApeGroupNormArgs p = *a;
   hipStream_t s = (hipStream_t)stream;
-  const int key = p.x_dt * 4 + p.y_dt * 2 + (p.add ? p.add_dt : p.y_dt);
-  switch (key) {
-    case 0: launch_gn<float, float, float>(p, s); break;
-    case 1: launch_gn<float, float, bf16_t>(p, s); break;
-    case 2: launch_gn<float, bf16_t, float>(p, s); break;
-    case 3: launch_gn<float, bf16_t, bf16_t>(p, s); break;
-    case 4: launch_gn<bf16_t, float, float>(p, s); break;
-    case 5: launch_gn<bf16_t, float, bf16_t>(p, s); break;
-    case 6: launch_gn<bf16_t, bf16_t, float>(p, s); break;
-    case 7: launch_gn<bf16_t, bf16_t, bf16_t>(p, s); break;
-    default: ape_set_error("ape_hip_groupnorm: bad dtypes"); return -1;
+  // one 16-bit storage type per call (bf16 | f16); key bits: x, y, add are 16-bit
+  const int add_dt = p.add ? p.add_dt : p.y_dt;
+  const int hk = APE_H16_KIND(p.x_dt, p.y_dt, add_dt);
+  if (hk < 0) { ape_set_error("ape_hip_groupnorm: dtypes must be f32 or ONE 16-bit type (x %d, y %d, add %d)", p.x_dt, p.y_dt, add_dt); return -1; }
+  const int key = (ape_is16(p.x_dt) ? 4 : 0) + (ape_is16(p.y_dt) ? 2 : 0) + (ape_is16(add_dt) ? 1 : 0);
+#define APE_NORM_CASES(H_)                                      \
+  switch (key) {                                                \
+    case 0: launch_gn<float, float, float>(p, s); break;        \
+    case 1: launch_gn<float, float, H_>(p, s); break;           \
+    case 2: launch_gn<float, H_, float>(p, s); break;           \
+    case 3: launch_gn<float, H_, H_>(p, s); break;              \
+    case 4: launch_gn<H_, float, float>(p, s); break;           \
+    case 5: launch_gn<H_, float, H_>(p, s); break;              \
+    case 6: launch_gn<H_, H_, float>(p, s); break;              \
+    default: launch_gn<H_, H_, H_>(p, s); break;                \
   }
+  if (hk == APE_DT_F16) { APE_NORM_CASES(f16_t) } else { APE_NORM_CASES(bf16_t) }
+#undef APE_NORM_CASES
   APE_CHECK_LAUNCH("ape_hip_groupnorm");
   return 0;
 }
@@ -385,7 +397,8 @@ extern "C" int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, f
                                  void* stream) {
   APE_CHECK_ARG(x && rowscale && rowshift && M > 0 && C > 0, "ape_hip_row_stats: bad args");
   const dim3 grid(ceil_div(M, 4)), block(256);
-  if (dt == APE_DT_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, eps, rowscale, rowshift);
+  if (dt == APE_DT_F16) hipLaunchKernelGGL(row_stats_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, ldx, M, C, eps, rowscale, rowshift);
+  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, eps, rowscale, rowshift);
   else hipLaunchKernelGGL(row_stats_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, M, C, eps, rowscale, rowshift);
   APE_CHECK_LAUNCH("ape_hip_row_stats");
   return 0;
@@ -470,11 +483,16 @@ extern "C" int ape_hip_postnorm_residual(const void* t, int ldt, int t_dt, const
   APE_CHECK_ARG(copy == nullptr || (ldc % 4 == 0 && ((uintptr_t)copy) % 8 == 0), "ape_hip_postnorm_residual: copy alignment");
   APE_CHECK_ARG(((uintptr_t)stream) % 16 == 0, "ape_hip_postnorm_residual: stream alignment");
   hipStream_t s = (hipStream_t)stream_;
-  const bool tb = t_dt == APE_DT_BF16, cb = copy_dt == APE_DT_BF16;
-  if (tb && cb) launch_postnorm<bf16_t, bf16_t>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
-  else if (tb) launch_postnorm<bf16_t, float>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
-  else if (cb) launch_postnorm<float, bf16_t>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  const int hk = APE_H16_KIND(t != nullptr ? t_dt : APE_DT_F32, copy != nullptr ? copy_dt : APE_DT_F32);
+  APE_CHECK_ARG(hk >= 0, "ape_hip_postnorm_residual: t and the copy are f32 or ONE 16-bit type");
+  const bool tb = t != nullptr && ape_is16(t_dt), cb = copy != nullptr && ape_is16(copy_dt);
+#define APE_PN_CASES(H_)                                                                              \
+  if (tb && cb) launch_postnorm<H_, H_>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);          \
+  else if (tb) launch_postnorm<H_, float>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);        \
+  else if (cb) launch_postnorm<float, H_>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);        \
   else launch_postnorm<float, float>(t, ldt, w, b, eps, stream, lds, copy, ldc, M, C, s);
+  if (hk == APE_DT_F16) { APE_PN_CASES(f16_t) } else { APE_PN_CASES(bf16_t) }
+#undef APE_PN_CASES
   APE_CHECK_LAUNCH("ape_hip_postnorm_residual");
   return 0;
 }

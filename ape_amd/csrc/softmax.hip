@@ -38,7 +38,8 @@ extern "C" int ape_hip_segment_softmax(const float* S, int lds, int T, int nseg,
   APE_CHECK_ARG(S && gmax && out && T > 0 && nseg > 0 && L > 0, "ape_hip_segment_softmax: bad args");
   const size_t tasks = (size_t)T * nseg;
   const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-  if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(segment_softmax_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (bf16_t*)out, ldo);
+  if (out_dt == APE_DT_F16) hipLaunchKernelGGL(segment_softmax_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (f16_t*)out, ldo);
+  else if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(segment_softmax_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (bf16_t*)out, ldo);
   else hipLaunchKernelGGL(segment_softmax_kernel<float>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_segment_softmax");
   return 0;
@@ -119,13 +120,14 @@ extern "C" int ape_hip_transpose(const void* S, int lds, int in_dt, int T, int C
   APE_CHECK_ARG(colmax == nullptr || gmax != nullptr, "ape_hip_transpose: softmax mode needs gmax");
   const dim3 grid(ceil_div(T, 64), ceil_div(C, 64)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  const int key = in_dt * 2 + out_dt;
-  switch (key) {
-    case 0: hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); break;
-    case 1: hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); break;
-    case 2: hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); break;
-    case 3: hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); break;
-    default: ape_set_error("ape_hip_transpose: bad dtypes"); return -1;
+  const int hk = APE_H16_KIND(in_dt, out_dt);
+  if (hk < 0) { ape_set_error("ape_hip_transpose: dtypes must be f32 or ONE 16-bit type (in %d, out %d)", in_dt, out_dt); return -1; }
+  const int key = (ape_is16(in_dt) ? 2 : 0) + (ape_is16(out_dt) ? 1 : 0);
+  if (key == 0) { hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); }
+  else if (hk == APE_DT_F16) {
+    if (key == 1) { hipLaunchKernelGGL((transpose_kernel<float, f16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((transpose_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { hipLaunchKernelGGL((transpose_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); }
+  } else {
+    if (key == 1) { hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); }
   }
   APE_CHECK_LAUNCH("ape_hip_transpose");
   return 0;

@@ -136,8 +136,8 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
   float* pacc = psum + nchunk * VL_H;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(vl_smax_partial_kernel, dim3(nchunk), dim3(256), 0, s, S, lds, T, pmax);
-  if (x_dt == APE_DT_BF16)
-    hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  if (x_dt == APE_DT_F16) hipLaunchKernelGGL(vl_pool_partial_kernel<f16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const f16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  else if (x_dt == APE_DT_BF16) hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
   else
     hipLaunchKernelGGL(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
   hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, sub, out);
@@ -149,12 +149,13 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
 // ------------------------------------------------------------------------------------------
 // Per-head matrix-vector products of the single-token language side (ape/layers/fuse_helper.py:70-73,140,160-161 after the
 // reassociation of layers/fuse_helper.py): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n], all fp32
-// (optionally a bf16 copy of out: the GEMM operand of the score product).
+// (optionally a 16-bit copy of out, bf16 or f16: the GEMM operand of the score product).
 // One wave per (h, n); replaces torch.einsum / matmul (rocBLAS launches inside the captured forward).
 // ------------------------------------------------------------------------------------------
+template <typename TC>
 __global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                         const float* __restrict__ bias, float* __restrict__ out, int ldo, int H,
-                                                        int N, int D, float alpha, bf16_t* __restrict__ out_bf16, int ldob) {
+                                                        int N, int D, float alpha, TC* __restrict__ out_bf16, int ldob) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // over H * N
   if (row >= H * N) return;
@@ -174,16 +175,21 @@ __global__ __launch_bounds__(256) void head_gemv_kernel(const float* __restrict_
   if (lane == 0) {
     const float r = s * alpha + (bias != nullptr ? bias[row] : 0.f);
     out[(size_t)h * ldo + n] = r;
-    if (out_bf16 != nullptr) out_bf16[(size_t)h * ldob + n] = f2bf(r);
+    if (out_bf16 != nullptr) stf<TC>(out_bf16 + (size_t)h * ldob + n, r);
   }
 }
 
 extern "C" int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N,
-                                 int D, float alpha, void* out_bf16, int ldob, void* stream) {
+                                 int D, float alpha, void* out_bf16, int ldob, int copy_dt, void* stream) {
   APE_CHECK_ARG(x && W && out && H > 0 && N > 0 && D > 0, "ape_hip_head_gemv: bad args");
+  APE_CHECK_ARG(out_bf16 == nullptr || ape_is16(copy_dt), "ape_hip_head_gemv: the copy is bf16 or f16 (copy_dt %d)", copy_dt);
   APE_CHECK_ARG(((uintptr_t)x) % 16 == 0 && ((uintptr_t)W) % 16 == 0, "ape_hip_head_gemv: x / W must be 16-byte aligned");
-  hipLaunchKernelGGL(head_gemv_kernel, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
-                     (bf16_t*)out_bf16, ldob);
+  if (out_bf16 != nullptr && copy_dt == APE_DT_F16)
+    hipLaunchKernelGGL(head_gemv_kernel<f16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
+                       (f16_t*)out_bf16, ldob);
+  else
+    hipLaunchKernelGGL(head_gemv_kernel<bf16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
+                       (bf16_t*)out_bf16, ldob);
   APE_CHECK_LAUNCH("ape_hip_head_gemv");
   return 0;
 }

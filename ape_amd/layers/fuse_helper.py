@@ -159,11 +159,11 @@ class BiAttentionBlock(nn.Module):
 
         def language_side():
             kh = k.view(a.num_heads, a.head_dim)
-            u, u_c = ops.head_gemv(kh, P["wvT"], bf16_copy=True)     # W_v,h^T k_h       [8, v_dim] (+ the GEMM operand copy)
+            u, u_c = ops.head_gemv(kh, P["wvT"], bf16_copy=dt if dt in ops.HALF16 else True)     # W_v,h^T k_h       [8, v_dim] (+ the GEMM operand copy)
             c = ops.head_gemv(kh, P["bv1"], alpha=a.scale)           # scale * b_v,h . k_h   [8, 1]
             # scores are taken on LN_v(v) = v_new - gdv: bias_h = scale * (c_h - u_h . gamma_v delta_v)
             _, sbias = ops.gemv(gdv, u, alpha=-a.scale, add=c.view(1, -1))
-            S = ops.gemm(v_new, u_c if dt == torch.bfloat16 else u, sbias[0], alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
+            S = ops.gemm(v_new, u_c if dt in ops.HALF16 else u, sbias[0], alpha=a.scale, out_dtype=torch.float32)   # [T, 8]
             pooled = ops.vl_pool(S, v_new, gdv[0])                   # sum_t p[t,h] LN_v(v)[t]     [8, v_dim]
             ol = ops.head_gemv(pooled, P["wvv"], P["bvv"])           # values_v_proj per head   [8, hd]
             return ops.gemv(ol.view(1, -1), P["wol"], P["bol"], scale=P["gl"], add=l_n)[1]       # l_n + gamma_l * delta_l

@@ -56,7 +56,7 @@ def half_value_kwargs(dt, rows):
     rows on, which is every encoder / decoder value projection of the full-size models; APE_MSDA_BF16_VALUE=1 keeps bf16."""
     if dt == torch.bfloat16 and rows >= 2048 and os.environ.get("APE_MSDA_BF16_VALUE") != "1":
         return dict(out_dtype=torch.float16, clamp=HALF_MAX)
-    return {}
+    return {}          # float16 flavour: the value projection is half already (every half store of the library saturates)
 
 
 class MultiScaleDeformableAttention(nn.Module):
@@ -97,7 +97,7 @@ class MultiScaleDeformableAttention(nn.Module):
         # offsets | logits: fp32 in validation mode and for the decoder's 900 queries; IEEE half for the encoder's 87 k tokens in
         # production mode -- that GEMM is bound by the bytes it writes (168 MB per layer in fp32) and the sampler reads them
         # back; half keeps 11 significant bits (offsets are a few pixels, logits feed a 20-way softmax)
-        half = dt == torch.bfloat16 and query_pos_sum.shape[0] >= 2048 and os.environ.get("APE_MSDA_F32_OFFSETS") != "1"
+        half = dt in ops.HALF16 and query_pos_sum.shape[0] >= 2048 and os.environ.get("APE_MSDA_F32_OFFSETS") != "1"
         offw = ops.gemm(query_pos_sum, P["woffw"], P["boffw"], out_dtype=torch.float16 if half else torch.float32)
         samp = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=dt)
         return ops.gemm(samp, P["wout"], P["bout"], residual=identity, out_dtype=out_dtype or dt)

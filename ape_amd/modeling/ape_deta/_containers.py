@@ -26,7 +26,7 @@ class FFN(nn.Module):
         def build(dt):
             l0, l1 = self.layers[0][0], self.layers[1]
             d = dict(w1=pack_matrix(l0.weight, dt), b1=f32(l0.bias), w2=pack_matrix(l1.weight, dt), b2=f32(l1.bias))
-            if dt == torch.bfloat16 and l0.weight.shape[0] % 64 == 0:
+            if dt in ops.HALF16 and l0.weight.shape[0] % 64 == 0:
                 d["w2p"] = permute_ffn_w2(d["w2"])            # hidden columns in the fused kernel's k order
             return d
         return self._pack.get(self, dt, build)
@@ -41,7 +41,7 @@ class FFN(nn.Module):
         layer's post-FFN norm) -- in the same launch on the one-kernel path"""
         P = self.packed(dt)
         mode = os.environ.get("APE_FFN_FUSED", "1")
-        if (mode != "0" and "w2p" in P and (out_dtype or dt) == torch.bfloat16 and x.shape[0] >= self.FUSED_MIN_ROWS
+        if (mode != "0" and "w2p" in P and (out_dtype or dt) in ops.HALF16 and (out_dtype or dt) == dt and x.shape[0] >= self.FUSED_MIN_ROWS
                 and x.shape[1] == 256 and P["w2"].shape[0] == 256 and P["w1"].shape[0] <= 4096):
             fuse_ln = norm if os.environ.get("APE_FFN_LN") != "0" else None
             if mode == "b64":

@@ -187,7 +187,7 @@ class Block(nn.Module):
         """bf16 production mode: the SwiGLU sub-LayerNorm (vit_eva_clip.py:129-131) is folded into the down projection,
         LN(h) W3^T = rstd (h W'^T) - rstd mean rowsum(W') + W3 b_ln  with  W' = W3 diag(gamma)  (ApeGemmArgs.rowscale ...):
         the 2730-wide activation is read once (statistics) instead of read + written + read again."""
-        if dt != torch.bfloat16 or not isinstance(m.ffn_ln, nn.LayerNorm) or os.environ.get("APE_NO_LNFOLD") == "1":
+        if dt not in ops.HALF16 or not isinstance(m.ffn_ln, nn.LayerNorm) or os.environ.get("APE_NO_LNFOLD") == "1":
             return {}
         w3 = m.w3.weight.detach().float()
         g, b = m.ffn_ln.weight.detach().float(), m.ffn_ln.bias.detach().float()

@@ -53,7 +53,7 @@ class EVA02CLIP(nn.Module):
         self.tokenizer = tokenizer          # resolved lazily: the merge table is data outside this repository
         self._clip_model = clip_model
         self.dtype = {"bfloat16": torch.bfloat16, "float16": torch.float16}.get(dtype, torch.float32)
-        self.net.text.compute_dtype = torch.float32 if self.dtype == torch.float32 else torch.bfloat16
+        self.net.text.compute_dtype = self.dtype          # float16: the f16 flavour of the kernels (the reference's eval dtype)
         if cache_dir:
             self.load_pretrained(cache_dir)
         if freeze:

@@ -14,14 +14,17 @@ from . import _lib
 from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU, ACT_SWIGLU, DT_BF16, DT_F32, MASK_NONE,  # noqa: F401
                    MASK_ZERO_INPUT, MASK_ZERO_OUTPUT)
 
-_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16}
+_DT = {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: _lib.DT_F16}
+# the two 16-bit flavours of the pipeline (csrc/common.h h16<>): bfloat16 = BASELINE's dtype, float16 = the reference's own
+# evaluation dtype (tools/train_net.py:642); every 16-bit operand of one call has the same one
+HALF16 = (torch.bfloat16, torch.float16)
 
 
 def _dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError(f"ape_amd: unsupported dtype {t.dtype} (float32 / bfloat16 only)")
+        raise TypeError(f"ape_amd: unsupported dtype {t.dtype} (float32 / bfloat16 / float16 only)")
 
 
 def _dev(*ts):
@@ -64,7 +67,7 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
     * few output tiles: 64x64 tiles plus split-K up to ~256 workgroups (900x256x2048: 11 vs 38 us);
     * one 128x128 tile per CU: 64x64 tiles for K <= 1024 (4096x1024x1024: 26 vs 30 us; the transposed-output variant
       prefers 128x128: 19 vs 21 us); long K stays on the 128x128 kernel unsplit (4096x1024x2752: 48 vs 50 us split)."""
-    if dtype != torch.bfloat16 or K % 32 != 0:
+    if dtype not in HALF16 or K % 32 != 0:
         return 0, 1
     if K % 64 == 0 and K >= 512:
         # eight-wave 256 x 256 / 256 x 128 tiles with the counted-wait pipeline (csrc/gemm_p8.hip) once they fill the chip
@@ -121,7 +124,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     args.M, args.N, args.K = M, N, K
     args.lda, args.ldw, args.ldc = _ld(a), _ld(w), _ld(out)
     # IEEE-half output: one kernel produces it (K = 256, >= 2048 rows, no residual) -- the launcher checks
-    args.in_dt, args.out_dt = _dt(a), (_lib.DT_F16 if out.dtype == torch.float16 else _dt(out))
+    args.in_dt, args.out_dt = _dt(a), _dt(out)
     if residual is not None:
         _rowmajor(residual, "residual")
         args.residual, args.ldr, args.res_dt = residual.data_ptr(), _ld(residual), _dt(residual)
@@ -221,7 +224,7 @@ def geometry(S, h, w, level_shapes, dim_t, level_embeds, offset, eps, scale, *, 
 
 def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):
     """out[h, n] = alpha * x[h, :] . w[h, n, :] + bias[h, n]; x [H, D], w [H, N, D], bias [H, N] (all fp32) -> [H, N] fp32
-    (bf16_copy: -> (out, out rounded to bf16), the copy written by the same launch)."""
+    (bf16_copy: True or a 16-bit dtype -> (out, out rounded to that type; True = bfloat16), the copy written by the same launch)."""
     _dev(x, w, bias)
     if x.dtype != torch.float32 or w.dtype != torch.float32 or not w.is_contiguous():
         raise TypeError("ape_amd.ops.head_gemv: fp32 x and contiguous fp32 w")
@@ -232,8 +235,12 @@ def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != H * N):
         raise ValueError("ape_amd.ops.head_gemv: bias must be a contiguous fp32 [H, N] tensor")
     out = torch.empty((H, N), dtype=torch.float32, device=x.device)
-    cp = torch.empty((H, N), dtype=torch.bfloat16, device=x.device) if bf16_copy else None
-    rc = _lib.load().ape_hip_head_gemv(_p(x), _ld(x), _p(w), _p(bias), _p(out), N, H, N, D, float(alpha), _p(cp), N, _stream())
+    cdt = torch.bfloat16 if bf16_copy is True else bf16_copy
+    if bf16_copy and cdt not in HALF16:
+        raise TypeError("ape_amd.ops.head_gemv: the copy is bfloat16 or float16")
+    cp = torch.empty((H, N), dtype=cdt, device=x.device) if bf16_copy else None
+    rc = _lib.load().ape_hip_head_gemv(_p(x), _ld(x), _p(w), _p(bias), _p(out), N, H, N, D, float(alpha), _p(cp), N,
+                                       _dt(cp) if cp is not None else 0, _stream())
     _lib.check(rc, "ape_hip_head_gemv")
     return (out, cp) if bf16_copy else out
 
@@ -269,8 +276,8 @@ def postnorm_residual(stream, t, norm, copy_dtype=None):
     if stream.dtype != torch.float32:
         raise TypeError("ape_amd.ops.postnorm_residual: the residual stream is float32")
     M, C = stream.shape
-    if copy_dtype not in (None, torch.float32, torch.bfloat16) or (t is not None and t.dtype not in (torch.float32, torch.bfloat16)):
-        raise TypeError("ape_amd.ops.postnorm_residual: t and the copy are float32 or bfloat16")
+    if copy_dtype not in (None, torch.float32) + HALF16 or (t is not None and t.dtype not in (torch.float32,) + HALF16):
+        raise TypeError("ape_amd.ops.postnorm_residual: t and the copy are float32, bfloat16 or float16")
     copy = torch.empty((M, C), dtype=copy_dtype, device=stream.device) if copy_dtype is not None else None
     w = b = None
     eps = 0.0
@@ -337,7 +344,7 @@ def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_lo
     if sampling_loc.shape[3] != L:
         raise ValueError("ms_deform_attn_forward: num_levels mismatch")
     out = torch.empty((B, Q, M * D), dtype=value.dtype, device=value.device)
-    dt = 2 if value.dtype == torch.float16 else _dt(value)          # APE_DT_F16: half storage, fp32 arithmetic
+    dt = _dt(value)          # APE_DT_F16: half storage, fp32 arithmetic
     rc = _lib.load().ape_hip_ms_deform_attn_forward(_p(value), M * D, shp, st, _p(sampling_loc), _p(attn_weight), _p(out),
                                                    M * D, B, S, Q, L, dt, _stream())
     _lib.check(rc, "ape_hip_ms_deform_attn_forward")
@@ -360,11 +367,13 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     if offw.shape[1] != 8 * L * 4 * 3 or ref.shape[-2] != L:
         raise ValueError("ape_amd.ops.msda_fused: offw/ref shape mismatch")
     if out is None:
+        # half values: the f16 flavour of the pipeline writes f16; the bf16 flavour (half VALUES next to bf16 activations) passes
+        # out_dtype=torch.bfloat16 explicitly (layers/multi_scale_deform_attn.py)
         out = torch.empty((batch * Q, 256), dtype=out_dtype or value.dtype, device=value.device)
+    if offw.dtype == torch.float16 and value.dtype == torch.float32:
+        raise TypeError("ape_amd.ops.msda_fused: half offsets go with bf16 / f16 values")
     fn = _lib.load().ape_hip_msda_fused_h if offw.dtype == torch.float16 else _lib.load().ape_hip_msda_fused
-    v_dt = _lib.DT_F16 if value.dtype == torch.float16 else _dt(value)          # IEEE-half values: bf16 / f32 output
-    if value.dtype == torch.float16 and out is None and out_dtype is None:
-        raise TypeError("ape_amd.ops.msda_fused: half values need an explicit out / out_dtype (bfloat16 or float32)")
+    v_dt = _dt(value)
     rc = fn(_p(value), _ld(value), v_dt, shp, st, _p(offw), _ld(offw), _p(ref), ref.shape[-1], _p(out), _ld(out), _dt(out),
             batch, S, Q, L, _stream())
     _lib.check(rc, "ape_hip_msda_fused")
@@ -1020,32 +1029,34 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
 
 
 def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False, norm=None):
-    """residual + relu(x w1^T + b1) w2^T + b2 in one kernel (csrc/ffn_fused.hip); x [M, 256] bf16, w1 [HID, 256],
-    w2 [256, HID] bf16 (w2_permuted: hidden columns in packing.permute_ffn_w2's order), biases fp32 -> [M, 256] bf16.  The hidden
+    """residual + relu(x w1^T + b1) w2^T + b2 in one kernel (csrc/ffn_fused.hip); x [M, 256], w1 [HID, 256],
+    w2 [256, HID] (w2_permuted: hidden columns in packing.permute_ffn_w2's order) all bf16 or all fp16, biases fp32 -> [M, 256] in x's type.  The hidden
     activations never reach HBM.  norm = (weight [256], bias [256], eps): the result is LayerNorm(residual + ffn(x)) (fp32 statistics of
     the fp32 sums) -- the transformer layer's post-FFN norm in the same launch."""
     _dev(x, w1, w2, b1, b2, residual, out)
     for t, name in ((x, "x"), (w1, "w1"), (w2, "w2")):
         _rowmajor(t, name)
-        if t.dtype != torch.bfloat16:
-            raise TypeError(f"ape_amd.ops.ffn_fused: {name} must be bfloat16")
+        if t.dtype not in HALF16 or t.dtype != x.dtype:
+            raise TypeError(f"ape_amd.ops.ffn_fused: {name} must be bfloat16 or float16, one type per call")
     M, K = x.shape
     HID, N = w1.shape[0], w2.shape[0]
     if w1.shape[1] != K or w2.shape[1] != HID:
         raise ValueError("ape_amd.ops.ffn_fused: weight shapes do not chain")
     if out is None:
-        out = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if out.dtype != x.dtype:
+        raise TypeError("ape_amd.ops.ffn_fused: out must have x's dtype")
     if residual is not None:
         _rowmajor(residual, "residual")
-        if residual.dtype != torch.bfloat16 or tuple(residual.shape) != (M, N):
-            raise TypeError("ape_amd.ops.ffn_fused: residual must be bfloat16 [M, N]")
+        if residual.dtype != x.dtype or tuple(residual.shape) != (M, N):
+            raise TypeError("ape_amd.ops.ffn_fused: residual must be [M, N] in x's dtype")
     if norm is not None:
         _dev(norm[0], norm[1])
         if norm[0].numel() != N or norm[1].numel() != N:
             raise ValueError("ape_amd.ops.ffn_fused: norm = (weight [N], bias [N], eps)")
     rc = _lib.load().ape_hip_ffn_fused(_p(x), _ld(x), _p(w1), _ld(w1), _p(_f32vec(b1, "b1")), _p(w2), _ld(w2), _p(_f32vec(b2, "b2")),
                                       _p(residual), _ld(residual) if residual is not None else 0, _p(out), _ld(out), M, K, HID, N,
-                                      1 if w2_permuted else 0, _p(_f32vec(norm[0], "norm weight")) if norm is not None else None,
+                                      1 if w2_permuted else 0, _dt(x), _p(_f32vec(norm[0], "norm weight")) if norm is not None else None,
                                       _p(_f32vec(norm[1], "norm bias")) if norm is not None else None,
                                       float(norm[2]) if norm is not None else 0.0, _stream())
     _lib.check(rc, "ape_hip_ffn_fused")

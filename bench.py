@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=3, help="images the CPU oracle times after its warm-up pass (cpu_baseline)")
     ap.add_argument("--ap-images", type=int, default=16,
                     help="seeded images for the box-AP parity number (bf16 detections vs the fp32 pipeline's as pseudo ground truth)")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
+                    help="16-bit flavour of the timed pipeline: bf16 = BASELINE's dtype (default); f16 = IEEE half operands, the reference's "
+                         "own evaluation dtype (tools/train_net.py:642) -- same kernels, v_mfma_f32_16x16x32_f16, 3 more mantissa bits")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="no software pipeline over steps (ViT of step i+1 || tails of step i inside one graph)")
     return ap.parse_args()
@@ -116,7 +119,7 @@ class GemmMeter:
         """the eight-wave tile kernel is compiled once per epilogue (third template argument, csrc/gemm_p8.hip): the roofline
         object is about the tile kernel as a whole = the sum over its epilogue specialisations"""
         import re
-        return re.sub(r"^(gemm_bf16_p8_kernel<\d+, \w+), \d+>$", r"\1>", name)
+        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), \d+>$", r"\1>", name)
 
     def summary(self):
         """per kernel family: (launches, seconds, flops), sorted by time; and per exact symbol (as rocprofv3 lists them)"""
@@ -201,13 +204,17 @@ def _detections_of(out):
     return out["det_boxes"][keep].float().cpu(), out["det_scores"][keep].float().cpu(), out["det_classes"][keep].cpu()
 
 
-def box_ap_vs_fp32(mv, images, text):
-    """COCO box AP (IoU 0.50:0.95) of the bf16 pipeline's detections against the fp32-kernel pipeline's detections of the same
+DTYPES = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def box_ap_vs_fp32(mv, images, text, flavours=("bf16", "f16")):
+    """COCO box AP (IoU 0.50:0.95) of each 16-bit pipeline's detections (bf16 = the timed default; f16 = the reference's eval dtype) against the fp32-kernel pipeline's detections of the same
     images as pseudo ground truth (the fp32 pipeline is pinned to the reference's fixtures to <= 1e-3: tests/test_model_gpu.py
     ::test_L_D_fp32_matches_reference).  Both runs select their own proposals (nothing is teacher forced)."""
     from ape_amd.evaluation import box_ap
 
-    gts, dets, same_set, ctl, spread = [], [], [], [], []
+    gts, ctl, spread = [], [], []
+    dets, same_set = {f: [] for f in flavours}, {f: [] for f in flavours}
     gen = torch.Generator().manual_seed(7001)
     for img in images:
         mv.set_compute_dtype(torch.float32)
@@ -218,18 +225,19 @@ def box_ap_vs_fp32(mv, images, text):
         noisy = img + (torch.rand(img.shape, generator=gen) - 0.5).to(img.device)
         ctl.append(_detections_of(mv.forward_single(noisy, text, with_masks=False)))
         spread.append(float(rs.max() - rs.min()) if rs.numel() else 0.0)
-        mv.set_compute_dtype(torch.bfloat16)
-        got = mv.forward_single(img, text, with_masks=False)
-        gb, gs, gc = _detections_of(got)
         gts.append((rb, rc))
-        dets.append((gb, gs, gc))
         a = set(zip(ref["det_query"].tolist(), ref["det_classes"].tolist()))
-        b = set(zip(got["det_query"].tolist(), got["det_classes"].tolist()))
-        same_set.append(len(a & b) / max(len(a), 1))
-    mv.set_compute_dtype(torch.bfloat16)
-    r = box_ap(dets, gts)
+        for f in flavours:
+            mv.set_compute_dtype(DTYPES[f])
+            got = mv.forward_single(img, text, with_masks=False)
+            dets[f].append(_detections_of(got))
+            b = set(zip(got["det_query"].tolist(), got["det_classes"].tolist()))
+            same_set[f].append(len(a & b) / max(len(a), 1))
+    r = {}
+    for f in flavours:
+        r[f] = box_ap(dets[f], gts)
+        r[f]["same_query_class_pairs"] = sum(same_set[f]) / max(len(same_set[f]), 1)
     r["images"] = len(images)
-    r["same_query_class_pairs"] = sum(same_set) / max(len(same_set), 1)
     c = box_ap(ctl, gts)
     r["control_fp32_on_half_grey_level_input_noise"] = {"AP": c["AP"], "AP50": c["AP50"], "AP75": c["AP75"]}
     r["fp32_detection_score_range"] = sum(spread) / max(len(spread), 1)
@@ -239,10 +247,31 @@ def box_ap_vs_fp32(mv, images, text):
     return r
 
 
-def parity_object(mv, images, text, stages_per_image, ap_images):
-    """the bf16 HIP pipeline against the oracle's fp32 forwards of the same images (same weights): head tensors with the
-    oracle's proposal order injected (max-abs error / max-abs reference, and rms), detection-level agreement of the free run,
-    box AP against the oracle's detections (the timed images) and against the fp32 pipeline's (ap_images seeded images)"""
+def parity_object(mv, images, text, stages_per_image, ap_images, timed="bf16"):
+    """both 16-bit flavours of the HIP pipeline (bf16 and f16; `timed` names the one the line's `value` was measured on) against the
+    oracle's fp32 forwards of the same images (same weights): head tensors with the oracle's proposal order injected (max-abs
+    error / max-abs reference, and rms), detection-level agreement of the free run, box AP against the oracle's detections (the
+    timed images) and against the fp32 pipeline's (ap_images seeded images)"""
+    res = {"timed_flavour": timed}
+    for f in ("bf16", "f16"):
+        mv.set_compute_dtype(DTYPES[f])
+        res[f] = _parity_one(mv, images, text, stages_per_image)
+    for k in ("pred_logits_relerr", "pred_boxes_relerr", "proposal_overlap", "detections_matched"):     # the timed flavour's, at top level
+        res[k] = res[timed][k]
+    res["against"] = res[timed].pop("against")
+    res["f16"].pop("against", None), res["bf16"].pop("against", None)
+    res["match_rule"] = "same class, |score| < 0.05, box within 5 %"
+    res["note"] = ("16-bit storage / fp32 accumulate vs fp32; f16 = the reference's own evaluation dtype (tools/train_net.py:642), bf16 = "
+                   "BASELINE's; max-norm head errors of a random-weight model are single-query outliers of the decoder's refinement "
+                   "(profiles/r03_bf16_error_trace.log); the fp32 kernels meet 1e-3 (tests/test_model_gpu.py)")
+    if ap_images > 0:
+        S = images[0].shape[-1]
+        res["box_ap_vs_fp32_pipeline"] = box_ap_vs_fp32(mv, make_images(ap_images, S, seed=7000, device=images[0].device), text)
+    mv.set_compute_dtype(DTYPES[timed])
+    return res
+
+
+def _parity_one(mv, images, text, stages_per_image):
     from ape_amd.evaluation import box_ap
 
     def rel(a, b):
@@ -278,13 +307,7 @@ def parity_object(mv, images, text, stages_per_image, ap_images):
     res = {"against": f"oracle fp32 (CPU) on {len(per_image)} image(s), same seeded weights; per-stage teacher-forced bounds: tests/test_teacher_forced.py",
            "pred_logits_relerr": first["pred_logits_relerr"], "pred_boxes_relerr": first["pred_boxes_relerr"],
            "proposal_overlap": first["proposal_overlap"], "detections_matched": first["detections_matched"],
-           "match_rule": "same class, |score| < 0.05, box within 5 %", "per_image": per_image,
-           "box_ap_vs_oracle": box_ap(dets, gts),
-           "note": "bf16 storage / fp32 accumulate vs fp32; max-norm head errors of a random-weight model are single-query outliers of the "
-                   "decoder's chaotic refinement (profiles/r03_bf16_error_trace.log), the fp32 kernels meet 1e-3 (tests/test_model_gpu.py)"}
-    if ap_images > 0:
-        S = images[0].shape[-1]
-        res["box_ap_vs_fp32_pipeline"] = box_ap_vs_fp32(mv, make_images(ap_images, S, seed=7000, device=images[0].device), text)
+           "per_image": per_image, "box_ap_vs_oracle": box_ap(dets, gts)}
     return res
 
 
@@ -376,7 +399,7 @@ def main():
 
     model = init_synthetic(build_ape(args.size), seed=0).to(dev)
     mv = model.model_vision
-    mv.set_compute_dtype(torch.bfloat16)
+    mv.set_compute_dtype(DTYPES[args.dtype])
     S = mv.backbone.padding_constraints["square_size"]
     from ape_amd.dp import DataParallelRunner
 
@@ -480,7 +503,7 @@ def main():
         result = {
             "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": world * args.steps * B / elapsed, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
                                    f"{B} images, everything after it one batch-1 forward per image ({B} parallel branches of one "
                                    f"hipGraph); {args.classes} classes (name prompt), masks on, top-{mv.test_topk_per_image} detections "
@@ -501,13 +524,15 @@ def main():
                                      for k, v in sorted(meter.symbols.items(), key=lambda kv: -kv[1][1]) if GemmMeter.family(k) == dom_name},
                          "all_gemm_kernels": {"ms_per_image": 1e3 * all_t / reps, "tflops": all_fl / all_t / 1e12,
                                               "flops_per_image": all_fl / reps,
-                                              "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups}}},
+                                              "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups},
+                                              "by_kernel_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in groups},
+                                              "by_kernel_launches_per_image": {k: round(v[0] / reps, 2) for k, v in groups}}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
                 timed = [im.contiguous() for im in images[:max(1, args.cpu_images)]]
                 result["cpu_baseline"], O = cpu_baseline(model, args.size, timed, text, n_images=args.cpu_images)
-                result["parity"] = parity_object(mv, timed, text, O, args.ap_images)
+                result["parity"] = parity_object(mv, timed, text, O, args.ap_images, timed=args.dtype)
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 import traceback
                 result.setdefault("cpu_baseline", {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",

@@ -258,9 +258,10 @@ int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, int x_dt, i
                     float* out, void* stream);
 /* per-head matrix-vector products of the same language side (fuse_helper.py:70-73 v_proj / values_v_proj applied to one
  * pooled vector per head): out[h][n] = alpha * sum_d x[h][d] * W[h][n][d] + bias[h][n]; x [H, ldx], W [H, N, D], bias [H, N] or
- * NULL, out [H, ldo], fp32; out_bf16 [H, ldob] (may be NULL) receives a bf16 copy.  -- csrc/vlpool.hip */
+ * NULL, out [H, ldo], fp32; out_bf16 [H, ldob] (may be NULL) receives a 16-bit copy in copy_dt (APE_DT_BF16 | APE_DT_F16).
+ * -- csrc/vlpool.hip */
 int ape_hip_head_gemv(const float* x, int ldx, const float* W, const float* bias, float* out, int ldo, int H, int N, int D,
-                      float alpha, void* out_bf16, int ldob, void* stream);
+                      float alpha, void* out_bf16, int ldob, int copy_dt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Softmaxes of the DENSE bi-directional attention (L > 1 text tokens: phrase / expression prompts;
@@ -434,7 +435,8 @@ int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* or
 
 /* ---------------------------------------------------------------------------------------------
  * The encoder / decoder FFN in one kernel: y = residual + relu(x W1^T + b1) W2^T + b2 (detrex FFN with add_identity,
- * ape/modeling/ape_deta/deformable_transformer_vl.py:45-54 and :160-166), bf16 in / out, K = N = 256, HID %% 64 == 0 (<= 4096).
+ * ape/modeling/ape_deta/deformable_transformer_vl.py:45-54 and :160-166), 16-bit in / out (dt = APE_DT_BF16 | APE_DT_F16: x, the
+ * weights, the residual, y and the hidden activation between the two contractions all in that type), K = N = 256, HID %% 64 == 0 (<= 4096).
  * The hidden activations stay in registers as the B operand of the second MFMA (csrc/ffn_fused.hip): the [M, HID] tensor the
  * two-GEMM form writes and reads back (357 MB per encoder layer at 1024^2) never exists.  residual may be NULL.
  * w2_permuted != 0: W2's hidden columns are stored pre-permuted inside every group of 32 -- position 8 g + e holds hidden
@@ -443,7 +445,7 @@ int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* or
  * "norm" that follows the "ffn" in detrex's BaseTransformerLayer -- on the fp32 sums, in the same launch.
  * ------------------------------------------------------------------------------------------- */
 int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw1, const float* b1, const void* W2, int ldw2, const float* b2,
-                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted,
+                      const void* residual, int ldr, void* Y, int ldy, int M, int K, int HID, int N, int w2_permuted, int dt,
                       const float* ln_weight, const float* ln_bias, float ln_eps, void* stream);
 
 #ifdef __cplusplus

@@ -81,7 +81,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
 def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):
     out = torch.einsum("hd,hnd->hn", x.float(), w.float()) * alpha
     out = out + bias.float().reshape(out.shape) if bias is not None else out
-    return (out, out.to(torch.bfloat16)) if bf16_copy else out
+    return (out, out.to(torch.bfloat16 if bf16_copy is True else bf16_copy)) if bf16_copy else out
 
 
 def row_stats(x, eps):
@@ -553,19 +553,19 @@ def detections(logits, boxes, scale, score_thresh, iou_thr, topk):
 
 
 def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False, norm=None):
-    """the two-GEMM form at the kernel's rounding points: H rounded to bf16, fp32 accumulation, one rounding of the output"""
+    """the two-GEMM form at the kernel's rounding points: H rounded to x's 16-bit type, fp32 accumulation, one rounding of the output"""
     if w2_permuted:
         from ape_amd.packing import ffn_w2_perm
         inv = torch.empty(w2.shape[1], dtype=torch.long)
         inv[ffn_w2_perm(w2.shape[1])] = torch.arange(w2.shape[1])
         w2 = w2[:, inv.to(w2.device)]
-    h = torch.relu(x.float() @ w1.float().t() + b1.float()).to(torch.bfloat16)
+    h = torch.relu(x.float() @ w1.float().t() + b1.float()).to(x.dtype)
     y = h.float() @ w2.float().t() + b2.float()
     if residual is not None:
         y = y + residual.float()
     if norm is not None:                      # LayerNorm of the fp32 sums (the kernel's epilogue), one rounding of the result
         y = F.layer_norm(y, (y.shape[1],), norm[0].float(), norm[1].float(), norm[2])
-    y = y.to(torch.bfloat16)
+    y = y.to(x.dtype)
     if out is not None:
         out.copy_(y)
         return out

@@ -25,6 +25,8 @@ import torch
 from ape_amd.stagetap import StageTap, rel_max, rel_rms
 
 U_RMS = 2.0 ** -8 / math.sqrt(3.0)
+# the same derivation for the IEEE-half flavour of the pipeline (11 significant bits; the reference's own evaluation dtype)
+U_RMS_BY_DTYPE = {torch.bfloat16: 2.0 ** -8 / math.sqrt(3.0), torch.float16: 2.0 ** -11 / math.sqrt(3.0)}
 GAIN = 2.0
 SIGMA_MAX = 8.0
 
@@ -80,9 +82,9 @@ def roundings(key):
     return None
 
 
-def tolerance(key):
+def tolerance(key, dt=torch.bfloat16):
     r = roundings(key)
-    return None if r is None else GAIN * U_RMS * math.sqrt(r)
+    return None if r is None else GAIN * U_RMS_BY_DTYPE[dt] * math.sqrt(r)
 
 
 def _f(t):
@@ -107,7 +109,7 @@ def linear_head_scales(model, teacher):
     return {"enc_cls2": s, "enc_class": s}
 
 
-def stage_errors(got, teacher, biases=None, scales=None):
+def stage_errors(got, teacher, biases=None, scales=None, dt=torch.bfloat16):
     """-> {key: dict(rms, max, tol, tol_max, R, n)} for every key the teacher-forced run tapped and the table knows.
     scales: {key: absolute rms scale} replaces the denominator rms(ref) (linear_head_scales)"""
     res = {}
@@ -136,13 +138,13 @@ def stage_errors(got, teacher, biases=None, scales=None):
             mx = err.abs().max().item()
             if dkey in teacher and key != "init_reference":
                 d_rms = _f(teacher[dkey]).pow(2).mean().sqrt().item()
-                tol = 0.25 * tolerance("dec0_delta") * d_rms
+                tol = 0.25 * tolerance("dec0_delta", dt) * d_rms
                 R = roundings("dec0_delta")
             else:
                 tol, R = 1e-6, 0                 # sigmoid of teacher-forced fp32 coordinates: fp32 arithmetic only
             res[key] = dict(rms=rms, max=mx, tol=tol, tol_max=SIGMA_MAX * tol, R=R, n=n, kind="abs")
             continue
-        tol = tolerance(key)
+        tol = tolerance(key, dt)
         if tol is None:
             continue
         if key in scales:
@@ -186,22 +188,22 @@ def path_roundings(model):
             "pred_boxes": memory + 4 + nd * 21 + 6}
 
 
-def path_bound(model, key):
-    return GAIN * U_RMS * math.sqrt(path_roundings(model)[key])
+def path_bound(model, key, dt=torch.bfloat16):
+    return GAIN * U_RMS_BY_DTYPE[dt] * math.sqrt(path_roundings(model)[key])
 
 
-def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name"):
-    """fp32 teacher run, teacher-forced bf16 run, (optionally) free-running bf16 run of one model on one image.
+def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name", dt=torch.bfloat16):
+    """fp32 teacher run, teacher-forced 16-bit run (dt = bfloat16 | float16), (optionally) free-running 16-bit run of one model on one image.
     -> (forced errors {key: ...}, free-running errors {key: ...} or None, outputs dict)"""
     mv = model.model_vision
     mv.set_compute_dtype(torch.float32)
     teacher = StageTap()
     out32 = mv.forward_single(image, text, forced_topk=ref_topk, stages=teacher, semantic=semantic, prompt=prompt)
-    mv.set_compute_dtype(torch.bfloat16)
+    mv.set_compute_dtype(dt)
     forced = StageTap(teacher=teacher)
     out_f = mv.forward_single(image, text, forced_topk=ref_topk, stages=forced, semantic=semantic, prompt=prompt)
     biases, scales = head_biases(model), linear_head_scales(model, teacher)
-    ferr = stage_errors(forced, teacher, biases, scales)
+    ferr = stage_errors(forced, teacher, biases, scales, dt)
     if "enc_cls2" in forced and "enc_cls2" in teacher:          # tokens whose main / ambiguous choice a rounding flipped
         flips = int((forced["enc_cls2"].float().argmax(1) != teacher["enc_cls2"].float().argmax(1).to(forced["enc_cls2"].device)).sum())
         ferr["enc_cls2"]["flips"] = flips
@@ -209,7 +211,7 @@ def run(model, image, text, ref_topk, semantic=None, free_run=True, prompt="name
     if free_run:
         free = StageTap()
         out_b = mv.forward_single(image, text, forced_topk=ref_topk, stages=free, semantic=semantic, prompt=prompt)
-        free_err = stage_errors(free, teacher, biases, scales)
+        free_err = stage_errors(free, teacher, biases, scales, dt)
     return ferr, free_err, dict(fp32=out32, forced=out_f, free=out_b, teacher=teacher, forced_stages=forced,
                                 free_stages=free)
 
