@@ -95,7 +95,8 @@ def _iou_matrix(a, b):
 def box_ap(detections, ground_truth, iou_thresholds=None, max_dets=100):
     """COCO-style box AP of `detections` against `ground_truth` (the protocol of pycocotools' COCOeval that the reference's
     evaluators run -- ape/evaluation/lvis_evaluation.py / detectron2's COCOEvaluator -- restated: area range "all", no crowd
-    regions, at most `max_dets` detections per image, IoU thresholds 0.50:0.05:0.95, greedy matching in score order to the
+    regions, at most `max_dets` detections per (image, CATEGORY) -- COCOeval applies maxDets inside its per-category evaluateImg, so a
+    model top-k of 300 / 500 loses nothing to the default 100 --, IoU thresholds 0.50:0.05:0.95, greedy matching in score order to the
     unmatched ground truth of the same class with the highest IoU, precision made monotone and sampled at 101 recall points,
     averaged over thresholds and over the classes that have ground truth).  pycocotools is not installable here: unpinned.
 
@@ -110,10 +111,10 @@ def box_ap(detections, ground_truth, iou_thresholds=None, max_dets=100):
     for (db, ds, dc), (gb, gc) in zip(detections, ground_truth):
         db, ds, dc = db.detach().cpu().double(), ds.detach().cpu().double(), dc.detach().cpu().long()
         gb, gc = gb.detach().cpu().double(), gc.detach().cpu().long()
-        order = torch.argsort(ds, descending=True, stable=True)[:max_dets]
+        order = torch.argsort(ds, descending=True, stable=True)
         db, ds, dc = db[order], ds[order], dc[order]
         for c in set(dc.tolist()) | set(gc.tolist()):
-            d_idx, g_idx = (dc == c).nonzero().flatten(), (gc == c).nonzero().flatten()
+            d_idx, g_idx = (dc == c).nonzero().flatten()[:max_dets], (gc == c).nonzero().flatten()
             n_gt[c] = n_gt.get(c, 0) + int(g_idx.numel())
             if d_idx.numel() == 0:
                 continue

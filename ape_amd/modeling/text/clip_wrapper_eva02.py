@@ -35,8 +35,39 @@ class _TextFeatures(dict):
         except KeyError:
             return default
 
+    def _materialise(self):
+        if self._lazy_full is not None:
+            self["last_hidden_state"]           # __missing__ computes and stores it
+
+    # every whole-dict view materialises first, so iteration / items() / values() / len() / copy() / dict(ret) / pickling all see
+    # the four keys of the reference's dict; only [] / get / in on the OTHER keys stay lazy
     def keys(self):
-        return list(dict.keys(self)) + (["last_hidden_state"] if self._lazy_full is not None else [])
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._materialise()
+        return dict.__len__(self)
+
+    def copy(self):
+        self._materialise()
+        return dict(self)
+
+    def __reduce__(self):
+        self._materialise()
+        return (dict, (dict(dict.items(self)),))
 
 
 class EVA02CLIP(nn.Module):

@@ -348,7 +348,10 @@ class GraphedForward:
             if len(self._graphs) >= self.max_graphs:
                 oldest = next(iter(self._graphs))
                 self.flush(self._graphs[oldest])       # a ticket waiting for its tails keeps its entry alive through ticket.entry
-                self._retire(self._graphs.pop(oldest))
+                # park FIRST, pop afterwards: when the retire limit refuses, the entry must stay live in _graphs -- popped and
+                # not parked, its hipGraph would be destroyed by the garbage collector, the one thing this stack does not survive
+                self._retire(self._graphs[oldest])
+                del self._graphs[oldest]
             e = self._graphs[key] = self._build(images, text, frames[0][0], frames[0][1], prompt)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=images[0].device)

@@ -42,7 +42,10 @@ def test_properties():
     assert box_ap(extra, gt)["AP"] == 1.0
     miss = [(b[c != 0], s[c != 0], c[c != 0]) for b, s, c in det]
     assert abs(box_ap(miss, gt)["AP"] - 0.8) < 1e-12
-    # max_dets: only the 100 best-scored detections of an image count
+    # max_dets counts per (image, CATEGORY) like COCOeval's evaluateImg: 30 true positives behind 120 better-scored false ones, i.e.
+    # per class n true behind 4 n false -- with a cap of min-class-count the kept ones are all false, with the default 100 nothing is cut
     many_b = torch.cat([gt[0][0]] + [gt[0][0] + 2000] * 4)
     many = [(many_b, torch.cat([torch.rand(30, generator=g)] + [torch.rand(30, generator=g) + 2] * 4), torch.cat([gt[0][1]] * 5))]
-    assert box_ap(many, gt[:1])["AP"] == 0.0 and box_ap(many, gt[:1], max_dets=150)["AP"] > 0.0
+    fewest = int(torch.bincount(gt[0][1], minlength=5).min())
+    assert fewest >= 1 and box_ap(many, gt[:1], max_dets=4 * fewest)["AP"] == 0.0 and box_ap(many, gt[:1])["AP"] > 0.0
+    assert box_ap(many, gt[:1])["dets"] == 150

@@ -544,6 +544,15 @@ def test_graph_retirement_is_bounded(monkeypatch):
     with pytest.raises(RuntimeError, match="any_size=True"):
         run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30))
     assert runtime.retired_graphs() == (3, 9 << 30)                      # nothing parked by the refused eviction
+    # eviction through submit(): a refused eviction leaves the entry LIVE in _graphs (popped and not parked it would be
+    # garbage-collected, i.e. destroyed)
+    victim = SimpleNamespace(graph=object(), pool_bytes=3 << 30)
+    run._graphs = {"old": victim}
+    run.max_graphs, run.any_size, run.B, run.flush = 1, False, 1, lambda e: None
+    img = torch.zeros(3, 8, 8)
+    with pytest.raises(RuntimeError, match="any_size=True"):
+        run.submit(img, torch.zeros(2, 4))
+    assert run._graphs.get("old") is victim and runtime.retired_graphs() == (3, 9 << 30)
     run._retire(SimpleNamespace(graph=None))                             # eager entries hold no graph
     run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30), strict=False)      # destructors park unconditionally
     rep = run.memory_report()

@@ -81,8 +81,11 @@ def test_host_model_matches_reference_fixture(fake_ops):
         assert relerr(out2["last_hidden_state_eot"], g[name]["eot"][:8]) < 1e-5
         # the reference's dict always carries the projected features of all 77 positions (clip_wrapper_eva02.py:117-122): here
         # they materialise on first access (nothing on the name-prompt path reads them)
-        assert "last_hidden_state" in out2 and "last_hidden_state" in out2.keys() and not dict.__contains__(out2, "last_hidden_state")
+        assert "last_hidden_state" in out2 and not dict.__contains__(out2, "last_hidden_state")      # lazy until someone looks
         assert relerr(out2["last_hidden_state"], g[name]["full"][:8]) < 1e-5 and dict.__contains__(out2, "last_hidden_state")
+        # whole-dict views see the reference's four keys, whether or not the lazy one was touched before
+        out3 = m2.forward_tokens(short)                             # a fresh dict whose lazy key nobody touched
+        assert set(dict(out3)) == set(out3.keys()) == {k for k, _ in out3.items()} and "last_hidden_state" in set(out3) and len(out3) == len(list(out3))
         # TextTransformer.forward(return_all_features=True) = ln_final(x) WITHOUT the projection (transformer.py:722-737)
         raw = m2.net.text(short, return_all_features=True)
         assert raw.shape == (8, short.shape[1], cfg["width"] if "width" in cfg else raw.shape[-1])
