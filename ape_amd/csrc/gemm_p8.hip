@@ -48,7 +48,9 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, bool STAGGER, typename H = bf16_t>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
+// ABL (builds with -DAPE_P8_ABLATION only; tools/gpu_p8_ablate.py): 0 = the kernel; 1 = epilogue without its bias / table / residual
+// loads; 2 = full epilogue, no stores; 3 = no epilogue; 4 = one K tile only (prologue + epilogue)
+template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const int nk = p.K / P8_BK;
+  const int nk = ABL == 4 ? 1 : p.K / P8_BK;
   constexpr int INFLIGHT = 2 * NIB + 2;          // loads of the three youngest half-tiles at a phase-4 wait: B0, A0, B1
   // ---- prologue: K tile 0 complete, the first three half-tiles of K tile 1 in flight
   issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
@@ -229,6 +231,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   // ---- epilogue from registers: lane (frow, fq) owns rows tile_i * 16 + frow, TN * 4 consecutive columns
   constexpr int W = TN * 4;
   const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
+  if (ABL == 3) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   // wave-uniform: the wave's whole column slab is inside N (a partial slab takes the generic, bounds-checked path)
   const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
   // one specialisation per launch (wave-uniform): the unrolled body stays short
@@ -244,8 +253,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[4 * j + r] = acc[i][j][r];
-        epi_row_fast<W, ROPE, NORM, ACT, H>(p, m, nb, o);
-        if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, nb >> 1, o);
+        if (ABL == 1) {            // the arithmetic of the epilogue on register constants: no bias / table / residual loads
+          const float c = p.alpha, sn = p.clamp;
+          if (ROPE) {
+#pragma unroll
+            for (int e = 0; e < W; e += 2) { const float x0 = o[e] + c, x1 = o[e + 1] + c; o[e] = x0 * c - x1 * sn; o[e + 1] = x1 * c + x0 * sn; }
+          } else if (ACT == EPI_ACT_SWIGLU) {
+#pragma unroll
+            for (int e = 0; e < W / 2; ++e) { const float g = o[2 * e] + c, u = o[2 * e + 1] + c; o[e] = (g / (1.f + __expf(-g))) * u; }
+          } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], c, sn);
+          }
+        } else {
+          epi_row_fast<W, ROPE, NORM, ACT, H>(p, m, nb, o);
+        }
+        if (ABL == 2) {
+#pragma unroll
+          for (int e = 0; e < W; ++e) asm volatile("" ::"v"(o[e]));
+        } else if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, nb >> 1, o);
         else store_row<W, H>(p, m, nb, o);
       }
     }
@@ -313,6 +339,19 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     hipLaunchKernelGGL((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(tiles), dim3(512), LDS_, s, p);                        \
     name = NAME_;                                                                                                       \
   } while (0)
+#ifdef APE_P8_ABLATION
+  {
+    const char* ab = getenv("APE_P8_ABLATE");
+    const int abl = ab ? atoi(ab) : 0;
+    if (abl > 0 && bn == 256 && !f16) {
+#define P8_ABL(A_) do { (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+      hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, bf16_t, A_>), dim3(tiles), dim3(512), 131072, s, p); } while (0)
+      if (abl == 1) P8_ABL(1); else if (abl == 2) P8_ABL(2); else if (abl == 3) P8_ABL(3); else P8_ABL(4);
+#undef P8_ABL
+      return "gemm_bf16_p8_kernel<256, true> (ablation)";
+    }
+  }
+#endif
   if (bn == 256) {
     if (stagger) { if (f16) P8_LAUNCH(256, true, f16_t, 131072, "gemm_f16_p8_kernel<256, true>"); else P8_LAUNCH(256, true, bf16_t, 131072, "gemm_bf16_p8_kernel<256, true>"); }
     else { if (f16) P8_LAUNCH(256, false, f16_t, 131072, "gemm_f16_p8_kernel<256, false>"); else P8_LAUNCH(256, false, bf16_t, 131072, "gemm_bf16_p8_kernel<256, false>"); }

@@ -30,11 +30,37 @@ def shard_indices(n_items, rank, world):
     return list(range(begin, end))
 
 
+class _Gathered:
+    """all ranks' tensors of one step, gathered asynchronously: `.get()` waits for THIS collective only (on the exchange stream,
+    never on the compute stream) and returns the stacked [world, ...] tensor"""
+
+    def __init__(self, outs, work, stream):
+        self.outs, self.work, self.stream = outs, work, stream
+
+    def get(self):
+        if self.work is not None:
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    self.work.wait()
+                self.stream.synchronize()
+            else:
+                self.work.wait()
+            self.work = None
+        return torch.stack(self.outs)
+
+
 class DataParallelRunner:
-    def __init__(self, forward_fn, records_per_image, device, group=None, gather_masks=False):
-        """forward_fn(image, text) -> (host instances, device record tensor [records_per_image, 6])"""
+    def __init__(self, forward_fn, records_per_image, device, group=None, gather_masks=False, lag=0):
+        """forward_fn(image, text) -> (host instances, device record tensor [records_per_image, 6]).
+        lag = 1: result(ticket_i) returns the gathered records of ticket i-1 (None for the first; `drain()` returns the last):
+        the all-gather of step i is issued asynchronously, its completion is awaited one step later and only by the host -- the
+        compute stream never waits for a collective, so a slow rank delays the others' BOOK-KEEPING by a step, not their GPUs.
+        lag = 0: the records of the ticket itself (the collective completes before result() returns them)."""
         self.forward_fn = forward_fn
         self.gather_masks = gather_masks
+        self.lag = int(lag)
+        self._late = None                 # (ticket, _Gathered records, _Gathered runs | None) awaiting collection (lag = 1)
+        self._xstream = None
         self._gather_runs = None
         self.k = records_per_image
         self.device = device
@@ -74,6 +100,17 @@ class DataParallelRunner:
         dist.all_gather(self._gather_runs[1], nruns.contiguous(), group=self.group)
         return torch.stack(self._gather_runs[0]), torch.stack(self._gather_runs[1])
 
+    def _all_gather_async(self, t):
+        """enqueue the all-gather of `t` behind the work already on the compute stream; nothing waits for it until `.get()`"""
+        t = t.contiguous()
+        if self.world == 1:
+            return _Gathered([t], None, None)
+        outs = [torch.empty_like(t) for _ in range(self.world)]       # per step: the previous step's may still be unread
+        work = dist.all_gather(outs, t, group=self.group, async_op=True)
+        if t.is_cuda and self._xstream is None:
+            self._xstream = torch.cuda.Stream(device=t.device)
+        return _Gathered(outs, work, self._xstream if t.is_cuda else None)
+
     def _all_gather(self, rec):
         if self.world == 1:
             return rec[None]
@@ -103,11 +140,31 @@ class DataParallelRunner:
         a ticket's detections are produced by the NEXT step's replay, so the record all-gather is enqueued here (every rank
         collects its tickets in the same order, which keeps the collective matched)."""
         inst, rec = self.forward_fn.result(ticket)
+        if self.lag:
+            runs = None
+            if self.gather_masks and getattr(ticket, "runs", None) is not None:
+                runs = (self._all_gather_async(ticket.runs[0]), self._all_gather_async(ticket.runs[1]))
+            late, self._late = self._late, (ticket, self._all_gather_async(rec), runs)
+            return inst, self._collect(late)
         if getattr(ticket, "records", None) is None:
             ticket.records = self._all_gather(rec)
         if self.gather_masks and getattr(ticket, "mask_runs", None) is None and getattr(ticket, "runs", None) is not None:
             ticket.mask_runs = self._all_gather_runs(ticket.runs)       # every rank's masks as run lengths: ticket.mask_runs
         return inst, ticket.records
+
+    def _collect(self, late):
+        if late is None:
+            return None
+        ticket, rec, runs = late
+        ticket.records = rec.get()
+        if runs is not None:
+            ticket.mask_runs = (runs[0].get(), runs[1].get())
+        return ticket.records
+
+    def drain(self):
+        """lag = 1: the gathered records of the last collected ticket (whose exchange nobody has waited for yet)"""
+        late, self._late = self._late, None
+        return self._collect(late)
 
 
 # ------------------------------------------------------------------------------------------------------------------

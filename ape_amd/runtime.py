@@ -73,8 +73,15 @@ class GraphedForward:
     SLOTS = 2
 
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
-                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096, semantic=None):
+                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096, semantic=None,
+                 input_resize=(1024, 1024), input_format="RGB"):
         self.mv = model_vision
+        # uint8 inputs (the predictor's contract, ape/engine/defaults.py:213-222: the ORIGINAL BGR image): submit() takes uint8
+        # [H, W, 3] tensors -- pinned host memory or device -- and runs upload + ResizeShortestEdge(short_edge_length, max_size)
+        # + BGR->RGB + float CHW (csrc/imageio.hip resize_u8_kernel, bit exact with Pillow) straight into the step's static
+        # image buffer, stream-ordered in front of the replay; the output frame defaults to the ORIGINAL (H, W)
+        self.input_resize = (int(input_resize[0]), int(input_resize[1]))
+        self.input_flip = input_format == "RGB"
         self.batch_vit = batch_vit
         self.pipeline = bool(pipeline)
         self.any_size = bool(any_size)
@@ -213,6 +220,28 @@ class GraphedForward:
             jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
             return [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
 
+    # ------------------------------------------------------------------ inputs: float CHW model images or uint8 HWC originals
+    @staticmethod
+    def _is_raw(im):
+        return im.dtype == torch.uint8 and im.dim() == 3 and im.shape[-1] == 3
+
+    def _model_hw(self, im):
+        """(h, w) of the model input an image becomes"""
+        if self._is_raw(im):
+            from .engine import shortest_edge_size
+            return shortest_edge_size(int(im.shape[0]), int(im.shape[1]), *self.input_resize)
+        return int(im.shape[-2]), int(im.shape[-1])
+
+    def _write_input(self, dst, im):
+        """im -> dst (float32 [3, h, w] view of a static image buffer), stream-ordered: a copy for model-ready images; upload
+        (pinned source: asynchronous) + the resize kernel for uint8 originals"""
+        if not self._is_raw(im):
+            dst.copy_(im, non_blocking=True)
+            return
+        from . import ops
+        raw = im if im.is_cuda else im.to(dst.device, non_blocking=True)
+        ops.resize_bilinear_u8(raw.contiguous(), dst.shape[-2], dst.shape[-1], out=dst, float_chw=True, flip=self.input_flip)
+
     # ------------------------------------------------------------------ per-image inputs of the size-agnostic graph
     def _level_shapes(self):
         S = self.mv.backbone.padding_constraints.get("square_size", 0)
@@ -234,11 +263,11 @@ class GraphedForward:
         dt = mv.compute_dtype
         vals = []
         for b, im in enumerate(images):
-            h, w = im.shape[-2:]
+            h, w = self._model_hw(im)
             if h > S or w > S:
                 raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
             e.images[b].copy_(e.mean_canvas, non_blocking=True)
-            e.images[b][:, :h, :w].copy_(im, non_blocking=True)
+            self._write_input(e.images[b][:, :h, :w], im)
             self._geometry_into(e.sgeo[b], S, h, w)
             height, width = frames[b]
             sx, sy = width / w, height / h
@@ -249,7 +278,7 @@ class GraphedForward:
     def _build(self, images, text, height, width, prompt):
         from .modeling.ape_deta.geometry import StaticGeometry
         mv = self.mv
-        dev = images[0].device
+        dev = next(mv.parameters()).device
         B = len(images)
         e = SimpleNamespace()
         e.text = text                 # keeps the bank alive: the graph key holds its address
@@ -267,13 +296,16 @@ class GraphedForward:
             key = next(iter(g0._lvl_pos))
             e.sgeo = [StaticGeometry(g0, key, lp) for _ in range(B)]
             e.frame = torch.zeros((B, 8), dtype=torch.float32, device=dev)
-            self._load_inputs(e, images, [(im.shape[-2], im.shape[-1]) for im in images])
+            self._load_inputs(e, images, [self._model_hw(im) for im in images])
             e.size = (S, S)
         else:
-            e.images = [im.clone() for im in images]
+            e.images = []
             vals = []
             for im in images:
-                sx, sy = width / im.shape[-1], height / im.shape[-2]
+                mh, mw = self._model_hw(im)
+                e.images.append(torch.empty((3, mh, mw), dtype=torch.float32, device=dev))
+                self._write_input(e.images[-1], im)
+                sx, sy = width / mw, height / mh
                 vals.append([sx, sy, sx, sy, width, height, width, height])
             e.frame = torch.tensor(vals, dtype=torch.float32).to(dev)
         if self.pipeline:
@@ -332,15 +364,18 @@ class GraphedForward:
         single = not isinstance(image, (list, tuple))
         hs = height if isinstance(height, (list, tuple)) else [height] * self.B
         ws = width if isinstance(width, (list, tuple)) else [width] * self.B
-        frames = [(int(hs[b] or im.shape[-2]), int(ws[b] or im.shape[-1])) for b, im in enumerate(images)]
+        # output frame: what the caller asked for; else the image's own size (for a uint8 original: its ORIGINAL size, :222)
+        own = [(int(im.shape[0]), int(im.shape[1])) if self._is_raw(im) else (int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        frames = [(int(hs[b] or own[b][0]), int(ws[b] or own[b][1])) for b in range(len(images))]
+        mhw = [self._model_hw(im) for im in images]
         # the classifier's text side is a per-vocabulary constant baked into the capture: an in-place update of the bank
         # (text._version) must rebuild the graph, exactly like a new bank
         tkey = (text.data_ptr(), text._version, tuple(text.shape), prompt)
         if self.any_size:
             key = ("any",) + tkey
         else:
-            h, w = images[0].shape[-2:]
-            if any(tuple(im.shape[-2:]) != (h, w) for im in images) or any(f != frames[0] for f in frames):
+            h, w = mhw[0]
+            if any(m != (h, w) for m in mhw) or any(f != frames[0] for f in frames):
                 raise ValueError("GraphedForward.submit: the images of one step must share a size (or use any_size=True)")
             key = (h, w) + frames[0] + tkey
         e = self._graphs.get(key)
@@ -354,7 +389,7 @@ class GraphedForward:
                 del self._graphs[oldest]
             e = self._graphs[key] = self._build(images, text, frames[0][0], frames[0][1], prompt)
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=images[0].device)
+            self._copy_stream = torch.cuda.Stream(device=next(self.mv.parameters()).device)
         if any(f[0] * f[1] > e.maxpix for f in frames):
             raise ValueError(f"GraphedForward.submit: output frame larger than max_out_pixels={e.maxpix}")
         t = _Ticket(e, single, frames)
@@ -382,17 +417,17 @@ class GraphedForward:
                 self._load_inputs(e, images, frames)
             else:
                 for buf, im in zip(e.images, images):
-                    buf.copy_(im, non_blocking=True)
+                    self._write_input(buf, im)
         elif images is not None:
             # pipelined + any_size: the canvases feed the ViT of THIS replay (new images), the static geometry / frame feed its
             # tails (previous images).  Canvases are loaded now; geometry and frame of the new images after the replay.
             S = e.size[0]
             for b, im in enumerate(images):
-                h, w = im.shape[-2:]
+                h, w = self._model_hw(im)
                 if h > S or w > S:
                     raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
                 e.images[b].copy_(e.mean_canvas, non_blocking=True)
-                e.images[b][:, :h, :w].copy_(im, non_blocking=True)
+                self._write_input(e.images[b][:, :h, :w], im)
         if e.graph is not None:
             e.graph.replay()
             outs = e.outs
@@ -437,7 +472,7 @@ class GraphedForward:
             S, shapes = self._level_shapes()
             vals = []
             for b, im in enumerate(images):
-                h, w = im.shape[-2:]
+                h, w = self._model_hw(im)
                 self._geometry_into(e.sgeo[b], S, h, w)
                 fh, fw = frames[b]
                 sx, sy = fw / w, fh / h

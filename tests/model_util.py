@@ -149,7 +149,8 @@ def check_panoptic(model, orc, image, text, gold, device):
 # its measured values to <dir>/stage_pins_measured.json (merged over the calls of one pytest session) instead of asserting
 # against missing entries; tools/update_pins.py merges such a file into the committed one.
 # ------------------------------------------------------------------------------------------------------------------
-PIN_SLACK = 1.5
+PIN_SLACK = 1.5           # teacher-forced stages: one stage's own rounding error, reproducible
+PIN_SLACK_FREE = 2.0      # free-running / pipeline quantities: the decoder's refinement amplifies any change of rounding order
 PIN_FLOOR = 2e-6          # errors below this are fp32 noise: not pinned
 _PINS = None
 _MEASURED = {}
@@ -179,5 +180,11 @@ def check_pins(group, values):
     if pins is None:
         assert out_dir or os.environ.get("APE_TEST_SELFCHECK") == "1", f"no regression pins committed for {group} (run with APE_WRITE_PINS=<dir>)"
         return
-    bad = {k: (float(v), pins[k]) for k, v in values.items() if k in pins and float(v) > max(PIN_SLACK * pins[k], PIN_FLOOR)}
-    assert not bad, f"{group}: regression against the committed measurement (measured, pinned; slack x{PIN_SLACK}): {bad}"
+    slack = PIN_SLACK if group.startswith("forced/") else PIN_SLACK_FREE
+
+    def limit(k):
+        if k == "detections_unmatched":            # a count out of ~100: a handful of borderline detections may move
+            return pins[k] + 0.08
+        return max(slack * pins[k], PIN_FLOOR)
+    bad = {k: (float(v), pins[k]) for k, v in values.items() if k in pins and float(v) > limit(k)}
+    assert not bad, f"{group}: regression against the committed measurement (measured, pinned; slack x{slack}): {bad}"
