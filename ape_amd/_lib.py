@@ -29,7 +29,7 @@ class GemmArgs(Structure):
         ("rope_rows", c_int32), ("rope_hd", c_int32), ("rope_cols", c_int32), ("vec_ok", c_int32),
         ("alpha", c_float), ("clamp", c_float),
         ("splitk", c_int32), ("tile64", c_int32), ("workspace", c_void_p),
-        ("rowscale", c_void_p), ("rowshift", c_void_p), ("colvec", c_void_p),
+        ("rowscale", c_void_p), ("rowshift", c_void_p), ("colvec", c_void_p), ("rope_cs", c_void_p),
     ]
 
 

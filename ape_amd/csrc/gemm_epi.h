@@ -186,40 +186,70 @@ template <int W> __device__ __forceinline__ void ldrow_f32(const float* src, flo
   }
 }
 
-template <int W, bool ROPE, bool NORM, int ACT, typename H = bf16_t>
-__device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb, float (&v)[W]) {
+// silu(g) * u with the reciprocal instruction (v_rcp_f32, 1 ulp) instead of an IEEE division (a ~10-instruction expansion):
+// the SwiGLU epilogue of the ViT up projection was VALU bound on it (ablation: 17 of the launch's 99 us were epilogue arithmetic)
+__device__ __forceinline__ float silu_mul_fast(float g, float u) { return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * u; }
+
+// row-invariant vectors of a lane's W columns, loaded ONCE per tile (the unrolled row loop re-read them per accumulator row:
+// the stores in between keep the compiler from merging the loads)
+template <int W>
+struct EpiCols {
+  float bias[W];
+  float colvec[W];
+};
+template <int W, bool NORM>
+__device__ __forceinline__ void epi_cols_load(const GemmParams& p, int nb, EpiCols<W>& c) {
+  if (!NORM) return;              // without the folded LayerNorm the bias rides in the accumulators (BIAS_IN_ACC): nothing to load
+  if (p.bias != nullptr && !(p.vec_ok & 16)) ldrow_f32<W>(p.bias + nb, c.bias);
+  else {
+#pragma unroll
+    for (int e = 0; e < W; ++e) c.bias[e] = 0.f;
+  }
+  ldrow_f32<W>(p.colvec + nb, c.colvec);
+}
+
+// cs = W/2 (cos, sin) pairs of the lane's columns when the packed table came through LDS (ROPE_LDS), else unused.
+// Without NORM the bias is already inside v: the tile kernel starts its accumulators from it (the bias is added before everything else
+// in the epilogue order, and "+ bias" commutes with the accumulation up to fp32 rounding) -- no loads, no live registers.
+template <int W, bool ROPE, bool NORM, int ACT, typename H = bf16_t, bool ROPE_LDS = false>
+__device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb, float (&v)[W], const EpiCols<W>& cols, const float* cs = nullptr) {
   if (NORM) {
     const float rs = p.rowscale[m], sh = p.rowshift[m];
-    float c[W];
-    ldrow_f32<W>(p.colvec + nb, c);
 #pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = fmaf(v[e], rs, sh * c[e]);
+    for (int e = 0; e < W; ++e) v[e] = fmaf(v[e], rs, sh * cols.colvec[e]);
   }
-  if (p.bias != nullptr) {
+  if (NORM && p.bias != nullptr) {
     if (p.vec_ok & 16) {
       const float b = p.bias[m];
 #pragma unroll
       for (int e = 0; e < W; ++e) v[e] += b;
     } else {
-      float b[W];
-      ldrow_f32<W>(p.bias + nb, b);
 #pragma unroll
-      for (int e = 0; e < W; ++e) v[e] += b[e];
+      for (int e = 0; e < W; ++e) v[e] += cols.bias[e];
     }
   }
   if (ROPE) {
     if (nb < p.rope_cols) {
-      const int hd = p.rope_hd;
-      const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;
-      const size_t trow = (size_t)(m & rmask) * hd + (nb & (hd - 1));
-      float c[W], sn[W];
-      ldrow_f32<W>(p.rope_cos + trow, c);
-      ldrow_f32<W>(p.rope_sin + trow, sn);
+      if (ROPE_LDS) {
 #pragma unroll
-      for (int e = 0; e < W; e += 2) {          // rotate_half pairs (2i, 2i+1) -> (-x[2i+1], x[2i])
-        const float x0 = v[e], x1 = v[e + 1];
-        v[e] = x0 * c[e] - x1 * sn[e];
-        v[e + 1] = x1 * c[e + 1] + x0 * sn[e + 1];
+        for (int e = 0; e < W; e += 2) {          // pair (2i, 2i+1) shares (cos, sin) = cs[e], cs[e + 1]
+          const float x0 = v[e], x1 = v[e + 1], c = cs[e], sn = cs[e + 1];
+          v[e] = x0 * c - x1 * sn;
+          v[e + 1] = x1 * c + x0 * sn;
+        }
+      } else {
+        const int hd = p.rope_hd;
+        const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;
+        const size_t trow = (size_t)(m & rmask) * hd + (nb & (hd - 1));
+        float c[W], sn[W];
+        ldrow_f32<W>(p.rope_cos + trow, c);
+        ldrow_f32<W>(p.rope_sin + trow, sn);
+#pragma unroll
+        for (int e = 0; e < W; e += 2) {          // rotate_half pairs (2i, 2i+1) -> (-x[2i+1], x[2i])
+          const float x0 = v[e], x1 = v[e + 1];
+          v[e] = x0 * c[e] - x1 * sn[e];
+          v[e + 1] = x1 * c[e + 1] + x0 * sn[e + 1];
+        }
       }
     }
   }
@@ -229,10 +259,7 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
   }
   if (ACT == EPI_ACT_SWIGLU) {                   // interleaved (gate, up) pairs -> W/2 outputs in v[0 .. W/2)
 #pragma unroll
-    for (int e = 0; e < W / 2; ++e) {
-      const float g = v[2 * e], u = v[2 * e + 1];
-      v[e] = (g / (1.f + __expf(-g))) * u;
-    }
+    for (int e = 0; e < W / 2; ++e) v[e] = silu_mul_fast(v[2 * e], v[2 * e + 1]);
     return;
   }
   if (p.residual != nullptr) {

@@ -148,11 +148,38 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       wf[h][j][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + j * 2048 + rd1));
     }
   };
+  // wave-uniform: the wave's whole column slab is inside N and the launch's epilogue is one of the specialised ones (else the
+  // generic, bounds-checked path)
+  constexpr int W = TN * 4;
+  const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
+  const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
+  // The accumulators START from the bias (fast epilogues without the folded LayerNorm, whose row scale comes first): the
+  // epilogue then has no bias loads at all -- re-read per accumulator row they were, with the RoPE tables, 11.7 of the 46.9 us of
+  // the q|k projection (profiles/r04_p8_ablation.log) -- and no registers are held for it across the main loop.
   f32x4_t acc[8][TN];
+  if (fast && p.bias != nullptr && p.rowscale == nullptr) {
+    if (p.vec_ok & P8_BIAS_BY_ROW) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + frow;
+        const float b = p.bias[m < p.M ? m : p.M - 1];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b, b, b, b};
+      }
+    } else {
+      float b[W];
+      ldrow_f32<W>(p.bias + nb, b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3]};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
   auto mma = [&](int ha, int hb) __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -176,6 +203,23 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   };
 
   const int nk = ABL == 4 ? 1 : p.K / P8_BK;
+  // ---- RoPE tables through LDS (BN = 256, head width 64, packed (cos, sin) table given): the tile's 256 table rows (256 B each:
+  // 32 pairs) are fetched by the LDS-DMA during the LAST K tile into the stage no K tile occupies any more, 64 KB = 8 x 1 KB per
+  // wave, and read from LDS in the epilogue.  LDS image: row r at r * 256, 16-byte chunk c (2 pairs) at slot c ^ h(r & 15),
+  // h(x) = x ^ ((x & 4) << 1) -- the 16 lanes of a ds_read_b128 lane group (two fq values, the frow sets {0-3, 12-15} / {4-11})
+  // then hit 16 different slots.  Free stage: K tile nk would live in stage nk & 1; its halves were last read in iteration
+  // nk - 2 (or never), and every wave is past those reads one phase into iteration nk - 1.
+  const bool rope_lds = BN == 256 && p.rope_cs != nullptr && p.rope_cos != nullptr && p.rope_hd == 64 && fast;
+  auto hswz = [](int x) __attribute__((always_inline)) { return x ^ ((x & 4) << 1); };
+  // (the source offsets are computed at issue time: eight more live registers across the main loop would spill)
+  auto issue_rope = [&](int jj) __attribute__((always_inline)) {
+    const int rmask = p.rope_rows >= p.M ? 0x7fffffff : p.rope_rows - 1;
+    const int row = (wave * 8 + jj) * 4 + (lane >> 4);
+    int m = m0 + row; m = m < p.M ? m : p.M - 1;
+    const uint32_t off = (uint32_t)(m & rmask) * 256u + (uint32_t)((lane & 15) ^ hswz(row & 15)) * 16u;
+    unsigned char* dst = smem + (nk & 1) * STG + (wave * 8 + jj) * 1024;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(p.rope_cs) + off), (lds_void_t*)dst, 16, 0, 0);
+  };
   constexpr int INFLIGHT = 2 * NIB + 2;          // loads of the three youngest half-tiles at a phase-4 wait: B0, A0, B1
   // ---- prologue: K tile 0 complete, the first three half-tiles of K tile 1 in flight
   issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
@@ -204,6 +248,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     // ---- phase 2
     read_B(s, 1);
     if (t + 2 < nk) issue_B(t + 2, 0);
+    if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(0); issue_rope(1); issue_rope(2); issue_rope(3); }
     barrier();
     lgkm0();
     mma(0, 1);
@@ -211,6 +256,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     // ---- phase 3
     read_A(s, 1);
     if (t + 2 < nk) issue_A(t + 2, 0);
+    if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(4); issue_rope(5); issue_rope(6); issue_rope(7); }
     barrier();
     lgkm0();
     mma(1, 1);
@@ -227,10 +273,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     barrier();
   }
   if (STAGGER && wr == 0) barrier();
+  if (BN == 256 && rope_lds) {            // every wave's share of the table has landed before anyone reads it
+    // the BUILTIN wait (vmcnt(0), other counters untouched), not the asm one: hipcc's wait-count pass must see the LDS-DMA retire,
+    // or it puts a vmcnt(0) in front of every row's table read -- which, stores counting on vmcnt, waits for the previous row's
+    // output stores (one store round trip per accumulator row)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    barrier();
+  }
 
   // ---- epilogue from registers: lane (frow, fq) owns rows tile_i * 16 + frow, TN * 4 consecutive columns
-  constexpr int W = TN * 4;
-  const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
   if (ABL == 3) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -238,15 +289,39 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
     return;
   }
-  // wave-uniform: the wave's whole column slab is inside N (a partial slab takes the generic, bounds-checked path)
-  const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
   // one specialisation per launch (wave-uniform): the unrolled body stays short
-  auto run = [&](auto rope_t, auto norm_t, auto act_t) __attribute__((always_inline)) {
-    constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value;
+  auto run = [&](auto rope_t, auto norm_t, auto act_t, auto lds_t) __attribute__((always_inline)) {
+    constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value, RLDS = decltype(lds_t)::value;
     constexpr int ACT = decltype(act_t)::value;
+    asm volatile("; p8 epilogue specialisation %0" ::"n"(ACT * 8 + ROPE * 4 + NORM * 2 + RLDS) : "memory");   // distinct per branch: the column
+    // vectors are loaded HERE (identical code in every branch is hoisted above the dispatch, where they were spilled across it
+    EpiCols<W> cols;
+    epi_cols_load<W, NORM>(p, nb, cols);
+    const unsigned char* tbl = smem + (nk & 1) * STG;
+    const int c0 = (nb & 63) >> 2;                               // first 16-byte chunk (2 pairs) of this lane's columns in a table row
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
       const int m = m0 + wr * 128 + i * 16 + frow;
+      float cs[RLDS ? W : 1];
+      if (RLDS) {
+        // table reads through inline asm: left to hipcc, every row's ds_read gets an `s_waitcnt vmcnt(0)` in front (its wait-count
+        // pass cannot rule out an LDS-DMA in flight behind the run-time dispatch) -- and with the stores of the previous row
+        // counting on vmcnt, that is one store round trip per accumulator row
+        const int r = wr * 128 + i * 16 + frow;
+        f32x4_t t4[W / 4];
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) {
+          const uint32_t a = (uint32_t)(uintptr_t)(lds_void_t*)(tbl + r * 256 + (((c0 + k) ^ hswz(r & 15)) << 4));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(t4[k]) : "v"(a));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < W / 4; ++k) {
+          asm volatile("" : "+v"(t4[k]));          // consumed only behind the wait
+          cs[4 * k] = t4[k][0]; cs[4 * k + 1] = t4[k][1]; cs[4 * k + 2] = t4[k][2]; cs[4 * k + 3] = t4[k][3];
+        }
+      }
       if (m < p.M) {
         float o[W];
 #pragma unroll
@@ -266,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
             for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], c, sn);
           }
         } else {
-          epi_row_fast<W, ROPE, NORM, ACT, H>(p, m, nb, o);
+          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, nb, o, cols, cs);
         }
         if (ABL == 2) {
 #pragma unroll
@@ -274,7 +349,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
         } else if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, nb >> 1, o);
         else store_row<W, H>(p, m, nb, o);
       }
-    }
+      __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: the scheduler otherwise starts several rows' loads ahead
+    }                                         // and spills the column vectors
   };
   using T = std::true_type; using F = std::false_type;
   if (!fast) {
@@ -291,15 +367,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       }
     }
   } else if (p.rope_cos != nullptr) {
-    run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
+    if (BN == 256 && rope_lds) run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, T{});
+    else run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
   } else if (p.rowscale != nullptr) {
-    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{});
+    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
   } else if (p.act == APE_ACT_SWIGLU) {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{});
   } else if (p.act == APE_ACT_RELU) {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{}, F{});
   } else {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
   }
 }
 
@@ -318,6 +395,11 @@ static bool p8_supported(const ApeGemmArgs& p) {
 
 const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s) {
   if (!p8_supported(p)) return nullptr;
+  // the packed RoPE table is an optimisation hint: dropped unless the tile kernel's LDS path applies (alignment, whole heads per
+  // wave slab, 32-bit offsets); the cos / sin tables then serve as before
+  if (p.rope_cs != nullptr && (p.trans_out || ((uintptr_t)p.rope_cs) % 16 != 0 || p.rope_hd != 64 || p.rope_cols % 64 != 0 ||
+                               (size_t)p.rope_rows * 256 >= (1ull << 32) || !(p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)))
+    p.rope_cs = nullptr;
   if (p.trans_out) {
     // C^T[N, M] = W . A^T: the same kernel on the exchanged problem, bias indexed by (new) row
     const void* a = p.A; p.A = p.W; p.W = a;

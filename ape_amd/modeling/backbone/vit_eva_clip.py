@@ -202,7 +202,7 @@ class Block(nn.Module):
         # V^T on a parallel graph branch: two M = 4096 GEMMs fill the chip better together than one after the other
         vjob = ops.fork(lambda: ops.gemm(xn, P["wv"], P["bv"], trans_out=True, out=vt_buf))
         if rope is not None:
-            qk = ops.gemm(xn, P["wqk"], P["bqk"], rope=(rope[0], rope[1], rope[2], hd, 2 * Ep))
+            qk = ops.gemm(xn, P["wqk"], P["bqk"], rope=(rope[0], rope[1], rope[2], hd, 2 * Ep) + tuple(rope[3:]))
         else:
             qk = ops.gemm(xn, P["wqk"], P["bqk"])
         vt = vjob.join()
@@ -252,6 +252,15 @@ class Block(nn.Module):
         t = self._mlp(xb, P, dt, None, torch.float32)
         xb = ops.postnorm_residual(x32, t, P["n2"], copy_dtype=cdt)
         return x32 if xb is None else xb
+
+
+def _with_packed(cos, sin, rows):
+    """(cos, sin, rows[, packed]) -- packed = [rows, hd / 2, 2] (cos, sin) per rotate_half pair when both columns of every pair share
+    an angle (VisionRotaryEmbeddingFast repeats each frequency twice, vit_eva_clip.py:179-216): the form the 256-row GEMM tile stages
+    through LDS (ApeGemmArgs.rope_cs); checked, not assumed"""
+    if torch.equal(cos[:, 0::2], cos[:, 1::2]) and torch.equal(sin[:, 0::2], sin[:, 1::2]):
+        return (cos, sin, rows, torch.stack([cos[:, 0::2], sin[:, 0::2]], dim=-1).contiguous())
+    return (cos, sin, rows)
 
 
 def window_major_order(ht, wt, ws):
@@ -342,9 +351,9 @@ class ViT(Backbone):
             w = self.patch_embed.proj.weight
             return dict(
                 hw=hw, t2r=t2r, r2t=r2t, pos=pos, wpe=pack_matrix(w.reshape(w.shape[0], -1), dt), bpe=f32(self.patch_embed.proj.bias),
-                rope_win=None if self.rope_win is None else (f32(self.rope_win.freqs_cos), f32(self.rope_win.freqs_sin), self.window_size ** 2),
-                rope_glb=None if self.rope_glb is None else (f32(self.rope_glb.freqs_cos)[t2r.long()].contiguous(),
-                                                             f32(self.rope_glb.freqs_sin)[t2r.long()].contiguous(), hw * hw),
+                rope_win=None if self.rope_win is None else _with_packed(f32(self.rope_win.freqs_cos), f32(self.rope_win.freqs_sin), self.window_size ** 2),
+                rope_glb=None if self.rope_glb is None else _with_packed(f32(self.rope_glb.freqs_cos)[t2r.long()].contiguous(),
+                                                                         f32(self.rope_glb.freqs_sin)[t2r.long()].contiguous(), hw * hw),
             )
         return self._pack.get(self, dt, build)
 

@@ -98,7 +98,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     rownorm = (rowscale [M], rowshift [M], colvec [N]) fp32: acc * rowscale[m] + rowshift[m] * colvec[n] right after alpha
     (a LayerNorm of `a` folded into this GEMM: statistics from `row_stats`, gamma folded into w, colvec = row sums of w).
 
-    a [M,K], w [N,K] (same dtype).  rope = (cos, sin, rows, head_dim, cols).  trans_out returns C^T as
+    a [M,K], w [N,K] (same dtype).  rope = (cos, sin, rows, head_dim, cols[, packed pairs]).  trans_out returns C^T as
     [N, m_pad or M].  act=ACT_SWIGLU expects interleaved (gate, up) rows in w and returns N/2 columns.
     """
     _dev(a, w, bias, out, residual, rowmask)
@@ -135,10 +135,16 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     args.mask_mode = mask_mode if rowmask is not None else MASK_NONE
     args.act, args.trans_out = act, 1 if trans_out else 0
     if rope is not None:
-        cos, sin, rows, hd, cols = rope
+        cos, sin, rows, hd, cols = rope[:5]
         _dev(cos, sin)
         args.rope_cos, args.rope_sin = _f32vec(cos, "rope cos").data_ptr(), _f32vec(sin, "rope sin").data_ptr()
         args.rope_rows, args.rope_hd, args.rope_cols = rows, hd, cols
+        if len(rope) > 5 and rope[5] is not None:        # packed (cos, sin) pairs [rows, hd / 2, 2]: see ApeGemmArgs.rope_cs
+            cs = rope[5]
+            _dev(cs)
+            if cs.dtype != torch.float32 or not cs.is_contiguous() or cs.numel() != cos.numel():
+                raise ValueError("ape_amd.ops.gemm: packed rope table must be contiguous float32 [rows, head_dim / 2, 2]")
+            args.rope_cs = cs.data_ptr()
     args.alpha, args.clamp = float(alpha), float(clamp)
     if rownorm is not None:
         rs, sh, cv = rownorm

@@ -16,9 +16,11 @@ heads -> class-wise NMS -> masks of the kept detections (upsample, ROIAlign 128,
 Inputs (images, text-embedding bank) are resident in HBM before the timed region.  Weights are seeded synthetic
 (no checkpoint can be downloaded here); data = synthetic COCO-shaped images.
 
-Multi-GPU: images are independent units -> rank r takes images r, r+N, ... (InferenceSampler striding,
-ape/data/build.py:127); the text bank is broadcast once from rank 0 (RCCL) and each step's fixed-size detection
-records are all-gathered (RCCL over xGMI).  scaling = weak (one image per rank per step).
+Multi-GPU: images are independent units -> rank r takes a CONTIGUOUS block of the stream (the reference's
+InferenceSampler, ape/data/samplers/distributed_sampler_multi_dataset.py:160-170; ape_amd/dp.py shard_indices); the text bank is
+broadcast once from rank 0 (RCCL) and each step's fixed-size detection records -- plus, for N > 1, the masks as COCO run
+lengths (--mask-format rle, the default for N > 1) -- are all-gathered (RCCL over xGMI), asynchronously: the host awaits step
+i's exchange while step i + 1 computes.  scaling = weak (B images per rank per step).
 
 Extra objects on the JSON line: `roofline` for the dominant kernel (the bf16 MFMA GEMM, measured with HIP events on
 the launch stream in an instrumented pass right after the timed region), `cpu_baseline` (the oracle -- a CPU port
@@ -67,6 +69,15 @@ def parse():
     ap.add_argument("--cpu-images", type=int, default=3, help="images the CPU oracle times after its warm-up pass (cpu_baseline)")
     ap.add_argument("--ap-images", type=int, default=16,
                     help="seeded images for the box-AP parity number (bf16 detections vs the fp32 pipeline's as pseudo ground truth)")
+    ap.add_argument("--input", choices=["resident", "uint8"], default="resident",
+                    help="resident: float32 model-ready images already in HBM (the tier's definition of `value`); uint8: the predictor's "
+                         "input side inside the timed region (ape/engine/defaults.py:213-222) -- ORIGINAL uint8 BGR images (1.25 x the model "
+                         "size) in pinned host memory -> upload -> ResizeShortestEdge (Pillow-exact resize kernel) + BGR->RGB + float CHW -> forward")
+    ap.add_argument("--mask-format", choices=["auto", "bitmask", "rle"], default="auto",
+                    help="how masks leave the device: bitmask = [k, H, W] bool on the host (the reference's Instances contract, 105 MB per "
+                         "image at k = 100); rle = the evaluators' COCO run lengths, encoded on the device (a few KB per image) and "
+                         "all-gathered across ranks with the records.  auto = bitmask on 1 GPU, rle on N > 1 (north_star: all-gather of boxes / masks)")
+    ap.add_argument("--dry-images", type=int, default=1000, help="--dry: length of the sharded synthetic stream")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
                     help="16-bit flavour of the timed pipeline: bf16 = BASELINE's dtype (default); f16 = IEEE half operands, the reference's "
                          "own evaluation dtype (tools/train_net.py:642) -- same kernels, v_mfma_f32_16x16x32_f16, 3 more mantissa bits")
@@ -78,6 +89,14 @@ def parse():
 def make_images(n, S, seed, device):
     g = torch.Generator().manual_seed(seed)
     return [torch.randint(0, 256, (3, S, S), generator=g).float().to(device) for _ in range(n)]
+
+
+def make_raw_images(n, S, seed):
+    """ORIGINAL images as the predictor receives them (cv2.imread: uint8 [H, W, 3] BGR) in pinned host memory, 1.25 x the model size
+    so that ResizeShortestEdge(S, S) really resamples (Pillow's triangle filter over a 2.5-pixel support)"""
+    g = torch.Generator().manual_seed(seed)
+    H = S * 5 // 4
+    return [torch.randint(0, 256, (H, H, 3), generator=g, dtype=torch.uint8).pin_memory() for _ in range(n)]
 
 
 class GemmMeter:
@@ -341,15 +360,21 @@ def dry_run(args, rank, world):
         def result(self, ticket):
             return None, ticket.rec6
 
-    dp = DataParallelRunner(Fake(), k, dev)
+    dp = DataParallelRunner(Fake(), k, dev, lag=1)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
     text = dp.broadcast_text_bank(bank, args.classes, 1024)
-    mine = shard_indices(1000, rank, world)
+    mine = shard_indices(args.dry_images, rank, world)
+    steps = args.steps if args.stream != "coco" else (len(mine) + args.images_per_step - 1) // args.images_per_step
     dist.barrier()
     t0 = time.perf_counter()
-    gathered = None
-    for i in range(args.steps):
-        gathered = dp.result(dp.submit(None, text))[1]          # [world, B, k, 6]: every rank's records of this step
+    gathered, collected = None, 0
+    for i in range(steps):
+        g = dp.result(dp.submit(None, text))[1]                 # lag 1: the records of the PREVIOUS step (None at the first)
+        collected += g is not None
+        gathered = g if g is not None else gathered
+    g = dp.drain()                                              # the last step's records
+    collected += g is not None
+    gathered = g if g is not None else gathered                 # [world, B, k, 6]: every rank's records of one step
     dist.barrier()
     elapsed = time.perf_counter() - t0
     sums = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
@@ -359,7 +384,8 @@ def dry_run(args, rank, world):
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "dry-run (no forward)",
                           "config": {"workload": "none (--dry)", "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size(),
-                                     "backend": dist.get_backend(), "shard_of_rank0": [mine[0], mine[-1]],
+                                     "backend": dist.get_backend(), "shard_of_rank0": [mine[0], mine[-1]], "steps_run": steps,
+                                     "record_sets_collected": collected, "shard_sizes": [len(shard_indices(args.dry_images, r, world)) for r in range(world)],
                                      "text_bank_identical_on_all_ranks": bool(all(abs(float(x) - float(sums[0])) < 1e-9 for x in sums)),
                                      "gathered_shape": list(gathered.shape) if torch.is_tensor(gathered) else None,
                                      "gathered_rank_ids": sorted({int(v) for v in gathered[:, 0, 0, 0].tolist()}) if torch.is_tensor(gathered) else None}}),
@@ -411,15 +437,22 @@ def main():
         mv.set_metadata(0, name="bench_thing_stuff", thing_classes=things, stuff_classes=stuff)
         sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
         args.classes = len(things) + len(stuff) - 1
+    mask_format = args.mask_format if args.mask_format != "auto" else ("rle" if world > 1 else "bitmask")
     graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
-                             pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta)
-    dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev)
+                             pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta, mask_format=mask_format,
+                             input_resize=(S, S), input_format="RGB")
+    # N > 1: masks travel as COCO run lengths and are all-gathered with the records (north_star: "all-gather of boxes / masks over
+    # xGMI"); the exchange of step i is awaited one step later and only by the host (lag = 1): a slow rank never stalls another GPU
+    dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev, gather_masks=mask_format == "rle" and world > 1, lag=1 if world > 1 else 0)
     # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
     text = dp.broadcast_text_bank(bank, args.classes, 1024)
     # rank r owns its own block of the synthetic stream (contiguous shards like the reference's InferenceSampler: dp.shard_indices)
     from ape_amd.dp import shard_indices
     images = make_images(args.stream_images, S, seed=100 + rank, device=dev)
+    raw_images = make_raw_images(args.stream_images, S, seed=100 + rank) if args.input == "uint8" else None
+    if raw_images is not None and args.stream == "coco":
+        raise SystemExit("--input uint8 is implemented for --stream square")
     if args.stream == "coco":
         # 1000 sizes, long side S, short side U[480, S] rounded, either orientation (seed 5); image i of the
         # stream = the top-left (h_i, w_i) crop of a base image (views: no extra memory); rank r takes its contiguous block
@@ -441,14 +474,21 @@ def main():
     queue = []
 
     def step(i):
-        batch = [images[(i * B + b) % len(images)] for b in range(B)]
-        queue.append(dp.submit(batch if B > 1 else batch[0], text))
+        if raw_images is not None:
+            # the masks are delivered in the S x S frame of the resident-input workload (the predictor's default is the ORIGINAL
+            # size): the two numbers then differ by the input side only
+            batch = [raw_images[(i * B + b) % len(raw_images)] for b in range(B)]
+            queue.append(dp.submit(batch if B > 1 else batch[0], text, height=S, width=S))
+        else:
+            batch = [images[(i * B + b) % len(images)] for b in range(B)]
+            queue.append(dp.submit(batch if B > 1 else batch[0], text))
         return dp.result(queue.pop(0)) if len(queue) > depth else None
 
     def flush():
         done = None
         while queue:
             done = dp.result(queue.pop(0))
+        dp.drain()
         return done
 
     for i in range(args.warmup):
@@ -510,7 +550,14 @@ def main():
                                    "per image incl. their full-resolution masks on the host; seeded synthetic weights"
                                    + ("; semantic branch on (54 stuff columns), label maps on the host" if args.semantic else ""),
                        "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if dist is not None else 1,
-                       "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B,
+                       "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B, "input": args.input,
+                       "input_note": ("uint8 BGR originals (%d x %d) in pinned host memory -> H2D -> resize kernel (Pillow-exact) + BGR->RGB + "
+                                      "float CHW -> forward, all inside the timed region" % (S * 5 // 4, S * 5 // 4)) if args.input == "uint8"
+                                     else "float32 model-ready images resident in HBM (PCIe-exclusive, the tier's definition of `value`)",
+                       "mask_format": mask_format, "records_exchange": "all-gather, awaited one step late by the host" if world > 1 else "none (1 rank)",
+                       "host_MB_per_s_per_rank": round((args.steps * B / elapsed) * (
+                           (mv.test_topk_per_image * S * S if mask_format == "bitmask" else mv.test_topk_per_image * graphed.rle_cap * 4)
+                           + mv.test_topk_per_image * 32) / 1e6, 1),
                        "batched_vit": not args.no_batch_vit, "stream": args.stream,
                        "software_pipeline": (not args.no_pipeline) and "ViT of step i+1 overlaps the tails of step i; the last step is flushed inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,

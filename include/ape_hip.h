@@ -84,6 +84,12 @@ typedef struct ApeGemmArgs {
   const float* rowscale;
   const float* rowshift;
   const float* colvec;
+  /* optional packed form of the RoPE tables: [rope_rows, rope_hd / 2] (cos, sin) float pairs, one per rotate_half pair (2i, 2i+1)
+   * -- valid when both columns of a pair share an angle (cos[m, 2i] == cos[m, 2i+1], the reference's VisionRotaryEmbeddingFast
+   * repeats every frequency twice, vit_eva_clip.py:179-216).  Same arithmetic, half the table bytes; the 256-row tile kernel
+   * stages its rows through LDS with the LDS-DMA of the last K tile instead of re-reading them from L2 per accumulator row
+   * (measured on the q|k projection: the table / bias loads were 11.7 of the launch's 46.9 us).  NULL = cos / sin tables only. */
+  const float* rope_cs;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */

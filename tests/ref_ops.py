@@ -47,7 +47,7 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     if bias is not None:
         x = x + bias.float()
     if rope is not None:
-        cos, sin, rows, hd, cols = rope
+        cos, sin, rows, hd, cols = rope[:5]          # a sixth entry (packed pairs) is the same table in another layout
         idx = torch.arange(M, device=a.device) % rows
         c, s = cos.float()[idx], sin.float()[idx]  # [M, hd]
         t = x[:, :cols].reshape(M, cols // hd, hd)

@@ -38,3 +38,14 @@ def test_gpus_1_runs_in_process_and_a_mismatched_world_size_is_refused():
     assert r["n_gpus"] == 1 and r["config"]["rccl_ranks"] == 1
     p, lines = _run("--gpus", "4", env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29591"})
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_uneven_shards_of_a_coco_shaped_stream_run_the_same_number_of_steps():
+    """7 images over 2 ranks: contiguous blocks of 4 and 3 -- the shorter block starts one image early (dp.shard_indices), so both
+    ranks run the same number of steps and every lagged all-gather finds its partner; every step's record set is collected"""
+    p, lines = _run("--gpus", "2", "--stream", "coco", "--dry-images", "7", "--images-per-step", "1")
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert c["shard_sizes"] == [4, 4] and c["shard_of_rank0"] == [0, 3]
+    assert c["steps_run"] == 4 and c["record_sets_collected"] == 4 and c["gathered_rank_ids"] == [0, 1]

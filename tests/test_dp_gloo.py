@@ -72,6 +72,23 @@ def _worker(rank, world, port, ret):
         for r in range(world):
             same &= torch.equal(counts[r][:, :4], allrec[r][:, :4].round().to(torch.int32))
 
+    # lagged exchange (lag = 1, what bench.py --gpus N > 1 runs): result(ticket_i) hands back the gathered records of ticket i-1,
+    # drain() the last; the same records in the same order, each collective awaited one step late and only by the host
+    lrunner = DataParallelRunner(Pipelined(), mv.test_topk_per_image, torch.device("cpu"), gather_masks=True, lag=1)
+    lagged, ltickets = [], []
+    for i in mine:
+        t = lrunner.submit(images[i], text)
+        ltickets.append(t)
+        g = lrunner.result(t)[1]
+        if g is not None:
+            lagged.append(g)
+    same &= len(lagged) == len(mine) - 1
+    lagged.append(lrunner.drain())
+    same &= lrunner.drain() is None and len(lagged) == len(gathered) and all(torch.equal(a, b) for a, b in zip(lagged, gathered))
+    for t in ltickets:
+        counts, nruns = t.mask_runs
+        same &= counts.shape[0] == world and torch.equal(counts[rank], t.runs[0]) and torch.equal(nruns[rank], t.runs[1])
+
     # text bank from class names: only rank 0 owns a text tower
     class Tower:
         calls = 0

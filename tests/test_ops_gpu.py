@@ -772,6 +772,14 @@ def test_gemm_p8(ops, tile, stagger, monkeypatch, bf):
             cos, sin = rnd(128, 64, seed=7), rnd(128, 64, seed=8)
             check("rope_pow2", a, w, bias, rope=(cos, sin, 128, 64, N // 2 // 64 * 64), out_dtype=torch.float32)
             check("rope_bf16", a, w, bias, rope=(cos, sin, 128, 64, N // 2 // 64 * 64))
+            # packed (cos, sin) pairs: the table rows go through LDS in the 256 x 256 tile kernel (pairs share an angle, as in the ViT)
+            cp, sp = cos[:, 0::2].repeat_interleave(2, 1).contiguous(), sin[:, 0::2].repeat_interleave(2, 1).contiguous()
+            packed = torch.stack([cp[:, 0::2], sp[:, 0::2]], -1).contiguous()
+            check("rope_packed", a, w, bias, rope=(cp, sp, 128, 64, N // 2 // 64 * 64, packed), out_dtype=torch.float32)
+            check("rope_packed_all_cols", a, w, bias, rope=(cp, sp, 128, 64, N // 64 * 64, packed))
+            big_rows = max(M, 128)             # table rows >= M (global blocks): no wrap
+            cb, sb = rnd(big_rows, 32, seed=17).repeat_interleave(2, 1).contiguous(), rnd(big_rows, 32, seed=18).repeat_interleave(2, 1).contiguous()
+            check("rope_packed_rows_ge_M", a, w, bias, rope=(cb, sb, big_rows, 64, N // 64 * 64, torch.stack([cb[:, 0::2], sb[:, 0::2]], -1).contiguous()))
             check("rope_mod100", a, w, bias, rope=(cos[:100].contiguous(), sin[:100].contiguous(), 100, 64, N // 2 // 64 * 64), out_dtype=torch.float32)
         rs, sh, cv = rnd(M, seed=10).abs() + 0.5, rnd(M, seed=11), rnd(N, seed=12)
         check("rownorm_res32", a, w, bias, rownorm=(rs, sh, cv), residual=res32, out_dtype=torch.float32)
