@@ -115,7 +115,7 @@ class GemmMeter:
             out = self.orig(a, w, *args, **kw)
             e.record()
             name = self.lib.ape_hip_gemm_last_kernel().decode()
-            self.records.append((name, s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0]))
+            self.records.append((name, s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0], f"{a.shape[0]}x{w.shape[0]}x{a.shape[1]}"))
             return out
 
         def wrapped_ffn(x, w1, b1, w2, b2, **kw):
@@ -125,7 +125,8 @@ class GemmMeter:
             out = self.orig_ffn(x, w1, b1, w2, b2, **kw)
             e.record()
             name = "ffn_fused_kernel<true>" if kw.get("w2_permuted") else "ffn_fused_kernel<false>"
-            self.records.append((name, s, e, 2.0 * x.shape[0] * x.shape[1] * w1.shape[0] + 2.0 * x.shape[0] * w1.shape[0] * w2.shape[0]))
+            self.records.append((name, s, e, 2.0 * x.shape[0] * x.shape[1] * w1.shape[0] + 2.0 * x.shape[0] * w1.shape[0] * w2.shape[0],
+                                 f"{x.shape[0]}x{x.shape[1]}x{w1.shape[0]}x{w2.shape[0]}"))
             return out
         self.ops.gemm, self.ops.ffn_fused = wrapped, wrapped_ffn
         return self
@@ -143,15 +144,15 @@ class GemmMeter:
     def summary(self):
         """per kernel family: (launches, seconds, flops), sorted by time; and per exact symbol (as rocprofv3 lists them)"""
         torch.cuda.synchronize()
-        groups, symbols = {}, {}
-        for name, s, e, fl in self.records:
+        groups, symbols, shapes = {}, {}, {}
+        for name, s, e, fl, shape in self.records:
             dt = s.elapsed_time(e) * 1e-3
-            for table, key in ((groups, self.family(name)), (symbols, name)):
+            for table, key in ((groups, self.family(name)), (symbols, name), (shapes, (self.family(name), shape))):
                 g = table.setdefault(key, [0, 0.0, 0.0])
                 g[0] += 1
                 g[1] += dt
                 g[2] += fl
-        self.symbols = symbols
+        self.symbols, self.shapes = symbols, shapes
         return sorted(groups.items(), key=lambda kv: -kv[1][1])
 
 
@@ -569,6 +570,10 @@ def main():
                          "symbols": {k: {"launches_per_image": v[0] / reps, "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 2),
                                          "tflops": round(v[2] / v[1] / 1e12, 1)}
                                      for k, v in sorted(meter.symbols.items(), key=lambda kv: -kv[1][1]) if GemmMeter.family(k) == dom_name},
+                         # the dominant family per problem shape M x N x K (launches per image, average us, TFLOP/s)
+                         "by_shape": {sh: {"launches_per_image": round(v[0] / reps, 2), "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 1),
+                                           "tflops": round(v[2] / v[1] / 1e12, 1)}
+                                      for (fam, sh), v in sorted(meter.shapes.items(), key=lambda kv: -kv[1][1]) if fam == dom_name},
                          "all_gemm_kernels": {"ms_per_image": 1e3 * all_t / reps, "tflops": all_fl / all_t / 1e12,
                                               "flops_per_image": all_fl / reps,
                                               "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups},

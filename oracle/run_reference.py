@@ -17,8 +17,17 @@ class _TorchProxy:
     (value desc, index asc -- the reference leaves ties to torch.topk's unspecified order), and the
     proposal gather is recorded so topk_proposals can be compared."""
 
-    def __init__(self, rec, stable_ties):
-        self._rec, self._stable = rec, stable_ties
+    def __init__(self, rec, stable_ties, forced_topk=None):
+        self._rec, self._stable, self._forced = rec, stable_ties, forced_topk
+
+    def stack(self, tensors, *a, **kw):
+        # `topk_proposals = torch.stack(topk_proposals)` (deformable_transformer_vl.py:625): with forced_topk the decoder of THIS run
+        # starts from the proposals of another run (the fp32 run's, for a reduced-precision yardstick that measures arithmetic, not a
+        # different selection)
+        if (self._forced is not None and len(tensors) and all(torch.is_tensor(t) and t.dim() == 1 and t.dtype == torch.int64 for t in tensors)
+                and len(tensors) == self._forced.shape[0] and tensors[0].numel() == self._forced.shape[1]):
+            return self._forced.clone()
+        return torch.stack(tensors, *a, **kw)
 
     def __getattr__(self, name):
         return getattr(torch, name)
@@ -40,9 +49,11 @@ def spec_of(model):
 
 
 def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, stable_ties=True, prompt="name", semantic=None,
-                  eval_dataset=False, panoptic_configs=None, mask_prompt=None):
+                  eval_dataset=False, panoptic_configs=None, mask_prompt=None, autocast=None, forced_topk=None):
     """returns (stages dict, instances dict, spec).  prompt="phrase": class names with a space, which the reference
-    routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337)."""
+    routes to the dense multi-token fusion (deformable_detr_segm_vl.py:224-232, 283-337).
+    autocast = torch.bfloat16: the forward runs under torch.autocast("cpu", dtype) -- the reference's own code at reduced precision, the
+    yardstick of tests/golden/make_autocast_yardstick.py; forced_topk [1, Q]: proposals injected (see _TorchProxy.stack)."""
     cfg = CONFIGS[cfg_name]
     refshim.METADATA.clear()
     if semantic is not None:        # semantic branch on: the (only) dataset's metadata carries the thing / stuff split
@@ -89,7 +100,7 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
     tmod = sys.modules["ape.modeling.ape_deta.deformable_transformer_vl" if vl else "ape.modeling.ape_deta.deformable_transformer"]
     smod = sys.modules["ape.modeling.ape_deta.deformable_detr_segm_vl" if vl else "ape.modeling.ape_deta.deformable_detr_segm"]
     old_torch = tmod.torch
-    tmod.torch = _TorchProxy(S, stable_ties)
+    tmod.torch = _TorchProxy(S, stable_ties, forced_topk)
     old_mf = mv.maskdino_mask_features
     old_inf = mv.inference
     old_retry = smod.retry_if_cuda_oom
@@ -131,7 +142,9 @@ def run_reference(cfg_name, seed, image, text_feats, height=None, width=None, st
                                                                 for i in range(text_feats.shape[0])))
         if mask_prompt is not None:                    # the predictor's inputs["mask_prompt"] (ape/engine/defaults.py:226-228)
             inputs["mask_prompt"] = mask_prompt
-        with torch.no_grad():
+        import contextlib
+        ctx = torch.autocast("cpu", dtype=autocast) if autocast is not None else contextlib.nullcontext()
+        with torch.no_grad(), ctx:
             out = model([inputs])[0]
     finally:
         tmod.torch = old_torch

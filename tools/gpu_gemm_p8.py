@@ -31,7 +31,10 @@ def make_case(M, N, K, kind, dev):
     bias = torch.randn(N, generator=g).to(dev)
     kw = {}
     if kind == "rope":
-        kw = dict(rope=(torch.randn(4096, 64, generator=g).to(dev), torch.randn(4096, 64, generator=g).to(dev), 4096, 64, N // 2))
+        # pairs (2i, 2i + 1) share an angle like the ViT's tables: the packed (cos, sin) table rides along (ApeGemmArgs.rope_cs)
+        c = torch.randn(4096, 32, generator=g).repeat_interleave(2, 1).contiguous().to(dev)
+        sn = torch.randn(4096, 32, generator=g).repeat_interleave(2, 1).contiguous().to(dev)
+        kw = dict(rope=(c, sn, 4096, 64, N, torch.stack([c[:, 0::2], sn[:, 0::2]], -1).contiguous()))
     elif kind == "swiglu":
         kw = dict(act=ops.ACT_SWIGLU)
     elif kind == "res32":
