@@ -899,6 +899,162 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
 }
 
 // ------------------------------------------------------------------------------------------
+// "kres" with the LayerNorm that follows the linear in its epilogue:  y = LN(x W^T + b + residual) * gamma + beta  for K = N = 256
+// (detrex BaseTransformerLayer: the deformable attention's output projection + identity, then "norm";
+// ape/layers/multi_scale_deform_attn.py:353-358 + the layer's norms[0]).  A workgroup still owns 128 rows; a wave keeps the
+// accumulators of BOTH 128-column chunks (2 x 64 registers), so a row's 256 channels sit in the 4 lanes frow + 16 fq and the
+// statistics are two lane swaps (as in ffn_fused.hip) -- on the fp32 sums, without the 16-bit rounding a separate LayerNorm launch
+// would read back, and without its 89 MB round trip per encoder layer.  The residual rows are fetched after the last MFMA (the
+// A fragments are dead by then: no registers to hold them earlier); the second workgroup of the CU covers that latency.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float kr_rows_sum(float v) {      // sum over the lanes l, l^16, l^32, l^48
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <typename H>
+__global__ __launch_bounds__(256, 2) void gemm_kres_ln_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* ring = reinterpret_cast<bf16_t*>(smem_raw);                     // 4 stages x [128][64] (swz128 image)
+  float* sbias = reinterpret_cast<float*>(smem_raw + 4 * 16384);          // bias | gamma | beta, 256 floats each
+  float* sgam = sbias + 256;
+  float* sbet = sgam + 256;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  sbias[tid] = p.bias != nullptr ? p.bias[tid] : 0.f;
+  sgam[tid] = p.ln_w[tid];
+  sbet[tid] = p.ln_b[tid];
+  __syncthreads();
+
+  const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
+  const int m_wave = blockIdx.x * KR_BM + wave * 32;
+  bf16x8_t af[2][8];
+  int mrow[2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = m_wave + mi * 16 + frow;
+    mrow[mi] = m;
+    const bf16_t* ap = A + (size_t)(m < p.M ? m : p.M - 1) * p.lda + fq * 8;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) af[mi][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(ap + s * 32));
+  }
+  uint32_t woff[4];                                                      // element offset of this lane's 16-byte piece inside a W chunk
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rho = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((rho >> 1) & 7);
+    const int idx = rho & 15;
+    const int wcol = (rho >> 5) * 32 + (idx >> 2) * 8 + ((rho >> 4) & 1) * 4 + (idx & 3);     // same row permutation as gemm_bf16_kres_kernel
+    woff[i] = (uint32_t)wcol * (uint32_t)p.ldw + (uint32_t)c * 8u;
+  }
+  constexpr int T = 8;                                                   // 2 chunks x 4 k steps
+  auto issue = [&](int t) {
+    t = t < T ? t : T - 1;
+    const int cc = t >> 2, ks = t & 3;
+    bf16_t* st = ring + (t & 3) * 8192;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(W + (size_t)cc * KR_CH * p.ldw + ks * 64 + woff[i]), (lds_void_t*)(st + (wave * 4 + i) * 512), 16, 0, 0);
+  };
+  f32x4_t acc[2][2][8];                                                  // [chunk][row tile][column tile]
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[cc][mi][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int t, int cc, int ks) __attribute__((always_inline)) {
+    const bf16_t* st = ring + (t & 3) * 8192;
+    auto rd = [&](int h, bf16x8_t (&wf)[4]) {
+      const int kk = h >> 1, jb = (h & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rho = (jb + j) * 16 + frow;
+        wf[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(st + rho * 64 + (((kk * 4 + fq) ^ ((rho >> 1) & 7)) << 3)));
+      }
+    };
+    auto mm = [&](int h, bf16x8_t (&wf)[4]) {
+      const int kk = h >> 1, jb = (h & 1) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[cc][mi][jb + j] = h16<H>::mfma(wf[j], af[mi][ks * 2 + kk], acc[cc][mi][jb + j]);
+    };
+    bf16x8_t w0[4], w1[4];
+    rd(0, w0);
+    rd(1, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(2, w0);
+    mm(1, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    rd(3, w1);
+    mm(2, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(3, w1);
+  };
+  issue(0); issue(1); issue(2);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {          // stage t's request is followed by the requests of t+1, t+2 (8 LDS-DMAs) when it is awaited
+    wait_vmcnt<8>();
+    __builtin_amdgcn_s_barrier();
+    issue(t + 3);
+    compute(t, t >> 2, t & 3);
+  }
+  // ---- epilogue: + bias + residual, LayerNorm over the row's 256 channels, 16-byte stores (64 contiguous bytes per row and instruction)
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int m = mrow[mi] < p.M ? mrow[mi] : p.M - 1;                   // clamped: the lane swaps need every lane
+    float v[64];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        const int col = cc * KR_CH + jp * 32 + fq * 8;
+        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.residual != nullptr) ld8<H>(reinterpret_cast<const H*>(p.residual) + (size_t)m * p.ldr + col, rv);
+        const float4 b0 = *reinterpret_cast<const float4*>(sbias + col), b1 = *reinterpret_cast<const float4*>(sbias + col + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[cc * 32 + jp * 8 + h * 4 + r] = acc[cc][mi][jp * 2 + h][r] + bb[h * 4 + r] + rv[h * 4 + r];
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) sum += v[e];
+    const float mean = kr_rows_sum(sum) * (1.f / 256.f);
+    float d2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 64; ++e) { v[e] -= mean; d2 = fmaf(v[e], v[e], d2); }
+    const float rstd = rsqrtf(kr_rows_sum(d2) * (1.f / 256.f) + p.ln_eps);
+    if (mrow[mi] < p.M) {
+      H* yp = reinterpret_cast<H*>(p.C) + (size_t)m * p.ldc;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+          const int col = cc * KR_CH + jp * 32 + fq * 8;
+          const float4 g0 = *reinterpret_cast<const float4*>(sgam + col), g1 = *reinterpret_cast<const float4*>(sgam + col + 4);
+          const float4 e0 = *reinterpret_cast<const float4*>(sbet + col), e1 = *reinterpret_cast<const float4*>(sbet + col + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+          float o[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = fmaf(v[cc * 32 + jp * 8 + q] * rstd, gg[q], ee[q]);
+          st8<H>(yp + col, o);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // one row tile at a time (both interleaved do not fit the register file)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // C-ABI launchers
 // ------------------------------------------------------------------------------------------
 static thread_local const char* g_last_gemm_kernel = "";
@@ -947,6 +1103,19 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<true, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       attr_done = true;
+    }
+    if (p.ln_w != nullptr) {
+      // LayerNorm in the epilogue: the K = N = 256 register-resident kernel only (the callers check the same conditions and
+      // launch a separate LayerNorm otherwise)
+      APE_CHECK_ARG(p.ln_b != nullptr && p.K == 256 && p.N == 256 && p.M >= 2048 && !p.trans_out && p.act == APE_ACT_NONE && p.rope_cos == nullptr &&
+                        p.rowscale == nullptr && p.rowmask == nullptr && p.splitk <= 1 && p.alpha == 1.f && p.clamp <= 0.f && p.out_dt == h16<H>::dt &&
+                        p.ldc % 8 == 0 && ((uintptr_t)p.C) % 16 == 0 && p.K % GB_K == 0 && ((uintptr_t)p.ln_w) % 16 == 0 && ((uintptr_t)p.ln_b) % 16 == 0 &&
+                        (p.residual == nullptr || (p.res_dt == h16<H>::dt && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0)),
+                    "ape_hip_gemm: an epilogue LayerNorm (ln_w) needs K == N == 256, M >= 2048, 16-bit operands / residual / output of one type, a plain epilogue");
+      static bool lattr = false;
+      if (!lattr) { (void)hipFuncSetAttribute((const void*)gemm_kres_ln_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS); lattr = true; }
+      LAUNCH_GEMM("gemm_kres_ln_kernel", (gemm_kres_ln_kernel<H>), dim3(ceil_div(p.M, KR_BM)), KR_LDS);
+      return 0;
     }
     const char* nk_env = getenv("APE_GEMM_NOKRES");     // read per call so a probe can flip it
     const int no_kres = nk_env ? atoi(nk_env) : 0;
@@ -1047,7 +1216,9 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
       (p.rope_hd & (p.rope_hd - 1)) == 0 && (p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)) vec |= 4;
   p.vec_ok = vec;
   hipStream_t s = (hipStream_t)stream;
+  APE_CHECK_ARG(p.ln_w == nullptr || ape_is16(p.in_dt), "ape_hip_gemm: the epilogue LayerNorm exists for the 16-bit K = N = 256 kernel only");
   if (ape_is16(p.in_dt)) {
+    if (p.ln_w != nullptr && (p.tile64 == 3 || p.tile64 == 4)) p.tile64 = 0;
     const int rc = p.in_dt == APE_DT_F16 ? gemm_launch_h16<f16_t>(p, s) : gemm_launch_h16<bf16_t>(p, s);
     if (rc != 0) return rc;
     if (p.in_dt == APE_DT_F16) {             // the f16 instantiations report as gemm_f16_*

@@ -27,10 +27,18 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
   const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
   const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
   float v[8];
+  const float* row = img + ((size_t)c * h + y) * w;
+  if (y < h && x0 + 7 < w && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0) {   // whole 8-pixel run inside the image, 16-byte aligned: two vector loads
+    const float4 a = *reinterpret_cast<const float4*>(row + x0), b = *reinterpret_cast<const float4*>(row + x0 + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int x = x0 + i;
-    v[i] = (y < h && x < w) ? (img[((size_t)c * h + y) * w + x] - mean) / sd : 0.f;
+    for (int i = 0; i < 8; ++i) v[i] = (v[i] - mean) / sd;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int x = x0 + i;
+      v[i] = (y < h && x < w) ? (row[x] - mean) / sd : 0.f;
+    }
   }
   st8<TO>(out + (size_t)t * ldo + c * 256 + ky * 16 + kx0, v);
 }

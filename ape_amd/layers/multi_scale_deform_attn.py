@@ -87,9 +87,11 @@ class MultiScaleDeformableAttention(nn.Module):
         return self._pack.get(self, dt, build)
 
     def forward_tokens(self, query_pos_sum, identity, ref, shapes, starts, dt, *, value_src=None, value=None, mask=None,
-                       out_dtype=None):
+                       out_dtype=None, norm=None):
         """query_pos_sum [Q,256] (= query + pos), identity [Q,256], ref [Q,L,2|4] fp32.
-        Either value_src [S,256] (projected here, padded rows zeroed with `mask`) or a pre-projected `value`."""
+        Either value_src [S,256] (projected here, padded rows zeroed with `mask`) or a pre-projected `value`.
+        norm = (weight, bias, eps): the LayerNorm that follows this attention in the transformer layer, applied to the result -- in
+        the output projection's epilogue where that kernel exists (87 k encoder tokens), as its own launch otherwise."""
         P = self.packed(dt)
         if value is None:
             value = ops.gemm(value_src, P["wval"], P["bval"], rowmask=mask, mask_mode=ops.MASK_ZERO_OUTPUT,
@@ -100,7 +102,10 @@ class MultiScaleDeformableAttention(nn.Module):
         half = dt in ops.HALF16 and query_pos_sum.shape[0] >= 2048 and os.environ.get("APE_MSDA_F32_OFFSETS") != "1"
         offw = ops.gemm(query_pos_sum, P["woffw"], P["boffw"], out_dtype=torch.float16 if half else torch.float32)
         samp = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=dt)
-        return ops.gemm(samp, P["wout"], P["bout"], residual=identity, out_dtype=out_dtype or dt)
+        if norm is not None and ops.gemm_norm_fusable(samp, P["wout"], identity, out_dtype):
+            return ops.gemm(samp, P["wout"], P["bout"], residual=identity, norm=norm)
+        y = ops.gemm(samp, P["wout"], P["bout"], residual=identity, out_dtype=out_dtype or dt)
+        return y if norm is None else ops.layernorm(y, norm[0], norm[1], norm[2], out_dtype=out_dtype or dt)
 
     def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
                 reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):

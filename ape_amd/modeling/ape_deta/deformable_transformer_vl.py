@@ -51,9 +51,9 @@ class DeformableDetrTransformerEncoderVL(nn.Module):
                 # deformable attention and FFN and is joined at the end of the layer
                 v_new, qp, ljob = self.vl_layers[i].b_attn.forward_tokens(x, lvl_pos, l, dt, defer_language=True)
             # BaseTransformerLayer ("self_attn", "norm", "ffn", "norm"): value = fused tokens (no pos), identity = same
-            x1 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
-                                                    mask=geo.mask_u8)
-            x2 = ops.layernorm(x1, *layer.norm_params(0), out_dtype=dt)
+            # ... with the layer's first norm in the output projection's epilogue (csrc/gemm.hip gemm_kres_ln_kernel)
+            x2 = layer.attentions[0].forward_tokens(qp, v_new, geo.enc_ref, geo.shapes, geo.starts, dt, value_src=v_new,
+                                                    mask=geo.mask_u8, norm=layer.norm_params(0))
             # FFN + the layer's last norm: one launch on the one-kernel FFN path (csrc/ffn_fused.hip, LayerNorm in its epilogue)
             x, xp = layer.ffns[0].forward_tokens(x2, dt, norm=layer.norm_params(1)), None
             l = ljob.join()

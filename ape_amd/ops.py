@@ -92,8 +92,11 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None):
     """C = epi(alpha * a @ w.T); see ApeGemmArgs in include/ape_hip.h for the epilogue order.
+
+    norm = (weight [N], bias [N], eps): LayerNorm of the finished row (after bias / residual) in the same launch -- the K = N = 256,
+    M >= 2048, 16-bit kernel only (`gemm_norm_fusable`); anything else is an argument error of the library.
 
     rownorm = (rowscale [M], rowshift [M], colvec [N]) fp32: acc * rowscale[m] + rowshift[m] * colvec[n] right after alpha
     (a LayerNorm of `a` folded into this GEMM: statistics from `row_stats`, gamma folded into w, colvec = row sums of w).
@@ -153,6 +156,9 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
             raise ValueError("ape_amd.ops.gemm: rownorm = (rowscale [M], rowshift [M], colvec [N])")
         args.rowscale, args.rowshift, args.colvec = (_f32vec(rs, "rowscale").data_ptr(), _f32vec(sh, "rowshift").data_ptr(),
                                                      _f32vec(cv, "colvec").data_ptr())
+    if norm is not None:
+        _dev(norm[0], norm[1])
+        args.ln_w, args.ln_b, args.ln_eps = _f32vec(norm[0], "norm weight").data_ptr(), _f32vec(norm[1], "norm bias").data_ptr(), float(norm[2])
     t64, sk = _auto_tiling(M, N, K, a.dtype, trans_out, act)
     if splitk is not None:
         sk = int(splitk)
@@ -164,6 +170,12 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         args.splitk, args.workspace = sk, ws.data_ptr()
     _lib.check(_lib.load().ape_hip_gemm(ctypes.byref(args), _stream()), "ape_hip_gemm")
     return out
+
+
+def gemm_norm_fusable(a, w, residual=None, out_dtype=None):
+    """can `gemm(a, w, ..., residual=residual, norm=...)` run the LayerNorm in its epilogue?  (csrc/gemm.hip gemm_kres_ln_kernel)"""
+    return (a.dtype in HALF16 and a.shape[1] == 256 and w.shape[0] == 256 and a.shape[0] >= 2048 and (out_dtype or a.dtype) == a.dtype
+            and (residual is None or residual.dtype == a.dtype) and os.environ.get("APE_NO_LN_EPILOGUE") != "1")
 
 
 def row_stats(x, eps):

@@ -90,6 +90,14 @@ typedef struct ApeGemmArgs {
    * stages its rows through LDS with the LDS-DMA of the last K tile instead of re-reading them from L2 per accumulator row
    * (measured on the q|k projection: the table / bias loads were 11.7 of the launch's 46.9 us).  NULL = cos / sin tables only. */
   const float* rope_cs;
+  /* LayerNorm of the finished output row in the epilogue (the "norm" that follows an attention's output projection + identity in
+   * detrex's BaseTransformerLayer): C = LN(acc + bias + residual) * ln_w + ln_b over the N channels, statistics on the fp32 sums.
+   * Implemented by the K = N = 256 register-resident kernel (16-bit operands, M >= 2048, plain epilogue); anything else is an
+   * argument error -- callers launch ape_hip_layernorm instead.  ln_w NULL = off. */
+  const float* ln_w;
+  const float* ln_b;
+  float ln_eps;
+  int32_t reserved0;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */

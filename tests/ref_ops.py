@@ -34,7 +34,7 @@ def _rotate_half(x):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None):
     M, K = a.shape
     N = w.shape[0]
     x = (a.float() @ w.float().t()) * alpha
@@ -63,6 +63,8 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         x = x + residual.float()
     if rm is not None and mask_mode == MASK_ZERO_OUTPUT:
         x = x.masked_fill(rm[:, None], 0.0)
+    if norm is not None:            # LayerNorm of the fp32 sums (the kernel's epilogue), one rounding of the result
+        x = F.layer_norm(x, (x.shape[1],), norm[0].float(), norm[1].float(), norm[2])
     odt = out.dtype if out is not None else (out_dtype or a.dtype)
     if trans_out:
         ld = m_pad or M
@@ -76,6 +78,11 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
         out[:, : x.shape[1]] = x.to(odt)
         return out
     return x.to(odt)
+
+
+def gemm_norm_fusable(a, w, residual=None, out_dtype=None):
+    return (a.dtype in (torch.bfloat16, torch.float16) and a.shape[1] == 256 and w.shape[0] == 256 and a.shape[0] >= 2048
+            and (out_dtype or a.dtype) == a.dtype and (residual is None or residual.dtype == a.dtype))
 
 
 def head_gemv(x, w, bias=None, alpha=1.0, *, bf16_copy=False):

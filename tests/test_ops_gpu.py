@@ -183,6 +183,27 @@ def test_gemm_kres(ops, bf):
     assert out[:, :256].abs().max().item() == 0 and out[:, 768:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("bf", H16)
+def test_gemm_kres_layernorm_epilogue(ops, bf):
+    """K = N = 256 linear + bias + residual + LayerNorm in one launch (the encoder's attention output projection and the norm behind
+    it) vs the two-step definition; ragged last row block; statistics on the fp32 sums"""
+    for M in (87296, 5000, 2048):
+        a, w = rnd(M, 256, dtype=bf, seed=1), rnd(256, 256, dtype=bf, scale=1 / 16, seed=2)
+        bias, res = rnd(256, seed=3), rnd(M, 256, dtype=bf, seed=4) * 2.0 + 0.3
+        gamma, beta = 1.0 + 0.1 * rnd(256, seed=5), 0.1 * rnd(256, seed=6)
+        assert ops.gemm_norm_fusable(a, w, res)
+        for r in (res, None):
+            got = ops.gemm(a, w, bias, residual=r, norm=(gamma, beta, 1e-5))
+            if not SELF:
+                from ape_amd import _lib
+                assert b"kres_ln" in _lib.load().ape_hip_gemm_last_kernel()
+            want = ref_ops.gemm(a, w, bias, residual=r, norm=(gamma, beta, 1e-5))
+            two = ref_ops.layernorm(ref_ops.gemm(a, w, bias, residual=r), gamma, beta, 1e-5)      # what two launches give (one more rounding)
+            e, e2 = relerr(got, want), relerr(got, two)
+            print(f"gemm + LayerNorm epilogue {bf} M{M} residual={r is not None}: {e:.3e} (vs the two-launch form {e2:.3e})")
+            assert got.dtype == bf and e < TOL[bf] and e2 < 3 * TOL[bf] and torch.isfinite(got.float()).all()
+
+
 def test_gemv(ops):
     x = rnd(3, 1024, seed=1)
     for dt in (torch.float32, torch.bfloat16):
