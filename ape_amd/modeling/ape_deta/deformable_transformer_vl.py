@@ -280,8 +280,8 @@ class DeformableDetrTransformerVL(nn.Module):
         Batch elements run one after the other through `forward_tokens` (the reference evaluates batch 1)."""
         if not self.as_two_stage or query_embed is not None:
             raise NotImplementedError("ape_amd: the two-stage transformer of the APE configs (as_two_stage=True, no query_embed)")
-        if attention_mask_l is not None or multi_level_masks_prompt is not None:
-            raise NotImplementedError("ape_amd: language masks (un-reduced text tokens) and mask prompts are not implemented")
+        if attention_mask_l is not None:
+            raise NotImplementedError("ape_amd: language masks (un-reduced text tokens, text_feature_reduce_before_fusion=False) are not implemented")
         dt = getattr(self, "compute_dtype", torch.bfloat16)
         B = multi_level_feats[0].shape[0]
         rows = []
@@ -290,9 +290,13 @@ class DeformableDetrTransformerVL(nn.Module):
             pos = [p[b].flatten(1).t() for p in multi_level_pos_embeds]
             geo = G.geometry_from_masks(masks, pos)
             src = torch.cat([f[b].flatten(1).t() for f in multi_level_feats]).to(dt).contiguous()
-            tr = self.forward_tokens(src, geo, query_l[b].float().contiguous(), dt)
+            # multi_level_masks_prompt (:430, :465-471): per-level bool maps [B, H_l, W_l], flattened and concatenated like the
+            # features; tokens outside the prompt are no proposals (:356-365)
+            mp = None if multi_level_masks_prompt is None else torch.cat([m[b].reshape(-1) for m in multi_level_masks_prompt]).to(torch.bool)
+            tr = self.forward_tokens(src, geo, query_l[b].float().contiguous(), dt, mask_prompt=mp)
+            anchors = geo.proposals if mp is None else geo.proposals.masked_fill(~mp.to(geo.proposals.device)[:, None], float("inf"))   # (:356-358)
             rows.append((torch.stack(tr["inter_states"]), tr["init_reference"], torch.stack(tr["inter_references"]),
-                         tr["enc_class"][:, None], tr["enc_coord_unact"], geo.proposals.sigmoid(), tr["memory"], tr["query_l"]))
+                         tr["enc_class"][:, None], tr["enc_coord_unact"], anchors.sigmoid(), tr["memory"], tr["query_l"]))
         odt = multi_level_feats[0].dtype
         cat = lambda i, dim: torch.stack([r[i] for r in rows], dim)                      # noqa: E731
         return (cat(0, 1).to(odt), cat(1, 0).to(odt), cat(2, 1).to(odt), cat(3, 0).to(odt), cat(4, 0).to(odt), cat(5, 0).to(odt),

@@ -78,6 +78,9 @@ def parse():
                          "image at k = 100); rle = the evaluators' COCO run lengths, encoded on the device (a few KB per image) and "
                          "all-gathered across ranks with the records.  auto = bitmask on 1 GPU, rle on N > 1 (north_star: all-gather of boxes / masks)")
     ap.add_argument("--dry-images", type=int, default=1000, help="--dry: length of the sharded synthetic stream")
+    ap.add_argument("--instrumented-only", action="store_true",
+                    help="skip the timed region: run only the instrumented pass that produces `roofline` (what tools/gpu_profile.sh puts "
+                         "under rocprofv3 --kernel-trace --stats, so that the trace holds exactly the launches the HIP events metered)")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
                     help="16-bit flavour of the timed pipeline: bf16 = BASELINE's dtype (default); f16 = IEEE half operands, the reference's "
                          "own evaluation dtype (tools/train_net.py:642) -- same kernels, v_mfma_f32_16x16x32_f16, 3 more mantissa bits")
@@ -492,6 +495,8 @@ def main():
         dp.drain()
         return done
 
+    if args.instrumented_only:
+        args.warmup = args.steps = 0
     for i in range(args.warmup):
         step(i)
     flush()
@@ -505,7 +510,7 @@ def main():
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max(time.perf_counter() - t0, 1e-9)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -542,8 +547,8 @@ def main():
         all_t, all_fl = sum(g[1][1] for g in groups), sum(g[1][2] for g in groups)
         achieved = dom_fl / dom_t / 1e12
         result = {
-            "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": world * args.steps * B / elapsed, "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": (world * args.steps * B / elapsed) if args.steps else None, "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": (1e3 * elapsed / args.steps) if args.steps else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
                                    f"{B} images, everything after it one batch-1 forward per image ({B} parallel branches of one "
@@ -556,7 +561,7 @@ def main():
                                       "float CHW -> forward, all inside the timed region" % (S * 5 // 4, S * 5 // 4)) if args.input == "uint8"
                                      else "float32 model-ready images resident in HBM (PCIe-exclusive, the tier's definition of `value`)",
                        "mask_format": mask_format, "records_exchange": "all-gather, awaited one step late by the host" if world > 1 else "none (1 rank)",
-                       "host_MB_per_s_per_rank": round((args.steps * B / elapsed) * (
+                       "host_MB_per_s_per_rank": round((args.steps * B / elapsed if args.steps else 0.0) * (
                            (mv.test_topk_per_image * S * S if mask_format == "bitmask" else mv.test_topk_per_image * graphed.rle_cap * 4)
                            + mv.test_topk_per_image * 32) / 1e6, 1),
                        "batched_vit": not args.no_batch_vit, "stream": args.stream,
@@ -566,10 +571,11 @@ def main():
                          "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n / reps,
                          "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
                          "flops_per_launch": dom_fl / max(dom_n, 1),
-                         # the family's exact symbols as rocprofv3 --kernel-trace lists them (one per epilogue specialisation)
-                         "symbols": {k: {"launches_per_image": v[0] / reps, "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 2),
-                                         "tflops": round(v[2] / v[1] / 1e12, 1)}
-                                     for k, v in sorted(meter.symbols.items(), key=lambda kv: -kv[1][1]) if GemmMeter.family(k) == dom_name},
+                         "metering": "HIP event pair per launch in an eager pass of the step's composition, every branch inline (one kernel at a "
+                                     "time).  A/B'd in round 4: keeping the queue full with a spin kernel ahead of each instrumented step changes "
+                                     "nothing (q|k 43.0 vs 43.3 us) -- these are stand-alone launch durations.  hipGraph replays of ONE kernel back to "
+                                     "back read ~10 us shorter (tools/gpu_gemm_p8.py: the tail of launch i overlaps the head of launch i + 1), which "
+                                     "dependent launches inside the model cannot do",
                          # the dominant family per problem shape M x N x K (launches per image, average us, TFLOP/s)
                          "by_shape": {sh: {"launches_per_image": round(v[0] / reps, 2), "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 1),
                                            "tflops": round(v[2] / v[1] / 1e12, 1)}

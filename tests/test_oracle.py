@@ -151,16 +151,24 @@ def test_oracle_vit_eva02_backbone_matches_reference_golden():
 
 
 @pytest.mark.skipif(not refshim.available(), reason="needs /root/reference")
-def test_transformer_reference_signature_matches_live_reference(fake_ops):
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_maskprompt"])
+def test_transformer_reference_signature_matches_live_reference(fake_ops, case):
     """`DeformableDetrTransformerVL.forward(multi_level_feats, masks, pos_embeds, query_embed, query_l, attention_mask_l,
     masks_prompt)` -> the reference's 8-tuple (deformable_transformer_vl.py:422-689).  The reference model is run on a padded
     image, the transformer's own inputs are captured by a hook and handed to the HIP-path module (ops = their definitions)."""
     from ape_amd.modeling.build import build_ape
     from oracle import run_reference as RR, weights
 
-    gold = U.load_golden("tiny_padded")
+    gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
-    S, _, spec, _ = RR.run_reference(cfg_name, wseed, image, text)
+    mask_prompt = None
+    if case == "tiny_maskprompt":          # the predictor's inputs["mask_prompt"]: multi_level_masks_prompt is the 7th positional argument
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+        from make_golden import CASES, case_mask_prompt
+        mask_prompt = case_mask_prompt(CASES[case], image.shape[-2:])
+    S, _, spec, _ = RR.run_reference(cfg_name, wseed, image, text, mask_prompt=mask_prompt)
+    assert (S["transformer_inputs"][6] is not None) == (mask_prompt is not None)
     model = build_ape(cfg_name)
     model.load_state_dict(weights.make_state_dict(spec, wseed), strict=False)
     mv = model.model_vision

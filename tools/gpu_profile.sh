@@ -8,7 +8,10 @@ TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_e /tmp/prof_g
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o eager -- env APE_NO_FORK=1 python $R/bench.py --no-graph --images-per-step 2 --no-pipeline --steps 6 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_eager_under_rocprof.json 2> /tmp/prof_e.err
+# (a) = the instrumented pass of the default bench and nothing else (--instrumented-only): the launches the HIP events of the `roofline`
+# object metered, each starting on a busy GPU (spin kernel ahead of every step); the per-kernel averages of this trace are what
+# `roofline.avg_launch_us` must agree with
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o eager -- python $R/bench.py --instrumented-only --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_bench_eager_under_rocprof.json 2> /tmp/prof_e.err
 find /tmp/prof_e -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_eager_kernel_stats.csv \;
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_g -o graph -- python $R/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_graph_under_rocprof.json 2> /tmp/prof_g.err
 find /tmp/prof_g -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_graph_kernel_stats.csv \;

@@ -26,6 +26,13 @@ for name, cs in sorted(agg.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
     g = m.get
     if g("SQ_WAVE_CYCLES") and g("SQ_ACTIVE_INST_VALU") is not None:
         print(f"   -> VALU active / wave cycles            {g('SQ_ACTIVE_INST_VALU') / g('SQ_WAVE_CYCLES'):.3f}")
+    # VALU-busy fraction of the SIMDs' time.  SQ_ACTIVE_INST_VALU counts QUAD-cycles (4 shader cycles, MI355X_MICROARCH.md
+    # "s_memtime tick vs SQ PMC units") summed over all waves; the chip offers 1024 SIMDs (256 CUs x 4) x GRBM_GUI_ACTIVE cycles
+    # while the kernel runs (GRBM_GUI_ACTIVE is summed over the 8 XCDs by this rocprofv3: / 8):
+    #     VALU busy = 4 * SQ_ACTIVE_INST_VALU / (1024 * GRBM_GUI_ACTIVE / 8)
+    if g("SQ_ACTIVE_INST_VALU") is not None and g("GRBM_GUI_ACTIVE"):
+        busy = 4.0 * g("SQ_ACTIVE_INST_VALU") / (1024.0 * g("GRBM_GUI_ACTIVE") / 8.0)
+        print(f"   -> VALU busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs)   {busy:.3f}")
     if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_INST_ANY") is not None:
         print(f"   -> issue stall (WAIT_INST_ANY) / cycles  {g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.3f}")
     if g("SQ_WAVE_CYCLES") and g("SQ_WAIT_ANY") is not None:
