@@ -1,4 +1,4 @@
-from . import vit_eva02, vit_eva_clip  # noqa: F401
+from . import vit_eva, vit_eva02, vit_eva_clip  # noqa: F401
 
 from ... import _overlay as _ov  # noqa: E402
 

@@ -131,6 +131,10 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     "ape_hip_ffn_fused": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
+    "ape_hip_attention_ext": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_int, c_float, c_int, c_void_p]),
+    "ape_hip_relpos_extend": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "ape_hip_resize_coeffs": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int]),
     "ape_hip_resize_tile_rows": (c_int, [c_void_p, c_int, POINTER(c_int)]),
     "ape_hip_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,

@@ -59,17 +59,31 @@ __device__ __forceinline__ float quad_rows_max(float v) {
 // QT = query tiles (16 rows each) per wave: a workgroup covers 64*QT queries.  QT = 2 halves both the K/V bytes every
 // workgroup streams from L2 (each (window, head) re-reads its K/V once per workgroup) and the LDS fragment reads per MFMA.
 // H = bf16_t | f16_t: storage of q / k / v^T / o and of the probabilities handed to the P.V MFMA.
-template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1, typename H = bf16_t>
+// HDV = head width of V / the output when it differs from the q.k width HD: the EVA-01 MIM ViT (vit_eva.py) adds decomposed relative
+// positions to the scores, which this kernel takes as EXTRA q / k channels (q_ext = [scale q | q.Rh | q.Rw], k_ext = [k | one-hot row |
+// one-hot column]: modeling/backbone/vit_eva.py) -- HD = 256 / 288 / 320 against HDV = 128.
+// chunk swizzle of K rows with >= 16 chunks: XOR of the low four chunk bits (whole groups of 16) -- a trailing group of 4 or 8 chunks
+// (HD = 288 / 320) swizzles inside itself
+template <int KC> __device__ __forceinline__ int kswz_wide(int cp, int row) {
+  constexpr int REM = KC & 15;
+  static_assert(REM == 0 || REM == 4 || REM == 8, "K rows of 16 g (+ 4 | 8) chunks");
+  const int s = kperm_swz16(row);
+  if (REM != 0 && cp >= KC - REM) return (cp & ~15) + ((cp & 15) ^ (s & (REM - 1)));
+  return cp ^ s;
+}
+
+template <int HD, int QT, bool CAUSAL = false, bool PERM = true, int OCC = 1, typename H = bf16_t, int HDV = HD>
 __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p) {
-  static_assert(HD == 32 || HD == 64 || (HD == 128 && PERM), "head dimension 32 / 64 / 128 (128: permuted key order only)");
+  static_assert(HD == 32 || HD == 64 || (HD % 32 == 0 && HD >= 128 && HD <= 320 && PERM), "q.k width 32 / 64 / 128 ... 320 (>= 128: permuted key order only)");
+  static_assert(HDV == HD || (HDV == 128 && HD > 128), "V width = q.k width, or 128 under a wider (extended) q.k");
   constexpr int KC = HD / 8;        // 16-byte chunks per K row
   constexpr int KSTEPS = HD / 32;   // MFMA k-steps over d for S
-  constexpr int DT = HD / 16;       // output d tiles
+  constexpr int DT = HDV / 16;      // output d tiles
   // two SEPARATE arrays (not one [2][...]) and a tile loop unrolled by two: with a run-time buffer index hipcc cannot tell the
   // LDS-DMA writes of the NEXT tile from the ds_reads of the current one and drains the DMA queue (s_waitcnt vmcnt(0)) in front of
   // the V^T reads of every tile -- the prefetch then overlaps nothing.  Distinct objects are provably disjoint.
-  __shared__ __attribute__((aligned(16))) bf16_t smemA[64 * HD + HD * 64];    // [K tile | Vt tile], even tiles
-  __shared__ __attribute__((aligned(16))) bf16_t smemB[64 * HD + HD * 64];    // odd tiles
+  __shared__ __attribute__((aligned(16))) bf16_t smemA[64 * HD + HDV * 64];   // [K tile | Vt tile], even tiles
+  __shared__ __attribute__((aligned(16))) bf16_t smemB[64 * HD + HDV * 64];   // odd tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
@@ -95,22 +109,25 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
   // nothing for the compiler to spill: the register-staged version kept the prefetched tile in scratch and waited for
   // every global load right after issuing it).  The LDS destination of an instruction is lane-linear (64 x 16 B), so the
   // XOR swizzle of swz_rows() is applied to the per-lane SOURCE chunk instead.
-  constexpr int PER = HD * 8 / 256;  // instructions per wave per operand: 4 (HD=128), 2 (HD=64) or 1 (HD=32)
+  constexpr int PER = HD * 8 / 256;    // K-tile instructions per wave: HD / 32
+  constexpr int PERV = HDV * 8 / 256;  // V^T-tile instructions per wave
   typedef __attribute__((address_space(3))) void lds_void_t;
   typedef const __attribute__((address_space(1))) void gbl_void_t;
   // per-lane source positions as 32-bit element offsets from wave-uniform bases (64-bit per-lane pointers cost twice the registers)
   const bf16_t* kbase = Kp + (size_t)b * p.bstride * p.ldk + h * HD;
-  const bf16_t* vbase = Vp + (size_t)(h * HD) * p.ldvt + (size_t)b * p.bstride;
-  int kcol[PER], voff[PER], krow[PER];
+  const bf16_t* vbase = Vp + (size_t)(h * HDV) * p.ldvt + (size_t)b * p.bstride;
+  int kcol[PER], voff[PERV], krow[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int slot = (wave * PER + i) * 64 + lane;
-    {
-      const int row = slot / KC, cp = slot % KC;
-      const int c = KC == 16 ? (cp ^ kperm_swz16(row)) : KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
-      krow[i] = row;
-      kcol[i] = c * 8;
-    }
+    const int row = slot / KC, cp = slot % KC;
+    const int c = KC >= 16 ? kswz_wide<KC>(cp, row) : KC == 8 ? (cp ^ (PERM ? kperm_swz(row) : ((row >> 1) & 7))) : (cp ^ (((row >> 3) & 1) << 1));
+    krow[i] = row;
+    kcol[i] = c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PERV; ++i) {
+    const int slot = (wave * PERV + i) * 64 + lane;
     {
       const int row = slot >> 3, cp = slot & 7;
       const int c = cp ^ ((row >> 1) & 7);
@@ -127,7 +144,8 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
     for (int i = 0; i < PER; ++i) {
       int key = key0 + krow[i]; key = key < N ? key : N - 1;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(kbase + ((size_t)key * p.ldk + kcol[i])), (lds_void_t*)(dst + (wave * PER + i) * 512), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(vbase + ((size_t)voff[i] + key0)), (lds_void_t*)(dst + 64 * HD + (wave * PER + i) * 512), 16, 0, 0);
+      if (i < PERV)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vbase + ((size_t)voff[i] + key0)), (lds_void_t*)(dst + 64 * HD + (wave * PERV + i) * 512), 16, 0, 0);
     }
   };
 
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
         const int krow_ = PERM ? kperm_row(i, frow) : i * 16 + frow;
-        const int koff = KC == 16 ? krow_ * 128 + (((ks * 4 + fq) ^ kperm_swz16(krow_)) << 3)
+        const int koff = KC >= 16 ? krow_ * HD + (kswz_wide<KC>(ks * 4 + fq, krow_) << 3)
                        : (PERM && KC == 8) ? krow_ * 64 + (((ks * 4 + fq) ^ kperm_swz(krow_)) << 3) : swz_rows(krow_, ks * 4 + fq, KC);
         const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(&sK[koff]));
 #pragma unroll
@@ -271,7 +289,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
     const float inv = 1.f / lacc[u][0];    // every row of the ones-tile holds the full sum over keys for query frow
     if (qrow[u] < N) {
       if (PERM) {
-        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 8;
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HDV + fq * 8;
 #pragma unroll
         for (int dp = 0; dp < DT / 2; ++dp) {
           const float v[8] = {oacc[u][2 * dp][0] * inv, oacc[u][2 * dp][1] * inv, oacc[u][2 * dp][2] * inv, oacc[u][2 * dp][3] * inv,
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
           st8<H>(reinterpret_cast<H*>(o + dp * 32), v);
         }
       } else {
-        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HD + fq * 4;
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.O) + ((size_t)b * p.bstride + qrow[u]) * p.ldo + h * HDV + fq * 4;
 #pragma unroll
         for (int d = 0; d < DT; ++d) {
           const float v[4] = {oacc[u][d][0] * inv, oacc[u][d][1] * inv, oacc[u][d][2] * inv, oacc[u][d][3] * inv};
@@ -293,10 +311,10 @@ __global__ __launch_bounds__(256, OCC) void attn_bf16_kernel(const AttnParams p)
 // ------------------------------------------------------------------------------------------
 // f32 validation kernel: block = 64 lanes = 64 queries of one (window, head)
 // ------------------------------------------------------------------------------------------
-template <int HD>
+template <int HD, int HDV = HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
   __shared__ float sK[64][HD];
-  __shared__ float sV[64][HD];
+  __shared__ float sV[64][HDV];
   const int lane = threadIdx.x;
   const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int N = p.N;
@@ -305,9 +323,11 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
   const float* Vp = reinterpret_cast<const float*>(p.Vt);
   const int qrow = qblk * 64 + lane;
   const int qrow_c = qrow < N ? qrow : N - 1;
-  float q[HD], o[HD];
+  float q[HD], o[HDV];
 #pragma unroll
-  for (int d = 0; d < HD; ++d) { q[d] = Qp[((size_t)b * p.bstride + qrow_c) * p.ldq + h * HD + d] * p.scale; o[d] = 0.f; }
+  for (int d = 0; d < HD; ++d) q[d] = Qp[((size_t)b * p.bstride + qrow_c) * p.ldq + h * HD + d] * p.scale;
+#pragma unroll
+  for (int d = 0; d < HDV; ++d) o[d] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const int nt = (N + 63) / 64;
   for (int t = 0; t < nt; ++t) {
@@ -318,10 +338,10 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
       int key = key0 + row; key = key < N ? key : N - 1;
       sK[row][d] = Kp[((size_t)b * p.bstride + key) * p.ldk + h * HD + d];
     }
-    for (int idx = lane; idx < 64 * HD; idx += 64) {
+    for (int idx = lane; idx < 64 * HDV; idx += 64) {
       const int d = idx / 64, kk = idx % 64;
       const int key = key0 + kk;
-      sV[kk][d] = key < N ? Vp[(size_t)(h * HD + d) * p.ldvt + (size_t)b * p.bstride + key] : 0.f;
+      sV[kk][d] = key < N ? Vp[(size_t)(h * HDV + d) * p.ldvt + (size_t)b * p.bstride + key] : 0.f;
     }
     __syncthreads();
     for (int c0 = 0; c0 < 64; c0 += 16) {
@@ -341,27 +361,27 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const AttnParams p) {
       const float alpha = expf(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < HD; ++d) o[d] *= alpha;
+      for (int d = 0; d < HDV; ++d) o[d] *= alpha;
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
         const float e = expf(s[kk] - m_new);
         l_run += e;
 #pragma unroll
-        for (int d = 0; d < HD; ++d) o[d] = fmaf(e, sV[c0 + kk][d], o[d]);
+        for (int d = 0; d < HDV; ++d) o[d] = fmaf(e, sV[c0 + kk][d], o[d]);
       }
       m_run = m_new;
     }
   }
   if (qrow < N) {
-    float* op = reinterpret_cast<float*>(p.O) + ((size_t)b * p.bstride + qrow) * p.ldo + h * HD;
+    float* op = reinterpret_cast<float*>(p.O) + ((size_t)b * p.bstride + qrow) * p.ldo + h * HDV;
     const float inv = 1.f / l_run;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
+    for (int d = 0; d < HDV; ++d) op[d] = o[d] * inv;
   }
 }
 
 template <typename H>
-static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, int bstride, int H_, int HD, int causal, hipStream_t s) {
+static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, int bstride, int H_, int HD, int HDV, int causal, hipStream_t s) {
   const void* Q = p.Q; const void* K = p.K; const void* Vt = p.Vt; void* O = p.O;
   const int ldq = p.ldq, ldk = p.ldk, ldvt = p.ldvt, ldo = p.ldo;
   const int nheads = H_;
@@ -373,6 +393,17 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
   const bool big = (size_t)ceil_div(N, 128) * nheads * B >= 512;
   if (big) grid.x = ceil_div(N, 128);
   static const bool natural = getenv("APE_ATTN_NATURAL_KEY_ORDER") != nullptr;     // A/B: the round-2 kernel (two b64 V halves, LDS shuffles)
+  if (HDV != HD) {                  // extended q.k (relative positions as extra channels): 256 / 288 / 320 against V of width 128
+    APE_CHECK_ARG(!causal && HDV == 128 && (HD == 256 || HD == 288 || HD == 320), "ape_hip_attention_ext(16-bit): q.k width 256 / 288 / 320 with V width 128");
+#define ATT_WIDE(HD_)                                                                                                         \
+    do {                                                                                                                      \
+      if (big) hipLaunchKernelGGL((attn_bf16_kernel<HD_, 2, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);              \
+      else hipLaunchKernelGGL((attn_bf16_kernel<HD_, 1, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);                  \
+    } while (0)
+    if (HD == 256) ATT_WIDE(256); else if (HD == 288) ATT_WIDE(288); else ATT_WIDE(320);
+#undef ATT_WIDE
+    return 0;
+  }
   if (causal) {
     APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
     if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true, true, 1, H>), grid, dim3(256), 0, s, p);
@@ -401,9 +432,11 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
 }
 
 static int attention_launch(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int B, int N,
-                            int bstride, int H, int HD, float scale, int dt, int causal, void* stream) {
+                            int bstride, int H, int HD, float scale, int dt, int causal, void* stream, int HDV = 0) {
+  if (HDV == 0) HDV = HD;
   APE_CHECK_ARG(Q && K && Vt && O, "ape_hip_attention: null pointer");
-  APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && (HD == 32 || HD == 64 || HD == 128), "ape_hip_attention: bad shape (HD must be 32, 64 or 128)");
+  APE_CHECK_ARG(B > 0 && N > 0 && H > 0 && ((HDV == HD && (HD == 32 || HD == 64 || HD == 128)) || (HDV == 128 && (HD == 256 || HD == 288 || HD == 320))),
+                "ape_hip_attention: head width 32 / 64 / 128, or an extended q.k width of 256 / 288 / 320 over a V width of 128 (got %d / %d)", HD, HDV);
   APE_CHECK_ARG(bstride >= N, "ape_hip_attention: batch stride %d < N %d", bstride, N);
   AttnParams p;
   p.Q = Q; p.K = K; p.Vt = Vt; p.O = O; p.ldq = ldq; p.ldk = ldk; p.ldvt = ldvt; p.ldo = ldo; p.N = N; p.H = H; p.bstride = bstride;
@@ -412,11 +445,14 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(ceil_div(N, 64), H, B);
   if (ape_is16(dt)) {
-    const int rc = dt == APE_DT_F16 ? attention_launch_h16<f16_t>(p, grid, B, N, bstride, H, HD, causal, s)
-                                    : attention_launch_h16<bf16_t>(p, grid, B, N, bstride, H, HD, causal, s);
+    const int rc = dt == APE_DT_F16 ? attention_launch_h16<f16_t>(p, grid, B, N, bstride, H, HD, HDV, causal, s)
+                                    : attention_launch_h16<bf16_t>(p, grid, B, N, bstride, H, HD, HDV, causal, s);
     if (rc != 0) return rc;
   } else {
-    if (HD == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
+    if (HD == 256) hipLaunchKernelGGL((attn_f32_kernel<256, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 288) hipLaunchKernelGGL((attn_f32_kernel<288, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 320) hipLaunchKernelGGL((attn_f32_kernel<320, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
     else if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
   }
@@ -427,6 +463,12 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
 extern "C" int ape_hip_attention_strided(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
                                          int B, int N, int bstride, int H, int HD, float scale, int dt, void* stream) {
   return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, B, N, bstride, H, HD, scale, dt, 0, stream);
+}
+
+// q.k width HDQ != V width HDV (relative-position channels appended to q / k): see attn_bf16_kernel
+extern "C" int ape_hip_attention_ext(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,
+                                     int B, int N, int bstride, int H, int HDQ, int HDV, float scale, int dt, void* stream) {
+  return attention_launch(Q, ldq, K, ldk, Vt, ldvt, O, ldo, B, N, bstride, H, HDQ, scale, dt, 0, stream, HDV);
 }
 
 extern "C" int ape_hip_attention_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo,

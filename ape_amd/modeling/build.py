@@ -54,6 +54,15 @@ SIZES = {
                 dec_layers=6, num_queries=900, topk_eval=300, backbone="clip_g", global_every=4, vl=False),
     "small_G": dict(img_size=512, embed_dim=352, depth=4, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=2,
                     dec_layers=2, num_queries=300, topk_eval=50, backbone="clip_g", global_every=4, vl=False),
+    # APE on the EVA-01 MIM ViT-g of vit_eva.py (ape_deta_vitg_eva01_lsj1536_cp_64x90k.py; vitg_eva01.py / vitg_eva01_1536.py): pre-norm,
+    # packed qkv with q / v bias, GELU MLP, DECOMPOSED RELATIVE POSITIONS in every attention, 16 x 16 windows, every fourth block global,
+    # 16 heads x 88, plain model family.  V_A_1536 is the configuration the reference trains; small_V keeps the head width on a 32 x 32 grid
+    "V_A": dict(img_size=1024, embed_dim=1408, depth=40, num_heads=16, window_size=16, pretrain_img_size=224, enc_layers=6,
+                dec_layers=6, num_queries=900, topk_eval=300, backbone="eva01", global_every=4, vl=False),
+    "V_A_1536": dict(img_size=1536, embed_dim=1408, depth=40, num_heads=16, window_size=32, pretrain_img_size=224, enc_layers=6,
+                     dec_layers=6, num_queries=900, topk_eval=300, backbone="eva01", global_every=4, vl=False),
+    "small_V": dict(img_size=512, embed_dim=352, depth=4, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=2,
+                    dec_layers=2, num_queries=300, topk_eval=50, backbone="eva01", global_every=4, vl=False),
 }
 
 
@@ -98,6 +107,14 @@ def build_ape(size="L_D", model_language=None, vision_kwargs=None, **overrides):
                   window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
                   out_feature="last_feat", use_act_checkpoint=True, xattn=True, pretrain_img_size=c.pretrain_img_size,
                   pretrain_use_cls_token=True)
+    elif getattr(c, "backbone", "eva_clip") == "eva01":       # EVA-01 MIM ViT-g: configs/common/backbone/vitg_eva01.py:9-47
+        from .backbone import vit_eva
+        ge = getattr(c, "global_every", 4)
+        net = vit_eva.ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.6,
+                          window_size=c.window_size, mlp_ratio=6144 / 1408, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                          window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
+                          rel_pos_zero_init=False, out_feature="last_feat", use_act_checkpoint=True, beit_like_qkv_bias=True,
+                          beit_like_gamma=False, freeze_patch_embed=True, pretrain_img_size=c.pretrain_img_size)
     elif getattr(c, "backbone", "eva_clip") == "clip_e":      # ViT-e: configs/common/backbone/vite_eva02_clip_1024.py:9-49
         ge = getattr(c, "global_every", 4)
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.4,

@@ -398,10 +398,12 @@ def msda_fused(value, spatial_shapes, level_start_index, offw, ref, *, batch=1, 
     return out
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False):
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False, v_head_dim=None):
     """softmax(scale * q k^T) v per (window, head); causal: keys after the query are masked (CLIP text tower).  q,k: [rows, >=heads*head_dim] views; vt: V transposed
-    [heads*head_dim, >= (batch-1)*stride + round_up(n, 64)] (finite padding; checked); returns [rows, heads*head_dim].  Window
-    b owns rows b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride)."""
+    [heads*v_head_dim, >= (batch-1)*stride + round_up(n, 64)] (finite padding; checked); returns [rows, heads*v_head_dim].  Window
+    b owns rows b*stride .. b*stride+n-1 (stride defaults to n; rows = (batch-1)*stride + n ... batch*stride).
+    v_head_dim (default head_dim): the V / output width per head when it differs from the q.k width -- the relative-position
+    channels of ape_amd.ops.relpos_extend ride in q / k only (head_dim 128 | 256 | 288 | 320 over v_head_dim 128)."""
     _dev(q, k, vt, out)
     _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(vt, "vt")
     if not (q.dtype == k.dtype == vt.dtype):
@@ -413,13 +415,43 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=No
     if vt.shape[1] < need or q.shape[0] < (batch - 1) * stride + n:
         raise ValueError(f"ape_amd.ops.attention: vt has {vt.shape[1]} columns, the tiled reads need {need} "
                          f"((batch - 1) * stride + round_up(n, 64)); q has {q.shape[0]} rows")
+    hdv = head_dim if v_head_dim is None else int(v_head_dim)
     if out is None:
-        out = (torch.empty if stride == n else torch.zeros)((batch * stride, heads * head_dim), dtype=q.dtype, device=q.device)
+        out = (torch.empty if stride == n else torch.zeros)((batch * stride, heads * hdv), dtype=q.dtype, device=q.device)
+    if hdv != head_dim:
+        if causal:
+            raise ValueError("ape_amd.ops.attention: v_head_dim != head_dim has no causal variant")
+        rc = _lib.load().ape_hip_attention_ext(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, stride, heads,
+                                               head_dim, hdv, float(scale), _dt(q), _stream())
+        _lib.check(rc, "ape_hip_attention_ext")
+        return out
     fn = _lib.load().ape_hip_attention_causal if causal else _lib.load().ape_hip_attention_strided
     rc = fn(_p(q), _ld(q), _p(k), _ld(k), _p(vt), _ld(vt), _p(out), _ld(out), batch, n, stride, heads, head_dim, float(scale),
             _dt(q), _stream())
     _lib.check(rc, "ape_hip_attention")
     return out
+
+
+def relpos_extend(q, k, t, ty, tx, *, heads, head_stride, head_dim, hk, wk, ext_dim, scale, t_rows_per_token=None):
+    """operands of attention with decomposed relative positions (ape/modeling/backbone/vit_eva.py:121-146, utils_eva.py:132-161):
+    q, k [rows, >= heads * head_stride] views (head h at columns h * head_stride .. + head_dim); t [rows * t_rows_per_token (default heads),
+    >= 2 hk - 1 + 2 wk - 1] = q . [Rh ; Rw]^T, the row of (token, head) being token * t_rows_per_token + head; ty / tx int32 [period]: position of token (row % period) in its attention group.  Returns
+    q_ext = [scale q | q.Rh[ty - kh] | q.Rw[tx - kw] | 0], k_ext = [k | one-hot ty | one-hot tx | 0]: [rows, heads * ext_dim] each."""
+    _dev(q, k, t, ty, tx)
+    _rowmajor(q, "q"), _rowmajor(k, "k"), _rowmajor(t, "t")
+    if not (q.dtype == k.dtype == t.dtype) or _ld(q) != _ld(k):
+        raise TypeError("ape_amd.ops.relpos_extend: q / k / t must share a dtype (and q, k a row stride)")
+    _i32(ty, "ty"), _i32(tx, "tx")
+    rows = q.shape[0]
+    tper = heads if t_rows_per_token is None else int(t_rows_per_token)
+    if t.shape[0] != rows * tper or ty.numel() != tx.numel() or rows % ty.numel():
+        raise ValueError("ape_amd.ops.relpos_extend: t must have rows * t_rows_per_token rows; rows a multiple of the coordinate period")
+    qe = torch.empty((rows, heads * ext_dim), dtype=q.dtype, device=q.device)
+    ke = torch.empty_like(qe)
+    rc = _lib.load().ape_hip_relpos_extend(_p(q), _p(k), _ld(q), _p(t), _ld(t), tper, _p(ty), _p(tx), ty.numel(), _p(qe), _p(ke), _ld(qe), rows,
+                                           heads, head_stride, head_dim, hk, wk, ext_dim, float(scale), _dt(q), _stream())
+    _lib.check(rc, "ape_hip_relpos_extend")
+    return qe, ke
 
 
 def embed_tokens(tokens, table, pos, length, stride):

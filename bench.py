@@ -162,16 +162,24 @@ class GemmMeter:
 def pmc_traffic_bytes(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh ->
     profiles/r0N_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md's HBM section prescribes for gfx950).  None when the summary does not list the kernel."""
-    for name in ("r03_pmc_summary.txt", "r02b_pmc_summary.txt", "r02_pmc_summary.txt", "r01_pmc_summary.txt"):
+    MI355X_MICROARCH.md's HBM section prescribes for gfx950).  None when the summary does not list the kernel.
+    The library reports `gemm_bf16_p8_kernel<256, true>` / `gemm_f16_...`; rocprofv3 lists the full instantiation
+    (`gemm_bf16_p8_kernel<256, true, unsigned short, 0>`, `..., _Float16, 0>`): matched by prefix + operand type."""
+    f16 = kernel.startswith("gemm_f16_")
+    prefix = ("gemm_bf16_" + kernel[len("gemm_f16_"):] if f16 else kernel).rstrip(">")
+    for name in ("r04_pmc_summary.txt", "r03_pmc_summary.txt", "r02b_pmc_summary.txt", "r02_pmc_summary.txt", "r01_pmc_summary.txt"):
         path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path) and any(l.split("|")[0].strip() == kernel for l in open(path)):
-            break
-    else:
-        return None
-    for line in open(path):
-        cols = [c.strip() for c in line.split("|")]
-        if len(cols) > 3 and cols[0] == kernel:
+        if not os.path.exists(path):
+            continue
+        for line in open(path):
+            cols = [c.strip() for c in line.split("|")]
+            if len(cols) <= 3 or not cols[0].startswith(prefix):
+                continue
+            rest = cols[0][len(prefix):]
+            if rest not in (">", "") and not rest.startswith(","):
+                continue                                   # a longer first-arguments match (e.g. <256, true> vs <256, true1>)
+            if ("_Float16" in rest) != f16 and rest not in (">", ""):
+                continue
             try:
                 return float(cols[-1]) * 1024.0 * 1024.0
             except ValueError:
@@ -584,7 +592,11 @@ def main():
                                               "flops_per_image": all_fl / reps,
                                               "by_kernel_ms_per_image": {k: round(1e3 * v[1] / reps, 3) for k, v in groups},
                                               "by_kernel_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in groups},
-                                              "by_kernel_launches_per_image": {k: round(v[0] / reps, 2) for k, v in groups}}},
+                                              "by_kernel_launches_per_image": {k: round(v[0] / reps, 2) for k, v in groups},
+                                              # every (kernel family, M x N x K) with >= 0.05 ms per image: launches, average us, TFLOP/s
+                                              "by_kernel_and_shape": {f"{fam} {sh}": [round(v[0] / reps, 2), round(1e6 * v[1] / max(v[0], 1), 1), round(v[2] / v[1] / 1e12, 1)]
+                                                                      for (fam, sh), v in sorted(meter.shapes.items(), key=lambda kv: -kv[1][1])
+                                                                      if 1e3 * v[1] / reps >= 0.05}}},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

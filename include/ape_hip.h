@@ -448,6 +448,21 @@ int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const int32_t* or
                      uint64_t* workspace, float* det_boxes, float* det_scores, int64_t* det_classes, int64_t* det_query, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Attention with a q.k width HDQ different from the V / output width HDV (HDQ = 256 | 288 | 320, HDV = 128), and the kernel that
+ * builds such operands for the EVA-01 MIM ViT's decomposed relative positions (ape/modeling/backbone/vit_eva.py:121-146,
+ * utils_eva.py:132-161):  attn[q, (kh, kw)] = scale q.k + q.Rh[qh - kh] + q.Rw[qw - kw] = q_ext . k_ext  with
+ *   q_ext = [scale q (hd) | q.Rh[qh - kh], kh = 0 .. Hk-1 | q.Rw[qw - kw], kw = 0 .. Wk-1 | 0 ...],  k_ext = [k | one-hot(kh) | one-hot(kw) | 0 ...]
+ * ape_hip_relpos_extend: q, k [rows, ldqk] (head h at columns h * hs), t [rows * tper, ldt] = q . [Rh ; Rw]^T (2 Hk - 1 + 2 Wk - 1
+ * columns, from ape_hip_gemm; the row of (token, head) is token * tper + head, tper >= nh), ty / tx [period] = position of token (row %% period) inside its attention group ->
+ * q_ext, k_ext [rows, lde] (head h at columns h * hdq), all tensors in dtype dt (0 / 1 / 2).  -- csrc/relpos.hip, csrc/attention.hip
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_attention_ext(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O, int ldo, int B, int N,
+                          int bstride, int H, int HDQ, int HDV, float scale, int dt, void* stream);
+int ape_hip_relpos_extend(const void* q, const void* k, int ldqk, const void* t, int ldt, int tper, const int* ty, const int* tx, int period,
+                          void* q_ext, void* k_ext, int lde, int rows, int nh, int hs, int hd, int Hk, int Wk, int hdq, float scale, int dt,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The encoder / decoder FFN in one kernel: y = residual + relu(x W1^T + b1) W2^T + b2 (detrex FFN with add_identity,
  * ape/modeling/ape_deta/deformable_transformer_vl.py:45-54 and :160-166), 16-bit in / out (dt = APE_DT_BF16 | APE_DT_F16: x, the
  * weights, the residual, y and the hidden activation between the two contractions all in that type), K = N = 256, HID %% 64 == 0 (<= 4096).

@@ -265,6 +265,55 @@ class ApeOracle:
         x = shortcut + x
         return x + self.lin(F.gelu(self.lin(self.ln(x, pre + "norm2", 1e-6), pre + "mlp.fc1")), pre + "mlp.fc2")
 
+    # --------------------------------------------------------------------------------------------
+    # EVA-01 MIM ViT-g (ape/modeling/backbone/vit_eva.py: Attention :72-146, Block :210-309): the packed-qkv / GELU-Mlp pre-norm block
+    # above PLUS decomposed relative positions (utils_eva.py:65-161): attn[q, (kh, kw)] += q . Rh[qh - kh] + q . Rw[qw - kw] with
+    # the UNSCALED q; tables of 2 * size - 1 rows (linear interpolation, "vitdet", when the stored length differs)
+    # --------------------------------------------------------------------------------------------
+    @staticmethod
+    def rel_pos_table(q_size, k_size, rel_pos):
+        """get_rel_pos (utils_eva.py:65-129, interp_type="vitdet"): -> [q_size, k_size, C]"""
+        max_rel_dist = int(2 * max(q_size, k_size) - 1)
+        if rel_pos.shape[0] != max_rel_dist:
+            rel_pos = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=max_rel_dist, mode="linear")
+            rel_pos = rel_pos.reshape(-1, max_rel_dist).permute(1, 0)
+        q_coords = torch.arange(q_size)[:, None] * max(k_size / q_size, 1.0)
+        k_coords = torch.arange(k_size)[None, :] * max(q_size / k_size, 1.0)
+        rel = (q_coords - k_coords) + (k_size - 1) * max(q_size / k_size, 1.0)
+        return rel_pos[rel.long()]
+
+    def vit_attention_relpos(self, x, i):
+        pre = f"backbone.net.blocks.{i}.attn."
+        B, H, W, C = x.shape
+        N = H * W
+        nh = self.num_heads_vit
+        q_bias, v_bias = self.p(pre + "q_bias"), self.p(pre + "v_bias")
+        qkv = F.linear(x.reshape(B, N, C), self.p(pre + "qkv.weight"), torch.cat((q_bias, torch.zeros_like(v_bias), v_bias)))
+        qkv = qkv.reshape(B, N, 3, nh, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = (t.reshape(B * nh, N, -1) for t in (qkv[0], qkv[1], qkv[2]))
+        att = (q * q.shape[-1] ** -0.5) @ k.transpose(-2, -1)
+        Rh, Rw = self.rel_pos_table(H, H, self.p(pre + "rel_pos_h")), self.rel_pos_table(W, W, self.p(pre + "rel_pos_w"))
+        r_q = q.reshape(B * nh, H, W, -1)
+        rel_h = torch.einsum("bhwc,hkc->bhwk", r_q, Rh)
+        rel_w = torch.einsum("bhwc,wkc->bhwk", r_q, Rw)
+        att = (att.view(B * nh, H, W, H, W) + rel_h[:, :, :, :, None] + rel_w[:, :, :, None, :]).view(B * nh, N, N).softmax(dim=-1)
+        o = (att @ v).view(B, nh, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
+        return self.lin(o, pre + "proj")
+
+    def vit_block_eva01(self, x, i):
+        pre = f"backbone.net.blocks.{i}."
+        shortcut = x
+        x = self.ln(x, pre + "norm1", 1e-6)
+        if i in self.win_blocks:
+            H, W = x.shape[1], x.shape[2]
+            xw = window_partition(x, self.ws)
+            xw = self.vit_attention_relpos(xw, i)
+            x = window_unpartition(xw, self.ws, H, W)
+        else:
+            x = self.vit_attention_relpos(x, i)
+        x = shortcut + x
+        return x + self.lin(F.gelu(self.lin(self.ln(x, pre + "norm2", 1e-6), pre + "mlp.fc1")), pre + "mlp.fc2")
+
     def vit_block_postnorm(self, x, i):
         pre = f"backbone.net.blocks.{i}."
         shortcut = x
@@ -301,7 +350,8 @@ class ApeOracle:
             t0 = time.perf_counter()
             kind = self.cfg.get("backbone")
             x = (self.vit_block_eva02(x, i) if kind == "eva02" else self.vit_block_postnorm(x, i) if kind == "clip_e"
-                 else self.vit_block_prenorm_packed(x, i) if kind == "clip_g" else self.vit_block(x, i))
+                 else self.vit_block_prenorm_packed(x, i) if kind == "clip_g" else self.vit_block_eva01(x, i) if kind == "eva01"
+                 else self.vit_block(x, i))
             self._tick("vit_win_block" if i in self.win_blocks else "vit_glb_block", t0)
             self.stages[f"vit_block{i}"] = x
         return x.permute(0, 3, 1, 2)

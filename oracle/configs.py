@@ -35,6 +35,13 @@ CONFIGS = {
     # configs/common/backbone/vite_eva02_clip_1024.py:9-49): EVA-02-CLIP ViT-e -- 64 post-norm blocks of width 1792 (16 heads of
     # 112), packed qkv, GELU MLP (ratio 8.5714), no rope, every fourth block global -- in front of a 9 + 9 layer DETA; and a small
     # copy that keeps the head width of 112 and a layer count other than 6
+    # the EVA-01 MIM ViT-g of vit_eva.py (configs/common/backbone/vitg_eva01.py / vitg_eva01_1536.py under ape_deta_vitg_eva01_lsj1536_cp_64x90k.py,
+    # plain model family): pre-norm, packed qkv with q / v bias, GELU MLP, DECOMPOSED RELATIVE POSITIONS in every attention (16 x 16
+    # windows, every fourth block global), 16 heads x 88.  small_V keeps the head width (88) on a 32 x 32 grid
+    "small_V": dict(img_size=512, embed_dim=352, depth=4, num_heads=4, window_size=16, pretrain_img_size=224, enc_layers=2, dec_layers=2,
+                    num_queries=300, topk_eval=50, backbone="eva01", global_every=4, vl=False),
+    "V_A": dict(img_size=1024, embed_dim=1408, depth=40, num_heads=16, window_size=16, pretrain_img_size=224, enc_layers=6, dec_layers=6,
+                num_queries=900, topk_eval=300, backbone="eva01", global_every=4, vl=False),
     "E_D": dict(img_size=1024, embed_dim=1792, depth=64, num_heads=16, window_size=32, pretrain_img_size=224,
                 enc_layers=9, dec_layers=9, num_queries=900, topk_eval=300, backbone="clip_e", global_every=4),
     "small_E": dict(img_size=512, embed_dim=224, depth=4, num_heads=2, window_size=16, pretrain_img_size=224,

@@ -81,6 +81,14 @@ def build_reference(cfg, text_feats, semantic_on=False, panoptic_on=False, panop
                   window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
                   out_feature="last_feat", use_act_checkpoint=False, xattn=True, pretrain_img_size=c.pretrain_img_size,
                   pretrain_use_cls_token=True)
+    elif cfg.get("backbone") == "eva01":        # EVA-01 MIM ViT-g of vit_eva.py: configs/common/backbone/vitg_eva01.py:9-47 (relative positions)
+        from ape.modeling.backbone.vit_eva import SimpleFeaturePyramid, ViT
+        ge = cfg.get("global_every", 4)
+        net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.0,
+                  window_size=c.window_size, mlp_ratio=6144 / 1408, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                  window_block_indexes=[i for i in range(c.depth) if i % ge != ge - 1], residual_block_indexes=[], use_rel_pos=True,
+                  rel_pos_zero_init=False, out_feature="last_feat", use_act_checkpoint=True, beit_like_qkv_bias=True, beit_like_gamma=False,
+                  freeze_patch_embed=True, pretrain_img_size=c.pretrain_img_size)
     elif cfg.get("backbone") == "clip_e":       # ViT-e: configs/common/backbone/vite_eva02_clip_1024.py:9-49
         ge = cfg.get("global_every", 4)
         net = ViT(img_size=c.img_size, patch_size=16, embed_dim=c.embed_dim, depth=c.depth, num_heads=c.num_heads, drop_path_rate=0.0,

@@ -437,6 +437,22 @@ def _mod(name, **attrs):
     return m
 
 
+class TimmMlp(nn.Module):
+    """stand-in for timm.models.layers.Mlp as vit_eva.py:258 uses it (published definition: fc1 -> act -> drop -> fc2 -> drop, bias on
+    both linears; parity unpinned -- timm is not installed here)"""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
 def _noop(*a, **k):
     return None
 
@@ -482,7 +498,10 @@ def install():
     _mod("torchvision.ops.boxes", batched_nms=tp.batched_nms, nms=tp.nms)
     _mod("timm")
     _mod("timm.models")
-    _mod("timm.models.layers", DropPath=DropPath)
+    _mod("timm.models.layers", DropPath=DropPath, Mlp=TimmMlp, trunc_normal_=nn.init.trunc_normal_)
+    _mod("fairscale")
+    _mod("fairscale.nn")
+    _mod("fairscale.nn.checkpoint", checkpoint_wrapper=lambda m, *a, **k: m)     # activation checkpointing: identity at inference
     _mod("fvcore")
     _mod("fvcore.nn")
     _mod("fvcore.nn.weight_init", c2_xavier_fill=_noop, c2_msra_fill=_noop)
@@ -523,6 +542,8 @@ def install():
     load("ape.modeling.backbone.utils_eva02", "ape/modeling/backbone/utils_eva02.py")
     load("ape.modeling.backbone.vit_eva_clip", "ape/modeling/backbone/vit_eva_clip.py")
     load("ape.modeling.backbone.vit_eva02", "ape/modeling/backbone/vit_eva02.py")
+    load("ape.modeling.backbone.utils_eva", "ape/modeling/backbone/utils_eva.py")
+    load("ape.modeling.backbone.vit_eva", "ape/modeling/backbone/vit_eva.py")
 
     A = sys.modules["ape.modeling.ape_deta"]
     _mod("ape.modeling.ape_deta.segmentation", MaskHeadSmallConv=object, MHAttentionMap=object)

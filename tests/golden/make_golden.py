@@ -52,10 +52,14 @@ CASES = {
     "small_E": ("small_E", 2, 6, (448, 512), 8, 7),
     # f4: APE on the EVA-01-CLIP ViT-g backbone (pre-norm, packed qkv, GELU MLP, head width 88) under the plain family, reduced size
     "small_G": ("small_G", 3, 8, (512, 400), 9, 5),
+    # f4: APE on the EVA-01 MIM ViT-g of vit_eva.py (decomposed relative positions in window and global attention, head width 88), reduced size
+    "small_V": ("small_V", 4, 11, (480, 512), 9, 5),
     # config 2 with a REAL photograph (demo/examples/*.jpg): the reference's demo image, decoded, BGR -> RGB, resized by
     # Pillow exactly as ape/engine/defaults.py:213-222 does (ResizeShortestEdge(1024, 1024): 394 x 700 -> 576 x 1024).  The JPEG
     # bytes (42 KB) travel inside the fixture; the tests decode them with the same library.
     "L_D_jpeg": ("L_D_coco", 0, "jpeg:Pisa.jpg", (576, 1024), 80, 3),
+    # f4: APE on ViT-e at FULL size (64 post-norm blocks x 1792, 9 + 9 layers: ape_deta_vite_eva02_clip_vlf_lsj1024_cp_16x4_1080k_mdl_fsdp.py)
+    "E_D_coco80": ("E_D", 0, 2, (1024, 1024), 80, 3),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }

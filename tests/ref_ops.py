@@ -212,8 +212,9 @@ def embed_tokens(tokens, table, pos, length, stride):
     return out.reshape(B * stride, W)
 
 
-def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False):
+def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=None, causal=False, v_head_dim=None):
     E = heads * head_dim
+    hdv = head_dim if v_head_dim is None else v_head_dim
     stride = n if stride is None else stride
     rows = batch * stride
 
@@ -224,18 +225,39 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=No
         return tf[:rows].reshape(batch, stride, heads, head_dim)[:, :n].permute(0, 2, 1, 3)
 
     qf, kf = win(q), win(k)
-    vf = vt[:, :rows].float().reshape(heads, head_dim, batch, stride)[..., :n].permute(2, 0, 3, 1)
+    vf = vt[:, :rows].float().reshape(heads, hdv, batch, stride)[..., :n].permute(2, 0, 3, 1)
     att = (qf @ kf.transpose(-1, -2)) * scale
     if causal:
         att = att + torch.full((n, n), float("-inf"), device=att.device).triu_(1)
-    o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                       # [batch, n, heads, head_dim]
-    full = o.new_zeros((batch, stride, heads, head_dim))
+    o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                       # [batch, n, heads, hdv]
+    full = o.new_zeros((batch, stride, heads, hdv))
     full[:, :n] = o
-    full = full.reshape(rows, E)
+    full = full.reshape(rows, heads * hdv)
     if out is not None:
         out[:rows].copy_(full.to(out.dtype))
         return out
     return full.to(q.dtype)
+
+
+def relpos_extend(q, k, t, ty, tx, *, heads, head_stride, head_dim, hk, wk, ext_dim, scale, t_rows_per_token=None):
+    rows = q.shape[0]
+    per = ty.numel()
+    y = ty.long().repeat(rows // per)
+    x = tx.long().repeat(rows // per)
+    qh = q[:, :heads * head_stride].float().reshape(rows, heads, head_stride)[..., :head_dim]
+    kh = k[:, :heads * head_stride].float().reshape(rows, heads, head_stride)[..., :head_dim]
+    tf = t.float().reshape(rows, t_rows_per_token or heads, -1)[:, :heads]
+    qe = q.new_zeros((rows, heads, ext_dim), dtype=torch.float32)
+    ke = torch.zeros_like(qe)
+    qe[..., :head_dim] = qh * scale
+    ke[..., :head_dim] = kh
+    ih = y[:, None] - torch.arange(hk, device=q.device)[None] + hk - 1                      # [rows, hk]
+    iw = x[:, None] - torch.arange(wk, device=q.device)[None] + wk - 1 + (2 * hk - 1)
+    qe[..., head_dim:head_dim + hk] = torch.gather(tf, 2, ih[:, None].expand(-1, heads, -1))
+    qe[..., head_dim + hk:head_dim + hk + wk] = torch.gather(tf, 2, iw[:, None].expand(-1, heads, -1))
+    ke[..., head_dim:head_dim + hk] = torch.nn.functional.one_hot(y, hk)[:, None].float()
+    ke[..., head_dim + hk:head_dim + hk + wk] = torch.nn.functional.one_hot(x, wk)[:, None].float()
+    return qe.reshape(rows, -1).to(q.dtype), ke.reshape(rows, -1).to(q.dtype)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -445,6 +445,60 @@ def test_vitg_clip_model_state_dict_contract_and_host_pipeline(fake_ops):
     assert frac >= 0.97
 
 
+def test_eva01_mim_vitg_relative_positions(fake_ops):
+    """APE on the EVA-01 MIM ViT-g of vit_eva.py (ape_deta_vitg_eva01_lsj1536_cp_64x90k.py: packed qkv with q / v bias, GELU
+    MLP, pre-norm, DECOMPOSED RELATIVE POSITIONS in every window / global attention, 40 x 1408 = 16 heads x 88, plain family):
+    parameterisation of the full-size models, and the host composition at reduced size -- the relative-position terms as extra q / k
+    channels (head 88 + 16 + 16 -> 128 in the windows, 88 + 32 + 32 -> 256 over a V width of 128 in the global block) -- vs the oracle
+    and the reference-generated fixture"""
+    from ape_amd.modeling.backbone import vit_eva
+    from ape_amd.modeling.build import build_ape
+
+    with torch.device("meta"):
+        big = build_ape("V_A_1536")
+    sd = big.state_dict()
+    assert sd["model_vision.backbone.net.blocks.39.attn.qkv.weight"].shape == (3 * 1408, 1408)
+    assert sd["model_vision.backbone.net.blocks.0.attn.rel_pos_h"].shape == (63, 88)            # 32 x 32 windows
+    assert sd["model_vision.backbone.net.blocks.3.attn.rel_pos_w"].shape == (191, 88)           # global: 96 x 96 tokens
+    assert "model_vision.backbone.net.blocks.0.attn.qkv.bias" not in sd and "model_vision.backbone.net.blocks.0.attn.q_bias" in sd
+    assert vit_eva.ext_width(88, 32, 32) == 256 and vit_eva.ext_width(88, 96, 96) == 288 and vit_eva.ext_width(88, 16, 16) == 128
+    with pytest.raises(ValueError):
+        vit_eva.ext_width(88, 128, 128)
+    with pytest.raises(NotImplementedError):
+        vit_eva.Attention(64, 2, use_rel_pos=True, input_size=(4, 4), interp_type="beit")
+    # get_rel_pos "vitdet" (utils_eva.py:65-129): a checkpoint table of another length is resized linearly
+    tbl = torch.randn(9, 8)
+    assert torch.equal(vit_eva.resized_rel_pos(tbl, 5), tbl)
+    want = torch.nn.functional.interpolate(tbl.t()[None], size=13, mode="linear")[0].t()
+    assert torch.allclose(vit_eva.resized_rel_pos(tbl, 7), want)
+    model, orc, image, text, gold = M.build_pair("small_V")
+    own = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert own == {k: list(v) for k, v in U.load_spec("small_V")}                        # == the reference model's state_dict()
+    mv = model.model_vision
+    stages = {}
+    mv.forward_single(image, text, stages=stages)
+    orc.forward(image, text)
+    for k in ("p2", "p4", "p6", "enc_input", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact"):
+        b = M.token_major(k, orc.stages[k])
+        assert U.relerr(stages[k].reshape(b.shape), b) < 2e-4, k
+    assert M.set_overlap(stages["topk_proposals"], gold["full"]["topk_proposals"][0]) >= 0.99
+    ref_topk = gold["full"]["topk_proposals"][0]
+    stages = {}
+    out = mv.forward_single(image, text, forced_topk=ref_topk, stages=stages)
+    assert U.relerr(stages["pred_logits"], gold["full"]["pred_logits"][0]) < 1e-3      # north_star tolerance, vs the reference run
+    assert U.relerr(stages["pred_boxes"], gold["full"]["pred_boxes"][0]) < 1e-3
+    frac = U.match_detections(out["det_boxes"], out["det_scores"], out["det_classes"], gold["full"]["det_boxes"],
+                              gold["full"]["det_scores"], gold["full"]["det_classes"])
+    assert frac >= 0.97
+    # the layer scale of the BEiT-style checkpoints (gamma_1 / gamma_2, vit_eva.py:278-281, 296-298) folds into the block's last linears
+    blk = vit_eva.Block(64, 2, mlp_ratio=2.0, norm_layer=torch.nn.LayerNorm, use_rel_pos=True, rel_pos_zero_init=False, window_size=4,
+                        input_size=(8, 8), beit_like_qkv_bias=True, beit_like_gamma=True)
+    with torch.no_grad():
+        blk.gamma_1.uniform_(0.5, 1.5), blk.gamma_2.uniform_(0.5, 1.5), blk.attn.q_bias.normal_(), blk.attn.v_bias.normal_()
+    P = blk.packed(torch.float32, 4)
+    assert torch.allclose(P["wproj"][:, :32], blk.attn.proj.weight[:, :32] * blk.gamma_1[:, None]) and torch.allclose(P["b2"], blk.mlp.fc2.bias * blk.gamma_2)
+
+
 def test_mask_prompt_restricts_the_proposals(fake_ops):
     """deformable_detr_segm_vl.py:394-414 / deformable_transformer_vl.py:356-365: with a mask prompt only encoder tokens inside
     the prompted region may become proposals (anchors +inf, memory rows zero elsewhere) -- vs the reference-generated fixture, through

@@ -26,7 +26,7 @@ def _run(case, dtype):
     return model, orc, image.cuda(), text.cuda(), gold, image, text
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G"])
+@pytest.mark.parametrize("case", ["tiny_padded", "tiny_square", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G", "small_V"])
 def test_fp32_pipeline_matches_oracle_and_reference(case):
     """T1: every HIP kernel in its fp32 instantiation; tolerance = north_star's 1e-3 on logits / boxes"""
     model, orc, image, text, gold, image_c, text_c = _run(case, torch.float32)
@@ -74,7 +74,7 @@ def test_fp32_pipeline_matches_oracle_and_reference(case):
     assert mm < 2e-3
 
 
-@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "small_G"])
+@pytest.mark.parametrize("case", ["tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "small_G", "small_V"])
 def test_bf16_pipeline(case):
     """bf16 storage + MFMA, fp32 accumulate on the small models (all prompt modes): (a) every stage, fed the fp32 pipeline's
     input (teacher forcing), is inside the tolerance derived from bf16's 8 significant bits (tests/teacher_forced.py); (b) the
@@ -333,7 +333,8 @@ def test_eval_dataset_panoptic_on_gpu():
 # ------------------------------------------------------------------------------------------------------------------
 # The BASELINE.json configurations at full size (APE-L_D, 1024^2 / 1536^2), against fixtures produced by executing the
 # reference on the same seeded inputs (tests/golden/make_golden.py: L_D_coco80 = config 2, L_D_lvis1203 = config 3,
-# L_D_padded = a COCO-shaped image of config 4, L_D_1536_sseg = config 5).  No oracle run here: fixtures only.
+# L_D_padded = a COCO-shaped image of config 4, L_D_1536_sseg = config 5; E_D_coco80 = APE on ViT-e at full size, 64 post-norm blocks
+# of width 1792 and a 9 + 9 layer DETA).  No oracle run here: fixtures only.
 # ------------------------------------------------------------------------------------------------------------------
 LD_STAGES = ("p2", "p4", "p6", "enc0_fused_v", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact",
              "mask_features")
@@ -365,7 +366,7 @@ def _ld_mask_sign_mismatch(stages, out, gold):
     return bad / max((~tie).float().sum().item(), 1.0), len(rows)
 
 
-@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg"])
+@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "E_D_coco80"])
 def test_L_D_fp32_matches_reference(case):
     """T1 at the benchmarked sizes: fp32 HIP kernels vs the reference run; north_star tolerance 1e-3 on logits / boxes,
     identical argmax masks"""
@@ -476,9 +477,11 @@ def test_predictor_input_pipeline_on_the_real_photograph():
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg"])
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "E_D_coco80"])
 def test_L_D_bf16_pipeline(case, dt):
     tag = "bf16" if dt == torch.bfloat16 else "f16"
+    if case == "E_D_coco80" and dt == torch.float16 and os.environ.get("APE_TEST_ALL_F16") != "1":
+        pytest.skip("APE-E_D (4.5 B parameters, 40 s of seeded weight generation per build): one 16-bit flavour by default")
     model, image, text, gold = M.build_model(case, DEV, dt)
     mv = model.model_vision
     image, text = image.to(DEV), text.to(DEV)

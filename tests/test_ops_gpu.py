@@ -402,6 +402,79 @@ def test_attention(ops, dtype, B, N, H, HD):
     assert e < T16(dtype, 2e-2, 2e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("B,N,H,HDQ", [(2, 1024, 4, 256), (1, 4096, 2, 256), (1, 2304, 2, 288), (1, 1000, 2, 320), (3, 200, 4, 256)])
+def test_attention_wide_keys(ops, dtype, B, N, H, HDQ):
+    """q.k width 256 / 288 / 320 over a V width of 128 (ape_hip_attention_ext): the operands of the EVA-01 MIM ViT's global blocks,
+    whose relative-position terms ride as extra q / k channels (vit_eva.py:121-146)"""
+    if dtype == torch.float32 and N > 2048:
+        pytest.skip("f32 validation kernel: keep the case small")
+    HDV = 128
+    q = rnd(B * N, H * HDQ, dtype=dtype, seed=1)
+    k = rnd(B * N, H * HDQ, dtype=dtype, seed=3)
+    vt = poisoned_vt(H * HDV, B, N, N, dtype, 2)
+    scale = HDQ ** -0.5
+    kw = dict(batch=B, n=N, heads=H, head_dim=HDQ, v_head_dim=HDV, scale=scale)
+    got = ops.attention(q, k, vt, **kw)
+    want = ref_ops.attention(q, k, vt, **kw)
+    assert tuple(got.shape) == (B * N, H * HDV)
+    e = relerr(got, want)
+    print(f"attention wide {dtype} B{B} N{N} H{H} HDQ{HDQ}: {e:.3e}")
+    assert e < T16(dtype, 1e-2, 2e-5)
+    qs = q.clone()
+    qs[::3] *= 12.0
+    e = relerr(ops.attention(qs, k, vt, **kw), ref_ops.attention(qs, k, vt, **kw))
+    print(f"attention wide (peaked) {dtype}: {e:.3e}")
+    assert e < T16(dtype, 2e-2, 2e-5)
+    if not SELF:
+        with pytest.raises(RuntimeError):                                  # widths outside the instantiated set are refused
+            ops.attention(q[:, :H * 192], k[:, :H * 192], vt, batch=B, n=N, heads=H, head_dim=192, v_head_dim=HDV, scale=scale)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,nh,hd,hs,g,ext,period", [(1024, 4, 88, 128, 16, 128, 256), (2048, 2, 88, 128, 32, 256, 1024), (512, 3, 64, 64, 16, 128, 256)])
+def test_relpos_extend(ops, dtype, rows, nh, hd, hs, g, ext, period):
+    """q_ext = [scale q | q.Rh[ty - kh] | q.Rw[tx - kw] | 0], k_ext = [k | one-hot ty | one-hot tx | 0] (csrc/relpos.hip) -- a pure
+    gather / scale: exact up to the one rounding of scale q; and its dot product reproduces add_decomposed_rel_pos
+    (utils_eva.py:132-161) on the scores"""
+    qk = rnd(rows, 2 * nh * hs, dtype=dtype, seed=1)
+    q, k = qk[:, :nh * hs], qk[:, nh * hs:]
+    nr = 2 * (2 * g - 1)
+    tper = 2 * nh
+    t = rnd(rows * tper, nr + 2, dtype=dtype, seed=2)
+    perm = torch.randperm(period, generator=torch.Generator().manual_seed(0))
+    ty = (perm // g % g).int().to(DEV).contiguous()
+    tx = (perm % g).int().to(DEV).contiguous()
+    kw = dict(heads=nh, head_stride=hs, head_dim=hd, hk=g, wk=g, ext_dim=ext, scale=hd ** -0.5, t_rows_per_token=tper)
+    qe, ke = ops.relpos_extend(q, k, t, ty, tx, **kw)
+    qw, kw_ = ref_ops.relpos_extend(q, k, t, ty, tx, **kw)
+    assert tuple(qe.shape) == (rows, nh * ext)
+    assert torch.equal(ke, kw_)
+    e = relerr(qe, qw)
+    print(f"relpos_extend {dtype} rows{rows} nh{nh} g{g} ext{ext}: q_ext {e:.2e}, k_ext exact")
+    assert e < T16(dtype, 4e-3, 1e-6)
+    if dtype == torch.float32:
+        # one attention group, end to end vs the reference formulation: t = q . [Rh ; Rw]^T
+        R = rnd(nr, hd, dtype=dtype, seed=5)
+        n = g * g
+        qh = q[:n].reshape(n, nh, hs)[..., :hd]
+        kh = k[:n].reshape(n, nh, hs)[..., :hd]
+        tt = torch.zeros((n * tper, nr), device=DEV)
+        tt.view(n, tper, nr)[:, :nh] = qh @ R.t()
+        yy = (torch.arange(n, device=DEV) // g).int().contiguous()
+        xx = (torch.arange(n, device=DEV) % g).int().contiguous()
+        qe, ke = ops.relpos_extend(q[:n], k[:n], tt, yy, xx, **kw)
+        scores = torch.einsum("qhc,khc->hqk", qe.view(n, nh, ext), ke.view(n, nh, ext))
+        Rh, Rw = R[:2 * g - 1], R[2 * g - 1:]
+        idx = (torch.arange(g, device=DEV)[:, None] - torch.arange(g, device=DEV)[None, :]) + g - 1
+        rel_h = torch.einsum("qhc,qkc->hqk", qh, Rh[idx][yy.long()])                      # [nh, n, g]: q . Rh[qy - ky]
+        rel_w = torch.einsum("qhc,qkc->hqk", qh, Rw[idx][xx.long()])
+        want = (hd ** -0.5) * torch.einsum("qhc,khc->hqk", qh, kh) + rel_h[:, :, yy.long()] + rel_w[:, :, xx.long()]
+        e = relerr(scores, want)
+        print(f"relpos_extend: q_ext . k_ext vs scale q.k + decomposed relative positions: {e:.2e}")
+        assert e < 1e-5
+
+
 def test_attention_kernel_variants_agree(ops, monkeypatch):
     """the opt-in 256-query kernel (APE_ATTN_QT4=1) computes every query with the 128-query kernel's arithmetic: bit-identical
     outputs, incl. ragged last tiles (N % 64 != 0), single-tile and two-tile sequences"""

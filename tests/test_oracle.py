@@ -18,7 +18,8 @@ FP32_TOL = 2e-4  # two fp32 implementations of the same math (different op order
 # small_E: APE on the ViT-e backbone (post-norm blocks, packed qkv, GELU MLP, head width 112) with 3 + 3 layers
 # tiny_maskprompt: a mask prompt restricts the proposals to the prompted region (and drives the selection into its fall-back list)
 # small_G: the plain family on the EVA-01-CLIP ViT-g flavour (pre-norm, packed qkv, GELU MLP, head width 88)
-@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G"])
+# small_V: the plain family on the EVA-01 MIM ViT-g of vit_eva.py (decomposed relative positions)
+@pytest.mark.parametrize("case", ["tiny_square", "tiny_padded", "small_padded", "tiny_phrase", "small_A", "small_E", "tiny_maskprompt", "small_G", "small_V"])
 def test_oracle_matches_reference_golden(case):
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
