@@ -6,7 +6,7 @@ under tests/ -- never the other way round.)
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libape_hip.so")
@@ -117,6 +117,10 @@ SIGNATURES = {
     "ape_hip_query_finish": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
                                      c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ape_hip_bilinear_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_panoptic_pixels": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "ape_hip_panoptic_decide": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ape_hip_panoptic_write": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ape_hip_enc_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ape_hip_topk_workspace_words": (c_int, [c_int]),
     "ape_hip_proposal_topk": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

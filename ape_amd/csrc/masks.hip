@@ -277,3 +277,133 @@ extern "C" int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_r
   APE_CHECK_LAUNCH("ape_hip_bilinear_resize");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Panoptic merge on the device (_postprocess_panoptic, ape/modeling/ape_deta/deformable_detr_segm_vl.py:921-998): the reference walks
+// over the kept queries with three `.item()` read-backs each; here the merge is three launches and no host round trip, so it can
+// sit inside a captured step (ape_amd/runtime.py, GraphedForward(panoptic=meta)).
+//   panoptic_pixels : per output pixel, over the kept queries q in index order: p_q = sigmoid(bilinear(mask logits of q)) (the
+//                     second resize of sem_seg_postprocess, :942, fused: the [k, H, W] tensor never exists), owner = first argmax of
+//                     score_q p_q (:957-959), conf = p_owner >= prob; areas[q] = (#pixels owned, #pixels with p_q >= prob, #both)
+//                     (:965-967) by wave-aggregated atomics
+//   panoptic_decide : the sequential walk (:963-995) on one thread: overlap test in double like Python's int / int, stuff classes
+//                     merged through a per-class memory, category remap of the "things first" stuff vocabulary -> segment id per
+//                     query + the segments_info table
+//   panoptic_write  : panoptic_seg[pixel] = id[owner] where conf, else 0
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void panoptic_pixels_kernel(const float* __restrict__ masks, int ldq, int ldr, int h, int w, int k,
+                                                              const float* __restrict__ score, const uint8_t* __restrict__ keep, float prob,
+                                                              int H, int W, int16_t* __restrict__ owner, uint8_t* __restrict__ conf,
+                                                              int* __restrict__ areas) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool in = gid < (size_t)H * W;
+  const size_t pix = in ? gid : 0;
+  const int x = (int)(pix % W), y = (int)(pix / W);
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+  float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+  int y0 = (int)fy; y0 = y0 < h - 1 ? y0 : h - 1;
+  int x0 = (int)fx; x0 = x0 < w - 1 ? x0 : w - 1;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const size_t o00 = (size_t)y0 * ldr + x0, o01 = (size_t)y0 * ldr + x1, o10 = (size_t)y1 * ldr + x0, o11 = (size_t)y1 * ldr + x1;
+  float bestv = -INFINITY;
+  int best = -1;
+  bool bconf = false;
+  for (int q = 0; q < k; ++q) {
+    if (keep[q] == 0) continue;                                     // uniform
+    const float* p = masks + (size_t)q * ldq;
+    const float v = (1.f - ly) * ((1.f - lx) * p[o00] + lx * p[o01]) + ly * ((1.f - lx) * p[o10] + lx * p[o11]);
+    const float pr = 1.f / (1.f + expf(-v));
+    const bool c = in && pr >= prob;
+    const unsigned long long b = __ballot(c);
+    if (b != 0ull && lane == (int)__builtin_ctzll(b)) atomicAdd(&areas[q * 3 + 1], (int)__builtin_popcountll(b));
+    const float val = score[q] * pr;
+    if (val > bestv) { bestv = val; best = q; bconf = c; }
+  }
+  if (in) { owner[gid] = (int16_t)best; conf[gid] = bconf ? 1 : 0; }
+  const int mine = in ? best : -1;
+  unsigned long long todo = __ballot(mine >= 0);
+  while (todo != 0ull) {                                            // one atomic pair per distinct owner in the wave
+    const int leader = (int)__builtin_ctzll(todo);
+    const int qv = __shfl(mine, leader, 64);
+    const unsigned long long same = __ballot(mine == qv);
+    const unsigned long long both = __ballot(mine == qv && bconf);
+    if (lane == leader) {
+      atomicAdd(&areas[qv * 3], (int)__builtin_popcountll(same));
+      if (both != 0ull) atomicAdd(&areas[qv * 3 + 2], (int)__builtin_popcountll(both));
+    }
+    todo &= ~same;
+  }
+}
+
+__global__ __launch_bounds__(256) void panoptic_decide_kernel(const int* __restrict__ areas, const int* __restrict__ classes, const uint8_t* __restrict__ keep,
+                                                              int k, const uint8_t* __restrict__ isthing, int num_classes, double overlap_thr,
+                                                              int stuff_offset, int* __restrict__ seg_id, int* __restrict__ info, int* __restrict__ count) {
+  extern __shared__ int stuff_mem[];                                // segment id a stuff class already owns (0 = none)
+  for (int i = threadIdx.x; i < num_classes; i += 256) stuff_mem[i] = 0;
+  for (int i = threadIdx.x; i < k * 3; i += 256) info[i] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  int cur = 0, n = 0;
+  for (int q = 0; q < k; ++q) {
+    seg_id[q] = 0;
+    if (keep[q] == 0) continue;
+    const int ma = areas[q * 3], oa = areas[q * 3 + 1], ba = areas[q * 3 + 2];
+    if (!(ma > 0 && oa > 0 && ba > 0)) continue;
+    if ((double)ma / (double)oa < overlap_thr) continue;
+    const int c = classes[q];
+    const bool thing = c >= 0 && c < num_classes && isthing[c] != 0;
+    if (!thing && c >= 0 && c < num_classes) {
+      if (stuff_mem[c] != 0) { seg_id[q] = stuff_mem[c]; continue; }
+      stuff_mem[c] = cur + 1;
+    }
+    ++cur;
+    seg_id[q] = cur;
+    info[n * 3] = cur;
+    info[n * 3 + 1] = thing ? 1 : 0;
+    info[n * 3 + 2] = (!thing && stuff_offset >= 0) ? c - stuff_offset + 1 : c;
+    ++n;
+  }
+  *count = n;
+}
+
+__global__ __launch_bounds__(256) void panoptic_write_kernel(const int16_t* __restrict__ owner, const uint8_t* __restrict__ conf,
+                                                             const int* __restrict__ seg_id, size_t total, int* __restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int q = owner[gid];
+  out[gid] = (q >= 0 && conf[gid] != 0) ? seg_id[q] : 0;
+}
+
+extern "C" int ape_hip_panoptic_pixels(const float* masks, int ld_query, int ld_row, int h, int w, int k, const float* scores, const uint8_t* keep,
+                                       float prob, int H, int W, int16_t* owner, uint8_t* conf, int* areas, void* stream) {
+  APE_CHECK_ARG(masks && scores && keep && owner && conf && areas && h > 0 && w > 0 && k > 0 && k < 32768 && H > 0 && W > 0,
+                "ape_hip_panoptic_pixels: bad args (1 <= k < 32768 queries)");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(areas, 0, (size_t)k * 3 * sizeof(int), s) != hipSuccess) { ape_set_error("ape_hip_panoptic_pixels: memset failed"); return -1; }
+  const size_t total = (size_t)H * W;
+  hipLaunchKernelGGL(panoptic_pixels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, masks, ld_query, ld_row, h, w, k, scores, keep, prob,
+                     H, W, owner, conf, areas);
+  APE_CHECK_LAUNCH("ape_hip_panoptic_pixels");
+  return 0;
+}
+
+extern "C" int ape_hip_panoptic_decide(const int* areas, const int* classes, const uint8_t* keep, int k, const uint8_t* isthing, int num_classes,
+                                       double overlap_threshold, int stuff_offset, int* seg_id, int* info, int* count, void* stream) {
+  APE_CHECK_ARG(areas && classes && keep && isthing && seg_id && info && count && k > 0 && num_classes > 0 && num_classes <= 16384,
+                "ape_hip_panoptic_decide: bad args (num_classes <= 16384)");
+  hipLaunchKernelGGL(panoptic_decide_kernel, dim3(1), dim3(256), (size_t)num_classes * sizeof(int), (hipStream_t)stream, areas, classes, keep, k, isthing,
+                     num_classes, overlap_threshold, stuff_offset, seg_id, info, count);
+  APE_CHECK_LAUNCH("ape_hip_panoptic_decide");
+  return 0;
+}
+
+extern "C" int ape_hip_panoptic_write(const int16_t* owner, const uint8_t* conf, const int* seg_id, int H, int W, int* out, void* stream) {
+  APE_CHECK_ARG(owner && conf && seg_id && out && H > 0 && W > 0, "ape_hip_panoptic_write: bad args");
+  const size_t total = (size_t)H * W;
+  hipLaunchKernelGGL(panoptic_write_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owner, conf, seg_id, total, out);
+  APE_CHECK_LAUNCH("ape_hip_panoptic_write");
+  return 0;
+}

@@ -366,8 +366,10 @@ class DeformableDETRSegmVL(nn.Module):
         level_shapes = [maps[f][1] for f in names]
         if geo is None:
             geo = self.geometry((h, w), level_shapes)
-        elif semantic is not None or panoptic:
-            raise NotImplementedError("ape_amd: the size-agnostic (static geometry) forward covers the instance branch")
+        elif panoptic:
+            # the semantic branch is size-agnostic (class scores over the whole pad; the caller crops / resizes with the image's
+            # sizes, runtime.GraphedForward._sem_labels); the panoptic branch crops its masks to (h, w) here
+            raise NotImplementedError("ape_amd: the size-agnostic (static geometry) forward covers the instance and semantic branches")
         t0 = time.perf_counter()
         src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
         def neck_level(i, f):
@@ -579,54 +581,42 @@ class DeformableDETRSegmVL(nn.Module):
             results.append(res)
         return results
 
-    def postprocess_panoptic(self, out, height, width, meta):
-        """_postprocess_panoptic (:921-998): Mask2Former-style merge of the kept queries' masks.  The per-segment decisions
-        are data dependent and read back by the host, exactly like the reference's `.item()` loop; the pixel work (resize,
-        sigmoid, per-pixel argmax over queries, mask writes) stays on the device.  -> (panoptic_seg int32 [H,W], segments_info)"""
+    def panoptic_device(self, out, height, width, meta):
+        """_postprocess_panoptic (:921-998), Mask2Former-style merge of the kept queries' masks, WITHOUT a host round trip: fixed
+        shapes (all k panoptic queries, dropped ones masked), so it captures into a hipGraph.  The per-query scores are tensor-level
+        (k x K' values); the pixel work and the sequential walk over the queries are csrc/masks.hip `panoptic_*` (3 launches).
+        -> (panoptic_seg int32 [H, W], info int32 [k, 3] = (id, isthing, category_id) per segment, count int32 [1]), all on the device"""
         cfg = self.panoptic_configs
-        valid = out["pan_valid"]
-        mask_cls = out["pan_cls"][valid]
-        mask_pred = ops.bilinear_resize(out["pan_masks"], height, width)[valid]              # (:942) on the logits
-        scores, labels = mask_cls.sigmoid().max(-1)
-        mask_pred = mask_pred.sigmoid()
-        keep = scores > cfg["object_mask_threshold"]
+        mask_cls = out["pan_cls"].float()
+        sig = mask_cls.sigmoid()
+        scores, labels = sig.max(-1)
+        keep = out["pan_valid"] & (scores > cfg["object_mask_threshold"])                    # (:947)
         if cfg["transform_eval"]:
-            scores, labels = torch.softmax(mask_cls.sigmoid() / cfg["pano_temp"], dim=-1).max(-1)
-        cur_scores, cur_classes, cur_masks = scores[keep], labels[keep], mask_pred[keep]
-        panoptic_seg = torch.zeros((height, width), dtype=torch.int32, device=mask_pred.device)
-        segments_info = []
-        if cur_masks.shape[0] == 0:
-            return panoptic_seg, segments_info
-        cur_mask_ids = (cur_scores.view(-1, 1, 1) * cur_masks).argmax(0)
-        n = cur_classes.shape[0]
-        ids = torch.arange(n, device=cur_masks.device).view(-1, 1, 1)
-        own = cur_mask_ids[None] == ids                                                     # [n, H, W]
-        conf = cur_masks >= cfg["prob"]
-        mask_area = own.flatten(1).sum(1).tolist()                                          # one read-back for all segments
-        original_area = conf.flatten(1).sum(1).tolist()
-        both = own & conf
-        both_area = both.flatten(1).sum(1).tolist()
-        classes = cur_classes.tolist()
-        thing_ids = set((meta.get("thing_dataset_id_to_contiguous_id") or {}).values())
+            scores, labels = torch.softmax(sig / cfg["pano_temp"], dim=-1).max(-1)            # (:948-949)
+        key = ("pan_isthing", mask_cls.shape[1], mask_cls.device)
+        cache = meta.setdefault("_ape_amd_cache", {}) if isinstance(meta, dict) else {}
+        if key not in cache:
+            thing = torch.zeros(mask_cls.shape[1], dtype=torch.bool)
+            ids = [i for i in (meta.get("thing_dataset_id_to_contiguous_id") or {}).values() if 0 <= i < thing.numel()]
+            thing[ids] = True
+            cache[key] = thing.to(mask_cls.device)
         things_first = (meta.get("stuff_classes") or [""])[0] == "things"
-        current_segment_id, stuff_memory = 0, {}
-        for k in range(n):
-            pred_class = int(classes[k])
-            isthing = pred_class in thing_ids
-            if mask_area[k] > 0 and original_area[k] > 0 and both_area[k] > 0:
-                if mask_area[k] / original_area[k] < cfg["overlap_threshold"]:
-                    continue
-                if not isthing:
-                    if pred_class in stuff_memory:
-                        panoptic_seg[both[k]] = stuff_memory[pred_class]
-                        continue
-                    stuff_memory[pred_class] = current_segment_id + 1
-                current_segment_id += 1
-                panoptic_seg[both[k]] = current_segment_id
-                if not isthing and things_first:
-                    pred_class = pred_class - len(meta["thing_classes"]) + 1
-                segments_info.append({"id": current_segment_id, "isthing": bool(isthing), "category_id": int(pred_class)})
-        return panoptic_seg, segments_info
+        return ops.panoptic_merge(out["pan_masks"], scores.contiguous(), keep, labels, cache[key], height, width, prob=cfg["prob"],
+                                  overlap_threshold=cfg["overlap_threshold"],
+                                  stuff_offset=len(meta["thing_classes"]) if things_first else -1)
+
+    @staticmethod
+    def segments_info(info, count):
+        """host view of the device table: [{"id", "isthing", "category_id"}] like the reference's list"""
+        n = int(count.reshape(-1)[0])
+        rows = info[:n].tolist()
+        return [{"id": int(r[0]), "isthing": bool(r[1]), "category_id": int(r[2])} for r in rows]
+
+    def postprocess_panoptic(self, out, height, width, meta):
+        """-> (panoptic_seg int32 [H, W] on the device, segments_info list): the reference's return value; one read-back of the
+        segment table at the end"""
+        seg, info, count = self.panoptic_device(out, height, width, meta)
+        return seg, self.segments_info(info.cpu(), count.cpu())
 
     def postprocess_instance(self, out, image_size, height, width):
         """detector_postprocess (:857-872): rescale to (height, width), clip, drop empty boxes, paste masks; the

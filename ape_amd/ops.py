@@ -714,6 +714,36 @@ def bilinear_resize(x, height, width):
     return out
 
 
+def panoptic_merge(masks, scores, keep, classes, isthing, height, width, *, prob, overlap_threshold, stuff_offset=-1):
+    """_postprocess_panoptic (deformable_detr_segm_vl.py:921-998) without a host round trip: masks [k, h, w] fp32 mask logits at the
+    input resolution (rows contiguous), scores [k] fp32, keep [k] bool, classes [k] (any int type), isthing [num_classes] bool ->
+    (panoptic_seg int32 [height, width], info int32 [k, 3] = (id, isthing, category_id) per segment, count int32 [1]); stuff_offset >= 0
+    remaps a stuff segment's category to class - stuff_offset + 1 (:985-986)."""
+    _dev(masks, scores, keep, classes, isthing)
+    if masks.dtype != torch.float32 or masks.dim() != 3 or masks.stride(2) != 1 or scores.dtype != torch.float32:
+        raise ValueError("ape_amd.ops.panoptic_merge: masks must be float32 [k, h, w] with contiguous rows, scores float32")
+    k, h, w = masks.shape
+    dev = masks.device
+    scores = scores.contiguous()
+    keep8 = keep.to(torch.uint8).contiguous()
+    cls32 = classes.to(torch.int32).contiguous()
+    thing8 = isthing.to(torch.uint8).contiguous()
+    owner = torch.empty((height, width), dtype=torch.int16, device=dev)
+    conf = torch.empty((height, width), dtype=torch.uint8, device=dev)
+    areas = torch.empty((k, 3), dtype=torch.int32, device=dev)
+    seg_id = torch.empty((k,), dtype=torch.int32, device=dev)
+    info = torch.empty((k, 3), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    out = torch.empty((height, width), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.ape_hip_panoptic_pixels(_p(masks), masks.stride(0), masks.stride(1), h, w, k, _p(scores), _p(keep8), float(prob), height, width,
+                                           _p(owner), _p(conf), _p(areas), _stream()), "ape_hip_panoptic_pixels")
+    _lib.check(lib.ape_hip_panoptic_decide(_p(areas), _p(cls32), _p(keep8), k, _p(thing8), thing8.numel(), float(overlap_threshold), int(stuff_offset),
+                                           _p(seg_id), _p(info), _p(count), _stream()), "ape_hip_panoptic_decide")
+    _lib.check(lib.ape_hip_panoptic_write(_p(owner), _p(conf), _p(seg_id), height, width, _p(out), _stream()), "ape_hip_panoptic_write")
+    return out, info, count
+
+
 def box_refine(delta, ref, vr4, eps=1e-3):
     """Decoder box refinement: new_ref = sigmoid(delta + inverse_sigmoid(ref, eps)) (delta None -> new_ref = ref) and the
     per-level MSDA reference ref_in[q, l, :] = new_ref[q, :] * vr4[l, :].  fp32 [Q,4] / [L,4] -> ([Q,4], [Q,L,4])."""

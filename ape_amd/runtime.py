@@ -59,12 +59,14 @@ def retired_graphs():
 
 class _Ticket:
     """handle of a submitted step (weak-referenceable, unlike SimpleNamespace)"""
-    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "runs", "mask_runs", "sem_labels", "__weakref__")
+    __slots__ = ("entry", "slot", "ready", "single", "rec6", "records", "frames", "model_hw", "runs", "mask_runs", "sem_labels", "panoptic", "__weakref__")
 
-    def __init__(self, entry, single, frames):
+    def __init__(self, entry, single, frames, model_hw=None):
         self.entry, self.single, self.frames = entry, single, frames      # frames: [(height, width)] of the output masks
+        self.model_hw = model_hw                      # [(h, w)] of the model inputs (any_size: where each image's valid region ends)
         self.slot, self.ready, self.rec6, self.records = None, False, None, None
         self.sem_labels = None                        # GraphedForward(semantic=...): per-image label maps [fh, fw] int16 (host)
+        self.panoptic = None                          # GraphedForward(panoptic=...): per-image (panoptic_seg int32 [fh, fw], segments_info)
         self.runs, self.mask_runs = None, None        # mask_format="rle": (device run lengths [B,k,cap], run counts [B,k]); all ranks'
 
 
@@ -73,7 +75,7 @@ class GraphedForward:
     SLOTS = 2
 
     def __init__(self, model_vision, use_graph=True, max_graphs=16, with_masks=True, images_per_step=1, batch_vit=True,
-                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096, semantic=None,
+                 pipeline=False, any_size=False, max_out_pixels=None, mask_format="bitmask", rle_cap=4096, semantic=None, panoptic=None,
                  input_resize=(1024, 1024), input_format="RGB"):
         self.mv = model_vision
         # uint8 inputs (the predictor's contract, ape/engine/defaults.py:213-222: the ORIGINAL BGR image): submit() takes uint8
@@ -99,10 +101,16 @@ class GraphedForward:
         # semantic branch inside the captured step (deformable_detr_segm_vl.py:628-666 + sem_seg_postprocess :875-918): `semantic`
         # = the dataset's metadata dict (thing_classes / stuff_classes / entity, as model.forward builds it).  The [K', H, W] score
         # volume stays on the device (1.3 GB per 1536^2 image with 134 classes); what leaves is its per-pixel argmax -- the
-        # label map every semantic evaluator reduces the scores to -- as int16 [H, W] (`ticket.sem_labels`).  Per-size graphs only.
+        # label map every semantic evaluator reduces the scores to -- as int16 [H, W] (`ticket.sem_labels`).  With any_size the
+        # captured step produces the class scores over the whole S x S pad (fixed shape); the crop to the image's own (h, w), the
+        # resize to its output frame and the argmax run behind the replay with the ticket's sizes, like the mask paste does.
         self.semantic = semantic
-        if semantic is not None and self.any_size:
-            raise NotImplementedError("GraphedForward: the semantic branch needs per-size graphs (any_size=False)")
+        # panoptic branch inside the captured step (:671-690 + _postprocess_panoptic :921-998): `panoptic` = the evaluation dataset's
+        # metadata dict (thing_classes, stuff_classes, thing_dataset_id_to_contiguous_id).  The merge runs on the device without a host
+        # round trip (csrc/masks.hip panoptic_*), so it is part of the graph; `ticket.panoptic` = [(panoptic_seg, segments_info)].
+        self.panoptic = panoptic
+        if panoptic is not None and self.any_size:
+            raise NotImplementedError("GraphedForward: the panoptic branch needs per-size graphs (any_size=False)")
         # pipelined steps: start the ViT branch behind the tails' encoders (see _run_entry); APE_PIPE_LATE_VIT=0|1 overrides
         self.late_vit = os.environ.get("APE_PIPE_LATE_VIT", "0") == "1"
         self._graphs = {}
@@ -143,15 +151,12 @@ class GraphedForward:
         from . import ops
         mv = self.mv
         out = mv.forward_single(image, text, with_masks=self.with_masks, prompt=prompt, vit_feat=vit_feat, geo=geo,
-                                encoder_done=encoder_done, semantic=self.semantic)
+                                encoder_done=encoder_done, semantic=self.semantic, panoptic=self.panoptic is not None)
         labels = None
         if self.semantic is not None:
-            r = ops.bilinear_resize(out["sem_seg"], height, width)                           # sem_seg_postprocess (:916)
-            meta = self.semantic
-            if (mv.eval_dataset_id >= 0 and meta.get("entity") == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
-                    and mv.stuff_prob_thing > 0):                                            # (:654-663)
-                r[0] = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
-            labels = r.argmax(0).to(torch.int16).contiguous()                                # [height, width]
+            # any_size: (height, width) = the pad; the scores stay [K', S, S] here and become labels in _replay (ticket sizes)
+            labels = out["sem_seg"] if self.any_size else self._sem_labels(out["sem_seg"], height, width)
+        pan = mv.panoptic_device(out, height, width, self.panoptic) if self.panoptic is not None else None
         # boxes in the output frame, keep flags, records with the kept detections first (stable) -- the host then takes PREFIX
         # views of the pinned buffers instead of gathering ~1 MB per mask with a boolean index; dropped rows (empty slots, empty
         # boxes after the rescale) carry score -1, so the 6-column view that is all-gathered across ranks tells kept from dropped
@@ -161,7 +166,19 @@ class GraphedForward:
         if masks128 is not None:
             n = masks128.shape[0]
             masks128 = ops.gather_rows(masks128.view(n, -1).view(torch.float32), order).view(torch.uint8).view(masks128.shape)
-        return rec, masks128, boxes, labels
+        return rec, masks128, boxes, labels, pan
+
+    def _sem_labels(self, sem, height, width):
+        """sem_seg_postprocess (:875-918) on the class scores [K', h, w] of the image's own region -> int16 labels [height, width]"""
+        import math
+        from . import ops
+        mv = self.mv
+        r = ops.bilinear_resize(sem, height, width)                                          # (:916)
+        meta = self.semantic
+        if (mv.eval_dataset_id >= 0 and meta.get("entity") == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
+                and mv.stuff_prob_thing > 0):                                                # (:654-663)
+            r[0] = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
+        return r.argmax(0).to(torch.int16).contiguous()
 
     def _tail(self, e, b, vit_feat, encoder_done=None):
         height, width = e.size
@@ -332,6 +349,9 @@ class GraphedForward:
         e.k = k
         e.maxpix = (self.max_out_pixels or e.size[0] * e.size[1]) if self.any_size else height * width
         e.slots = []
+        # rows of the panoptic segment table = the step's panoptic queries (the class-wise NMS keeps test_topk_per_image of them;
+        # all queries without panoptic_post_nms)
+        pq = (k if mv.panoptic_post_nms else mv.num_queries) if self.panoptic is not None else 0
         for _ in range(self.SLOTS):
             s = SimpleNamespace()
             s.d_rec = torch.empty((B, k, 8), dtype=torch.float32, device=dev)
@@ -345,6 +365,11 @@ class GraphedForward:
             s.h_nruns = torch.zeros((B, k), dtype=torch.int32, pin_memory=True) if rle else None
             s.d_sem = torch.empty((B, e.maxpix), dtype=torch.int16, device=dev) if self.semantic is not None else None
             s.h_sem = torch.empty((B, e.maxpix), dtype=torch.int16, pin_memory=True) if self.semantic is not None else None
+            # panoptic: the map + the segment table of the step's panoptic queries (one extra row carries the segment count)
+            s.d_pan = torch.empty((B, e.maxpix), dtype=torch.int32, device=dev) if self.panoptic is not None else None
+            s.h_pan = torch.empty((B, e.maxpix), dtype=torch.int32, pin_memory=True) if self.panoptic is not None else None
+            s.d_paninfo = torch.zeros((B, pq + 1, 3), dtype=torch.int32, device=dev) if self.panoptic is not None else None
+            s.h_paninfo = torch.zeros((B, pq + 1, 3), dtype=torch.int32, pin_memory=True) if self.panoptic is not None else None
             s.computed, s.copied = torch.cuda.Event(), torch.cuda.Event()
             s.busy = False
             e.slots.append(s)
@@ -392,7 +417,7 @@ class GraphedForward:
             self._copy_stream = torch.cuda.Stream(device=next(self.mv.parameters()).device)
         if any(f[0] * f[1] > e.maxpix for f in frames):
             raise ValueError(f"GraphedForward.submit: output frame larger than max_out_pixels={e.maxpix}")
-        t = _Ticket(e, single, frames)
+        t = _Ticket(e, single, frames, mhw)
         if not self.pipeline:
             self._replay(e, images, frames, completes=t)
             return t
@@ -437,10 +462,17 @@ class GraphedForward:
             cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
             has_masks = s.d_masks is not None and outs[0][1] is not None
             k = e.k
-            for b, (rec, masks128, boxes, labels) in enumerate(outs):
+            for b, (rec, masks128, boxes, labels, pan) in enumerate(outs):
                 s.d_rec[b].copy_(rec, non_blocking=True)
                 if labels is not None:
+                    if self.any_size:           # class scores over the pad -> this image's region -> its output frame
+                        mh, mw = completes.model_hw[b]
+                        labels = self._sem_labels(labels[:, :mh, :mw], *completes.frames[b])
                     s.d_sem[b, : labels.numel()].copy_(labels.reshape(-1), non_blocking=True)
+                if pan is not None:
+                    s.d_pan[b, : pan[0].numel()].copy_(pan[0].reshape(-1), non_blocking=True)
+                    s.d_paninfo[b, : pan[1].shape[0]].copy_(pan[1], non_blocking=True)
+                    s.d_paninfo[b, -1, 0:1].copy_(pan[2], non_blocking=True)        # last row, column 0: the segment count
                 if has_masks:
                     fh, fw = completes.frames[b]
                     pasted = ops.paste_bits(masks128, boxes, fh, fw, out=s.d_masks[b, : k * fh * fw].view(k, fh, fw))   # detector_postprocess (:869-871)
@@ -452,6 +484,9 @@ class GraphedForward:
                 s.h_rec.copy_(s.d_rec, non_blocking=True)
                 if s.d_sem is not None:
                     s.h_sem.copy_(s.d_sem, non_blocking=True)
+                if s.d_pan is not None:
+                    s.h_pan.copy_(s.d_pan, non_blocking=True)
+                    s.h_paninfo.copy_(s.d_paninfo, non_blocking=True)
                 if has_masks and s.d_runs is not None:
                     s.h_runs.copy_(s.d_runs, non_blocking=True)
                     s.h_nruns.copy_(s.d_nruns, non_blocking=True)
@@ -513,6 +548,9 @@ class GraphedForward:
                                         query_index=hr[:n, 6].long(), **extra))
         if s.h_sem is not None:       # label maps (views of the slot's pinned buffer, valid like pred_masks)
             ticket.sem_labels = [s.h_sem[b, : fh * fw].view(fh, fw) for b, (fh, fw) in enumerate(ticket.frames)]
+        if s.h_pan is not None:       # (panoptic_seg view of the slot's pinned buffer, segments_info) per image
+            ticket.panoptic = [(s.h_pan[b, : fh * fw].view(fh, fw), self.mv.segments_info(s.h_paninfo[b, :-1], s.h_paninfo[b, -1, 0:1]))
+                               for b, (fh, fw) in enumerate(ticket.frames)]
         if ticket.single:
             return insts[0], ticket.rec6
         return insts, ticket.rec6

@@ -319,6 +319,24 @@ int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_row, int h, 
                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Panoptic merge on the device (_postprocess_panoptic, deformable_detr_segm_vl.py:921-998) -- csrc/masks.hip.  No host round trip
+ * (the reference reads three `.item()`s per kept query), so the merge can sit inside a captured step.
+ *   panoptic_pixels: masks [k, h, w] fp32 mask LOGITS at the input resolution (query / row strides given), scores [k], keep [k] ->
+ *                    per pixel of the H x W output frame: owner = first argmax over the kept queries of score_q * sigmoid(
+ *                    bilinear(masks_q)) (int16, -1 = no kept query), conf = that probability >= prob; areas [k, 3] = (pixels owned,
+ *                    pixels with p_q >= prob, both) -- zeroed by the call
+ *   panoptic_decide: the sequential walk over the queries (:963-995): areas, classes [k], keep [k], isthing [num_classes] ->
+ *                    seg_id [k] (0 = dropped), info [k, 3] = (id, isthing, category_id) for the first *count segments; stuff_offset
+ *                    >= 0: category_id of a stuff segment = class - stuff_offset + 1 (the "things"-first stuff vocabulary, :985-986)
+ *   panoptic_write : panoptic_seg [H, W] int32 = seg_id[owner] where conf, else 0
+ * ------------------------------------------------------------------------------------------- */
+int ape_hip_panoptic_pixels(const float* masks, int ld_query, int ld_row, int h, int w, int k, const float* scores, const uint8_t* keep,
+                            float prob, int H, int W, int16_t* owner, uint8_t* conf, int* areas, void* stream);
+int ape_hip_panoptic_decide(const int* areas, const int* classes, const uint8_t* keep, int k, const uint8_t* isthing, int num_classes,
+                            double overlap_threshold, int stuff_offset, int* seg_id, int* info, int* count, void* stream);
+int ape_hip_panoptic_write(const int16_t* owner, const uint8_t* conf, const int* seg_id, int H, int W, int* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Decoder box refinement (deformable_transformer_vl.py:203-210, 232-246):
  * new_ref = sigmoid(delta + inverse_sigmoid(ref, eps)), ref_in[q, l, :] = new_ref[q, :] * vr4[l, :].
  * delta may be NULL (new_ref = ref).  -- csrc/boxes.hip

@@ -599,3 +599,39 @@ def ffn_fused(x, w1, b1, w2, b2, residual=None, out=None, w2_permuted=False, nor
         out.copy_(y)
         return out
     return y
+
+
+def panoptic_merge(masks, scores, keep, classes, isthing, height, width, *, prob, overlap_threshold, stuff_offset=-1):
+    """the reference's loop (deformable_detr_segm_vl.py:921-998) on fixed-size inputs: kept queries in index order"""
+    k = masks.shape[0]
+    dev = masks.device
+    pr = bilinear_resize(masks, height, width).sigmoid()
+    keep = keep.bool()
+    panoptic_seg = torch.zeros((height, width), dtype=torch.int32, device=dev)
+    info = torch.zeros((k, 3), dtype=torch.int32, device=dev)
+    n = 0
+    idx = torch.nonzero(keep).flatten().tolist()
+    if idx:
+        cur_masks = pr[idx]
+        cur_mask_ids = (scores[idx].view(-1, 1, 1) * cur_masks).argmax(0)
+        cur, stuff_memory = 0, {}
+        for j, q in enumerate(idx):
+            c = int(classes[q])
+            thing = bool(isthing[c])
+            own = cur_mask_ids == j
+            conf = cur_masks[j] >= prob
+            ma, oa = int(own.sum()), int(conf.sum())
+            both = own & conf
+            if ma > 0 and oa > 0 and int(both.sum()) > 0:
+                if ma / oa < overlap_threshold:
+                    continue
+                if not thing:
+                    if c in stuff_memory:
+                        panoptic_seg[both] = stuff_memory[c]
+                        continue
+                    stuff_memory[c] = cur + 1
+                cur += 1
+                panoptic_seg[both] = cur
+                info[n] = torch.tensor([cur, int(thing), c - stuff_offset + 1 if (not thing and stuff_offset >= 0) else c], dtype=torch.int32)
+                n += 1
+    return panoptic_seg, info, torch.tensor([n], dtype=torch.int32, device=dev)

@@ -168,6 +168,52 @@ def test_semantic_branch_in_graph_runtime():
         assert frac >= 0.99
 
 
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_semantic_branch_in_the_size_agnostic_graph(pipeline):
+    """GraphedForward(semantic=meta, any_size=True): ONE graph serves images of different sizes (also inside one step); the class
+    scores are captured over the whole pad, the crop to each image's region / resize to its frame / argmax run behind the replay with
+    the ticket's sizes -- label maps equal those of model.forward() on the same image (sem_seg_postprocess, :875-918)"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_semantic", torch.float32)
+    mv = model.model_vision
+    meta = gold["semantic_meta"]
+    mv.semantic_on = True
+    mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
+    sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    g = torch.Generator().manual_seed(11)
+    sizes = [tuple(image.shape[-2:]), (256, 256), (128, 240), (176, 208)]
+    imgs = [image] + [torch.randint(0, 256, (3, h, w), generator=g).float().cuda() for h, w in sizes[1:]]
+    frames = [(h + h // 2, w + 8) for h, w in sizes]
+    ref = []
+    for im, (fh, fw) in zip(imgs, frames):
+        res = model([{"image": im, "height": fh, "width": fw, "text_features": text}])[0]
+        ref.append((res["sem_seg"].argmax(0).cpu(), res["instances"]))
+    run = GraphedForward(mv, semantic=sem_meta, images_per_step=2, pipeline=pipeline, any_size=True, max_out_pixels=400 * 272)
+    labels, insts, queue = [], [], []
+
+    def take(t):
+        inst, _ = run.result(t)
+        insts.extend(_own(inst))
+        labels.extend(lab.clone() for lab in t.sem_labels)
+
+    for rnd_ in range(2):                                                # second round replays the captured graph
+        for i in range(0, len(imgs), 2):
+            queue.append(run.submit(imgs[i:i + 2], text, [f[0] for f in frames[i:i + 2]], [f[1] for f in frames[i:i + 2]]))
+            if len(queue) > (2 if pipeline else 1):
+                take(queue.pop(0))
+    while queue:
+        take(queue.pop(0))
+    assert len(run._graphs) == 1 and len(labels) == 2 * len(imgs)
+    for i, lab in enumerate(labels):
+        want, rinst = ref[i % len(imgs)]
+        assert lab.shape == want.shape and lab.dtype == torch.int16, (i, lab.shape, want.shape)
+        agree = (lab.long() == want).float().mean().item()
+        assert agree > 0.999, (i, agree)
+        frac = U.match_detections(insts[i].pred_boxes, insts[i].scores, insts[i].pred_classes, rinst.pred_boxes, rinst.scores, rinst.pred_classes)
+        assert frac >= 0.99, (i, frac)
+
+
 def test_parallel_images_in_one_graph():
     """images_per_step = 2: two batch-1 forwards as parallel branches of one hipGraph give the same detections and masks
     as two sequential single-image replays"""
@@ -328,6 +374,33 @@ def test_eval_dataset_panoptic_on_gpu():
     """evaluation-dataset mode + panoptic merge with the fp32 HIP kernels"""
     model, orc, image, text, gold, image_c, text_c = _run("tiny_panoptic", torch.float32)
     M.check_panoptic(model, orc, image_c, text_c, gold, "cuda")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(images_per_step=2, pipeline=True)], ids=["plain", "pipelined2"])
+def test_panoptic_merge_in_graph_runtime(kw):
+    """GraphedForward(panoptic=meta): the panoptic branch AND its merge (csrc/masks.hip panoptic_*: no host round trip) captured
+    with the step; `ticket.panoptic` = (panoptic_seg, segments_info) equal to model.forward()'s, which check_panoptic holds against
+    the reference-generated fixture"""
+    from ape_amd.runtime import GraphedForward
+
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_panoptic", torch.float32)
+    M.check_panoptic(model, orc, image_c, text_c, gold, "cuda")          # evaluation-dataset mode on; forward() vs the reference fixture
+    mv = model.model_vision
+    H, W = gold["out_hw"]
+    res = model([{"image": image_c, "height": H, "width": W}])[0]
+    seg_ref, info_ref = res["panoptic_seg"]
+    feats, _, prompt = mv.text_features({"image": image_c, "height": H, "width": W})
+    run = GraphedForward(mv, panoptic=mv.metadata_list[0], **kw)
+    B = kw.get("images_per_step", 1)
+    tickets = [run.submit([image_c] * B if B > 1 else image_c, feats, H, W, prompt) for _ in range(2)]      # second submit replays the graph
+    for t in tickets:
+        run.result(t)
+        assert len(t.panoptic) == B
+        for seg, info in t.panoptic:
+            assert seg.shape == (H, W) and seg.dtype == torch.int32
+            assert torch.equal(seg, seg_ref.cpu()) and info == info_ref, (len(info), len(info_ref))
+    with pytest.raises(NotImplementedError):
+        GraphedForward(mv, panoptic=mv.metadata_list[0], any_size=True)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1027,3 +1027,31 @@ def test_ffn_fused(ops, M, HID, bf):
             assert torch.equal(ops.ffn_fused(x, w1, b1, w2p, b2, residual=res, w2_permuted=True, norm=(lw, lb, 1e-5)), gotn), rt
         finally:
             os.environ.pop("APE_FFN_RT")
+
+
+@pytest.mark.parametrize("k,h,w,H,W,nthing,offset", [(40, 96, 128, 150, 200, 5, -1), (100, 64, 64, 64, 64, 3, 3), (7, 50, 70, 33, 91, 0, 0)])
+def test_panoptic_merge(ops, k, h, w, H, W, nthing, offset):
+    """csrc/masks.hip panoptic_* (pixel ownership + areas, the sequential walk, the map) vs the reference's loop
+    (deformable_detr_segm_vl.py:921-998) restated in tests/ref_ops.py"""
+    g = torch.Generator().manual_seed(k)
+    K = 12
+    # smooth blobs: low-resolution noise upsampled, so owners form regions and several queries overlap
+    low = torch.randn(k, 6, 8, generator=g) * 4.0
+    masks_full = torch.nn.functional.interpolate(low[None], size=(h + 5, w + 3), mode="bilinear", align_corners=False)[0].to(DEV).contiguous()
+    masks = masks_full[:, :h, :w]                                       # a cropped view: row / query strides differ from the shape
+    scores = torch.rand(k, generator=g).to(DEV)
+    keep = (torch.rand(k, generator=g) > 0.3).to(DEV)
+    classes = torch.randint(0, K, (k,), generator=g).to(DEV)
+    isthing = (torch.arange(K) < nthing).to(DEV)
+    kw = dict(prob=0.5, overlap_threshold=0.4, stuff_offset=offset)
+    seg, info, count = ops.panoptic_merge(masks, scores, keep, classes, isthing, H, W, **kw)
+    wseg, winfo, wcount = ref_ops.panoptic_merge(masks, scores, keep, classes, isthing, H, W, **kw)
+    n, wn = int(count.item()), int(wcount.item())
+    agree = (seg == wseg).float().mean().item()
+    print(f"panoptic_merge k{k} {h}x{w} -> {H}x{W}: {n} segments (definition {wn}), pixel agreement {agree:.5f}")
+    assert seg.dtype == torch.int32 and tuple(seg.shape) == (H, W)
+    assert n == wn and torch.equal(info[:n].cpu(), winfo[:wn].cpu())
+    assert agree > 0.999                                                # sigmoid / bilinear rounding at a threshold pixel
+    none = torch.zeros_like(keep)
+    seg, info, count = ops.panoptic_merge(masks, scores, none, classes, isthing, H, W, **kw)
+    assert int(count.item()) == 0 and int(seg.abs().sum().item()) == 0
