@@ -6,7 +6,7 @@ TAG=${1:-final_r4}
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/$TAG
 mkdir -p $O
-if [ "$2" != "slim" ]; then
+if [ "$2" != "slim" ] && [ "$2" != "nosuite" ]; then
 APE_WRITE_PINS=$O timeout 1700 python -m pytest tests -q -m gpu -s 2>&1 | grep -v Warning > $O/pytest_gpu.log; tail -6 $O/pytest_gpu.log | cut -c1-300
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 | tee $O/smoke.log
 fi
@@ -21,6 +21,8 @@ b 1536_semantic --size L_D_1536 --semantic --steps 30
 b one_image_per_step --images-per-step 1
 b L_A --size L_A
 b E_D --size E_D --steps 20 --warmup 3
+b V_A --size V_A --steps 20 --warmup 3
+b V_A_1536 --size V_A_1536 --steps 10 --warmup 2
 if [ "$2" != "slim" ]; then
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_torchrun_n1.json; cut -c1-160 $O/bench_torchrun_n1.json
 fi
