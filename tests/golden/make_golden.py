@@ -60,6 +60,9 @@ CASES = {
     "L_D_jpeg": ("L_D_coco", 0, "jpeg:Pisa.jpg", (576, 1024), 80, 3),
     # f4: APE on ViT-e at FULL size (64 post-norm blocks x 1792, 9 + 9 layers: ape_deta_vite_eva02_clip_vlf_lsj1024_cp_16x4_1080k_mdl_fsdp.py)
     "E_D_coco80": ("E_D", 0, 2, (1024, 1024), 80, 3),
+    # f4c at FULL size: APE on the EVA-01 MIM ViT-g of vit_eva.py (40 pre-norm blocks x 1408, 16 x 16 windows, every fourth block global
+    # over 4096 tokens with decomposed relative positions; plain family, 6 + 6 layers)
+    "V_A_coco80": ("V_A", 0, 2, (1024, 1024), 80, 3),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }

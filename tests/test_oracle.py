@@ -187,3 +187,39 @@ def test_transformer_reference_signature_matches_live_reference(fake_ops, case):
         e = U.relerr(got[fin], ref[fin])
         print(f"transformer.forward {name}: {e:.2e}")
         assert e < 1e-3, (name, e)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="needs /root/reference")
+def test_rel_pos_tables_match_the_live_reference():
+    """get_rel_pos "vitdet" (utils_eva.py:65-129), also when the checkpoint's table has another length (linear resize): the oracle's
+    restatement and the host packing's `resized_rel_pos` (row (q - k) + size - 1 = offset q - k) against the reference's function, and
+    add_decomposed_rel_pos (:132-161) against the extra-channel formulation of ape_amd/modeling/backbone/vit_eva.py on one head"""
+    import importlib
+
+    from ape_amd.modeling.backbone import vit_eva
+    from oracle.ape_oracle import ApeOracle
+    refshim.install()
+    R = importlib.import_module("ape.modeling.backbone.utils_eva")
+    g = torch.Generator().manual_seed(0)
+    for size, rows in ((16, 31), (16, 27), (32, 63), (32, 127), (12, 31)):
+        tbl = torch.randn(rows, 24, generator=g)
+        want = R.get_rel_pos(size, size, tbl, "vitdet")                         # [size, size, C]
+        got_o = ApeOracle.rel_pos_table(size, size, tbl)
+        rs = vit_eva.resized_rel_pos(tbl, size)
+        idx = (torch.arange(size)[:, None] - torch.arange(size)[None, :]) + size - 1
+        assert torch.allclose(got_o, want, atol=1e-6) and torch.allclose(rs[idx], want, atol=1e-6), (size, rows)
+    # one head, 8 x 8 tokens: scores with the reference's bias == q_ext . k_ext
+    H = W = 8
+    hd = 24
+    q, k = torch.randn(1, H * W, hd, generator=g), torch.randn(1, H * W, hd, generator=g)
+    rh, rw = torch.randn(2 * H - 1, hd, generator=g), torch.randn(2 * W - 1, hd, generator=g)
+    scale = hd ** -0.5
+    attn = (q * scale) @ k.transpose(-2, -1)
+    want = R.add_decomposed_rel_pos(attn.clone(), q, rh, rw, (H, W), (H, W), "vitdet")[0]
+    import ref_ops
+    t = (q[0] @ torch.cat([rh, rw], 0).t()).contiguous()                                  # [tokens, 2H-1 + 2W-1]
+    ty = (torch.arange(H * W) // W).int()
+    tx = (torch.arange(H * W) % W).int()
+    qe, ke = ref_ops.relpos_extend(q[0].contiguous(), k[0].contiguous(), t, ty, tx, heads=1, head_stride=hd, head_dim=hd, hk=H, wk=W,
+                                   ext_dim=vit_eva.ext_width(hd, H, W), scale=scale)
+    assert torch.allclose(qe @ ke.t(), want, atol=1e-5)

@@ -23,6 +23,7 @@ b L_A --size L_A
 b E_D --size E_D --steps 20 --warmup 3
 b V_A --size V_A --steps 20 --warmup 3
 b V_A_1536 --size V_A_1536 --steps 10 --warmup 2
+b G_A --size G_A --steps 10 --warmup 2
 if [ "$2" != "slim" ]; then
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 > $O/bench_torchrun_n1.json; cut -c1-160 $O/bench_torchrun_n1.json
 fi
