@@ -144,7 +144,7 @@ def main():
         if isinstance(CASES[case][2], str):
             with open(os.path.join("/root/reference/demo/examples", CASES[case][2][5:]), "rb") as fh:
                 gold["jpeg"] = torch.frombuffer(bytearray(fh.read()), dtype=torch.uint8).clone()
-        big = cfg.startswith("L_D") or cfg in ("Ti", "L_A", "E_D", "G_A")
+        big = cfg.startswith("L_D") or cfg in ("Ti", "L_A", "E_D", "G_A", "V_A", "V_A_1536")
         for k, v in S.items():
             if torch.is_tensor(v):
                 gold["stages"][k] = fingerprint(v)
