@@ -63,6 +63,9 @@ CASES = {
     # f4c at FULL size: APE on the EVA-01 MIM ViT-g of vit_eva.py (40 pre-norm blocks x 1408, 16 x 16 windows, every fourth block global
     # over 4096 tokens with decomposed relative positions; plain family, 6 + 6 layers)
     "V_A_coco80": ("V_A", 0, 2, (1024, 1024), 80, 3),
+    # f4b at FULL size: APE on the EVA-01-CLIP ViT-g (ape_deta_vitg_eva01_clip_lsj1536_cp_64x90k.py): 40 pre-norm blocks x 1408, 1536^2
+    # (9216 ViT tokens, 32 x 32 windows), plain family
+    "G_A_1536": ("G_A", 0, 2, (1536, 1536), 80, 3),
     # config 5: 1536x1536, semantic branch on (80 things + "things" + 53 stuff names -> 54 channels), top-500
     "L_D_1536_sseg": ("L_D_1536", 0, 2, (1536, 1536), 134, 3, "name", "semantic"),
 }
