@@ -593,12 +593,12 @@ class DeformableDETRSegmVL(nn.Module):
         keep = out["pan_valid"] & (scores > cfg["object_mask_threshold"])                    # (:947)
         if cfg["transform_eval"]:
             scores, labels = torch.softmax(sig / cfg["pano_temp"], dim=-1).max(-1)            # (:948-949)
-        key = ("pan_isthing", mask_cls.shape[1], mask_cls.device)
-        cache = meta.setdefault("_ape_amd_cache", {}) if isinstance(meta, dict) else {}
+        ids = tuple(sorted(i for i in (meta.get("thing_dataset_id_to_contiguous_id") or {}).values() if 0 <= i < mask_cls.shape[1]))
+        key = (ids, mask_cls.shape[1], mask_cls.device)
+        cache = self.__dict__.setdefault("_pan_thing_cache", {})          # per (thing ids, vocabulary width, device): built outside captures
         if key not in cache:
             thing = torch.zeros(mask_cls.shape[1], dtype=torch.bool)
-            ids = [i for i in (meta.get("thing_dataset_id_to_contiguous_id") or {}).values() if 0 <= i < thing.numel()]
-            thing[ids] = True
+            thing[list(ids)] = True
             cache[key] = thing.to(mask_cls.device)
         things_first = (meta.get("stuff_classes") or [""])[0] == "things"
         return ops.panoptic_merge(out["pan_masks"], scores.contiguous(), keep, labels, cache[key], height, width, prob=cfg["prob"],
