@@ -408,7 +408,8 @@ def test_panoptic_merge_in_graph_runtime(kw):
 # reference on the same seeded inputs (tests/golden/make_golden.py: L_D_coco80 = config 2, L_D_lvis1203 = config 3,
 # L_D_padded = a COCO-shaped image of config 4, L_D_1536_sseg = config 5; E_D_coco80 = APE on ViT-e at full size, 64 post-norm blocks
 # of width 1792 and a 9 + 9 layer DETA; V_A_coco80 = APE on the EVA-01 MIM ViT-g of vit_eva.py at full size: 40 pre-norm blocks of width
-# 1408 with decomposed relative positions, plain family).  No oracle run here: fixtures only.
+# 1408 with decomposed relative positions, plain family; G_A_1536 = APE on the EVA-01-CLIP ViT-g at its own 1536^2).  No oracle run here:
+# fixtures only.
 # ------------------------------------------------------------------------------------------------------------------
 LD_STAGES = ("p2", "p4", "p6", "enc0_fused_v", "enc0_out", "memory", "output_memory", "enc_class", "enc_coord_unact",
              "mask_features")
@@ -440,7 +441,7 @@ def _ld_mask_sign_mismatch(stages, out, gold):
     return bad / max((~tie).float().sum().item(), 1.0), len(rows)
 
 
-@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "V_A_coco80"])
+@pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "V_A_coco80", "G_A_1536"])
 def test_L_D_fp32_matches_reference(case):
     """T1 at the benchmarked sizes: fp32 HIP kernels vs the reference run; north_star tolerance 1e-3 on logits / boxes,
     identical argmax masks"""
@@ -580,7 +581,7 @@ def test_E_D_full_size_fp32_vs_reference_through_the_chaotic_stack():
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "V_A_coco80"])
+@pytest.mark.parametrize("case", ["L_D_coco80", "L_D_lvis1203", "L_D_padded", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "V_A_coco80", "G_A_1536"])
 def test_L_D_bf16_pipeline(case, dt):
     tag = "bf16" if dt == torch.bfloat16 else "f16"
     model, image, text, gold = M.build_model(case, DEV, dt)

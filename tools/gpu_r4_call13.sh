@@ -3,6 +3,6 @@
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 O=gpurun_out/call13
 mkdir -p $O
-APE_WRITE_PINS=$O APE_TEST_ALL_F16=1 timeout 900 python -m pytest tests/test_model_gpu.py -q -m gpu -s -k "V_A_coco80" 2>&1 | grep -v Warning > $O/pytest.log; tail -4 $O/pytest.log | cut -c1-300
-grep -n "V_A_coco80\]" $O/pytest.log | cut -c1-400 | head -40
-timeout 400 python bench.py --no-cpu-baseline --size G_A --steps 10 --warmup 2 2>&1 | tail -1 > $O/bench_G_A.json; cut -c1-300 $O/bench_G_A.json
+APE_WRITE_PINS=$O APE_TEST_ALL_F16=1 timeout 900 python -m pytest tests/test_model_gpu.py -q -m gpu -s -k "G_A_1536" 2>&1 | grep -v Warning > $O/pytest.log; tail -4 $O/pytest.log | cut -c1-300
+grep -n "G_A_1536\]" $O/pytest.log | cut -c1-400 | head -40
+
