@@ -19,6 +19,7 @@ TARGETS = [
                                "DeformableDetrTransformerVL", "SomeThing"]),
     ("ape.modeling.backbone.vit_eva_clip", ["SimpleFeaturePyramid", "ViT"]),
     ("ape.modeling.backbone.vit_eva02", ["SimpleFeaturePyramid", "ViT"]),
+    ("ape.modeling.backbone.vit_eva", ["SimpleFeaturePyramid", "ViT"]),
     ("ape.engine.defaults", ["DefaultPredictor"]),
     ("ape.modeling.text", ["EVA02CLIP"]),
     ("ape.checkpoint", ["DetectionCheckpointer"]),

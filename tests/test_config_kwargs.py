@@ -20,6 +20,9 @@ CHAINS = {
            "LVISCOCOCOCOSTUFF_O365_OID_VGR_SA1B_REFCOCO_GQA_PhraseCut_Flickr30k/ape_deta/ape_deta_vitt_eva02_vlf_lsj1024_cp_16x4_1080k.py",
            "common/backbone/vitt_eva02.py"],
     "L_A": ["common/backbone/vitl_eva02.py"],
+    # f4b / f4c: the ViT-g / ViT-e backbone configurations (EVA-01-CLIP ViT-g, ViT-e: vit_eva_clip classes; EVA-01 MIM ViT-g: vit_eva.py)
+    "G_A": ["common/backbone/vitg_eva01_clip_1024.py", "common/backbone/vitg_eva01_clip_1536.py", "common/backbone/vite_eva02_clip_1024.py"],
+    "V_A": ["common/backbone/vitg_eva01.py", "common/backbone/vitg_eva01_1536.py"],
 }
 # config class name -> (our class, attribute path whose later assignments also count)
 pytestmark = pytest.mark.skipif(not os.path.isdir(CFG), reason="needs the reference checkout")
@@ -50,16 +53,16 @@ def _accepts(cls):
     return set(sig.parameters) - {"self"}
 
 
-@pytest.mark.parametrize("chain", ["L_D", "Ti", "L_A"])
+@pytest.mark.parametrize("chain", ["L_D", "Ti", "L_A", "G_A", "V_A"])
 def test_every_config_keyword_is_accepted(chain):
     from ape_amd.layers import VisionLanguageFusion
     from ape_amd.modeling.ape_deta import (DeformableDETRSegmVL, DeformableDetrTransformerDecoderVL, DeformableDetrTransformerEncoderVL,
                                            DeformableDetrTransformerVL)
-    from ape_amd.modeling.backbone import vit_eva02, vit_eva_clip
+    from ape_amd.modeling.backbone import vit_eva, vit_eva02, vit_eva_clip
     from ape_amd.modeling.text import EVA02CLIP
 
     calls, assigns = _collect(CHAINS[chain])
-    vit_mod = vit_eva_clip if chain == "L_D" else vit_eva02
+    vit_mod = vit_eva_clip if chain in ("L_D", "G_A") else vit_eva if chain == "V_A" else vit_eva02
     table = [
         (("DeformableDETRSegm", "DeformableDETRSegmVL"), "", DeformableDETRSegmVL),
         (("DeformableDetrTransformer", "DeformableDetrTransformerVL"), ".transformer", DeformableDetrTransformerVL),
@@ -87,7 +90,7 @@ def test_every_config_keyword_is_accepted(chain):
         missing = sorted(want - ok)
         assert not missing, f"{chain}: {cls.__name__} does not accept {missing}"
         checked += len(want)
-    assert checked >= (8 if chain == "L_A" else 40), checked
+    assert checked >= (8 if chain in ("L_A", "G_A", "V_A") else 40), checked      # backbone-only chains: the ViT + pyramid keywords
 
 
 def test_overrides_of_every_vit_ape_config_are_accepted():
