@@ -423,6 +423,10 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return None
+    if os.environ.get("APE_BENCH_SHARE_GPU") == "1":
+        # smoke of the N > 1 code path on a box with fewer GPUs than ranks (ranks share a device; use --backend gloo: RCCL refuses two
+        # ranks on one GPU).  Throughput of such a run means nothing; the exchange, the lagged collection and the timing protocol run
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
