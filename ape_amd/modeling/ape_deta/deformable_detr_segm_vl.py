@@ -140,8 +140,21 @@ class DeformableDETRSegmVL(nn.Module):
     def device(self):
         return self.pixel_mean.device
 
+    def _apply(self, fn, *args, **kwargs):
+        """`model.half()` / `model.to(torch.float16)` -- how the reference evaluates (tools/train_net.py:642) -- selects the IEEE-half
+        flavour of the kernels, `.to(torch.bfloat16)` the bf16 one: a change of the PARAMETER dtype to a 16-bit type is a request for that
+        arithmetic.  (`.float()` leaves the compute dtype alone: fp32 parameters are the normal state of every flavour.)"""
+        p0 = next(self.parameters(), None)
+        before = p0.dtype if p0 is not None else None
+        out = super()._apply(fn, *args, **kwargs)
+        p1 = next(self.parameters(), None)
+        if p1 is not None and p1.dtype != before and p1.dtype in (torch.float16, torch.bfloat16):
+            self.set_compute_dtype(p1.dtype)
+        return out
+
     def set_compute_dtype(self, dt):
-        """torch.bfloat16 (production) or torch.float32 (exact-math validation mode)"""
+        """torch.bfloat16 (BASELINE's dtype, the default), torch.float16 (the reference's evaluation dtype: same kernels on IEEE half)
+        or torch.float32 (exact-math validation mode)"""
         self.compute_dtype = dt
         for m in self.modules():
             if hasattr(m, "compute_dtype") and m is not self and not isinstance(getattr(type(m), "compute_dtype", None), property):

@@ -323,8 +323,14 @@ def test_fp16_model_runs_through_the_module_edge(fake_ops):
     model, orc, image, text, gold = M.build_pair("tiny_padded")
     h, w = image.shape[-2:]
     ref = model([{"image": image, "height": h, "width": w, "text_features": text}])[0]["instances"]
+    assert model.model_vision.compute_dtype == torch.float32          # build_pair's validation mode
     model.half()
     assert model.model_vision.backbone.net.blocks[0].attn.q_proj.weight.dtype == torch.float16
+    # fp16 parameters select the IEEE-half flavour of the kernels, everywhere (the reference's evaluation arithmetic)
+    assert model.model_vision.compute_dtype == torch.float16 and model.model_vision.backbone.net.compute_dtype == torch.float16
+    model.float()
+    assert model.model_vision.compute_dtype == torch.float16          # fp32 parameters are the normal state of every flavour
+    model.half()
     model.model_vision.set_compute_dtype(torch.float32)
     got = model([{"image": image.half(), "height": h, "width": w, "text_features": text.half()}])[0]["instances"]
     frac = U.match_detections(got.pred_boxes, got.scores, got.pred_classes, ref.pred_boxes, ref.scores, ref.pred_classes,
