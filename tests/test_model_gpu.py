@@ -214,6 +214,25 @@ def test_semantic_branch_in_the_size_agnostic_graph(pipeline):
         assert frac >= 0.99, (i, frac)
 
 
+def test_half_model_selects_the_f16_flavour():
+    """model.half() -- the reference's evaluation cast (tools/train_net.py:642) -- switches every module to the IEEE-half kernels; the
+    MFMA weights are then bit-identical to the f16 flavour of the fp32 model (fp32 -> f16 rounds once either way), norms / biases carry
+    one extra rounding: same detections"""
+    model, orc, image, text, gold, image_c, text_c = _run("tiny_padded", torch.float32)
+    mv = model.model_vision
+    h, w = image.shape[-2:]
+    mv.set_compute_dtype(torch.float16)
+    ref = model([{"image": image, "height": h, "width": w, "text_features": text}])[0]["instances"]
+    mv.set_compute_dtype(torch.float32)
+    model.half()
+    assert mv.compute_dtype == torch.float16 and mv.backbone.net.compute_dtype == torch.float16
+    got = model([{"image": image.half(), "height": h, "width": w, "text_features": text.half()}])[0]["instances"]
+    frac = U.match_detections(got.pred_boxes, got.scores, got.pred_classes, ref.pred_boxes, ref.scores, ref.pred_classes,
+                              box_tol=3e-2, score_tol=3e-2)
+    print(f"[half model] {len(got.scores)} instances, {frac:.3f} of the f16 flavour's detections matched")
+    assert frac >= 0.9, frac
+
+
 def test_parallel_images_in_one_graph():
     """images_per_step = 2: two batch-1 forwards as parallel branches of one hipGraph give the same detections and masks
     as two sequential single-image replays"""
