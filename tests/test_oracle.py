@@ -223,3 +223,42 @@ def test_rel_pos_tables_match_the_live_reference():
     qe, ke = ref_ops.relpos_extend(q[0].contiguous(), k[0].contiguous(), t, ty, tx, heads=1, head_stride=hd, head_dim=hd, hk=H, wk=W,
                                    ext_dim=vit_eva.ext_width(hd, H, W), scale=scale)
     assert torch.allclose(qe @ ke.t(), want, atol=1e-5)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="needs /root/reference")
+@pytest.mark.parametrize("variant", ["beit_bias", "layer_scale", "packed_bias"])
+def test_vit_eva_host_module_matches_the_live_reference_class(fake_ops, variant):
+    """ape/modeling/backbone/vit_eva.py ViT in the parameterisations its constructor offers -- q / v bias vectors (`beit_like_qkv_bias`,
+    the APE config), the BEiT layer scale `gamma_1 / gamma_2` (`beit_like_gamma`: folded into the block's last linears here), a plain
+    packed qkv bias -- instantiated from the reference's own file, its state dict loaded into the HIP-path class of the same name
+    (ops = their definitions): same keys, same feature map"""
+    import importlib
+    from functools import partial
+
+    import torch.nn as nn
+
+    from ape_amd.modeling.backbone import vit_eva
+    refshim.install()
+    R = importlib.import_module("ape.modeling.backbone.vit_eva")
+    kw = dict(img_size=256, patch_size=16, embed_dim=128, depth=4, num_heads=2, mlp_ratio=2.0, qkv_bias=True, drop_path_rate=0.0,
+              norm_layer=partial(nn.LayerNorm, eps=1e-6), window_size=8, window_block_indexes=[0, 1, 2], residual_block_indexes=[],
+              use_rel_pos=True, rel_pos_zero_init=False, out_feature="last_feat", use_act_checkpoint=False, pretrain_img_size=224,
+              beit_like_qkv_bias=variant != "packed_bias", beit_like_gamma=variant == "layer_scale")
+    torch.manual_seed(3)
+    ref = R.ViT(**kw).eval()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():                      # biases / layer scales / tables away from their trivial initial values
+            if n.endswith(("q_bias", "v_bias", "qkv.bias", "proj.bias", "fc1.bias", "fc2.bias")):
+                p.normal_(std=0.2)
+            elif "gamma_" in n:
+                p.uniform_(0.5, 1.5)
+    ours = vit_eva.ViT(**kw)
+    assert {k: tuple(v.shape) for k, v in ours.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    ours.load_state_dict(ref.state_dict())
+    ours.compute_dtype = torch.float32
+    x = torch.randn(1, 3, 256, 256)
+    with torch.no_grad():
+        want = ref(x)["last_feat"]
+        got = ours(x)["last_feat"]
+    e = U.relerr(got, want)
+    assert tuple(got.shape) == tuple(want.shape) == (1, 128, 16, 16) and e < 2e-5, (variant, e)
