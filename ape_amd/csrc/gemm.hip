@@ -1080,6 +1080,15 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
   const char* ring_env = getenv("APE_GEMM_RING");     // read per call so a probe can flip it
   const int use_ring_always = ring_env ? atoi(ring_env) : 0;
   const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
+  if (p.conv_h > 0) {
+    // implicit-GEMM 3 x 3 convolution: the 256 x 256 tile kernel only (callers fall back to im2col + gemm when this is refused)
+    APE_CHECK_ARG(p.conv_w > 0 && p.splitk <= 1 && !p.trans_out && ceil_div(p.M, 256) * ceil_div(p.N, 256) >= 200,
+                  "ape_hip_gemm(conv3x3): needs >= 200 tiles of 256 x 256 (M = %d, N = %d), no split-K / transposed output", p.M, p.N);
+    const char* name = ape_gemm_p8_launch(p, 256, 1, s);
+    APE_CHECK_ARG(name != nullptr, "ape_hip_gemm(conv3x3): K = 9 * 256 channels of 16-bit operands, lda >= 256, M == conv_h * conv_w, a 16-byte aligned zero row");
+    g_last_gemm_kernel = name;
+    return 0;
+  }
   if (p.tile64 == 3 || p.tile64 == 4) {
     // 256 x 256 / 256 x 128 eight-wave tiles with the counted-wait pipeline (gemm_p8.hip); falls back when unsupported
     const char* st_env = getenv("APE_GEMM_P8_STAGGER");
@@ -1217,6 +1226,7 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   p.vec_ok = vec;
   hipStream_t s = (hipStream_t)stream;
   APE_CHECK_ARG(p.ln_w == nullptr || ape_is16(p.in_dt), "ape_hip_gemm: the epilogue LayerNorm exists for the 16-bit K = N = 256 kernel only");
+  APE_CHECK_ARG(p.conv_h <= 0 || ape_is16(p.in_dt), "ape_hip_gemm(conv3x3): implicit convolution exists for the 16-bit tile kernel only (use ape_hip_im2col3x3 in fp32)");
   if (ape_is16(p.in_dt)) {
     if (p.ln_w != nullptr && (p.tile64 == 3 || p.tile64 == 4)) p.tile64 = 0;
     const int rc = p.in_dt == APE_DT_F16 ? gemm_launch_h16<f16_t>(p, s) : gemm_launch_h16<bf16_t>(p, s);

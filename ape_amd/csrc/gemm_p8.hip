@@ -50,7 +50,12 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
 
 // ABL (builds with -DAPE_P8_ABLATION only; tools/gpu_p8_ablate.py): 0 = the kernel; 1 = epilogue without its bias / table / residual
 // loads; 2 = full epilogue, no stores; 3 = no epilogue; 4 = one K tile only (prologue + epilogue)
-template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
+// CONV: implicit-GEMM 3 x 3 convolution (stride 1, zero padding 1) over a token-major [H * W, C = 256] map: A is the conv INPUT, K = 9 * C
+// in (tap, channel) order, and the A half-tile of K tile kt is staged from the rows the tap (kt / 4) shifts the tile's 256 output
+// pixels to -- through the index table `conv_perm` when the map's rows are not in raster order -- or from a zero row outside the
+// image.  The [H * W, 9 C] im2col matrix (302 MB for a 256 x 256 map) is never written or read; the 33.5 MB input is re-read nine
+// times out of L2 / the Infinity Cache.  Same schedule, same MFMA order: results are bit-identical to im2col + the ordinary kernel.
+template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0, bool CONV = false>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
       int gm = m0 + trow; gm = gm < p.M ? gm : p.M - 1;
       const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      offA[h][q] = (uint32_t)gm * (uint32_t)p.lda * 2u + (uint32_t)c * 16u;
+      // CONV: the byte address (in LDS) of this lane's row in the tap-0 slice of the source-row table; the chunk offset rides in bits 0-6
+      offA[h][q] = CONV ? (uint32_t)trow * 4u : (uint32_t)gm * (uint32_t)p.lda * 2u + (uint32_t)c * 16u;
     }
 #pragma unroll
     for (int q = 0; q < NIB; ++q) {
@@ -119,6 +125,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     for (int q = 0; q < 2; ++q)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + offA[h][q]), (lds_void_t*)(dst + q * 1024), 16, 0, 0);
   };
+  // ---- CONV: source-row table in LDS behind the two stages: sidx[tap][row of the tile] = byte offset of the input row the tap maps
+  // the output pixel to, 0xffffffff outside the image / the problem.  A lane's two entries for an issue are read one phase ahead
+  // (inline asm: hipcc would put a vmcnt(0) in front of an LDS read it cannot prove disjoint from the LDS-DMA in flight) and are
+  // covered by that phase's lgkmcnt(0).
+  constexpr int CONV_KTP = 4;                                                // K tiles per tap: C = 256 channels
+  const unsigned char* __restrict__ Zb = reinterpret_cast<const unsigned char*>(p.conv_zero);
+  auto conv_read = [&](int kt, int h, uint32_t (&ro)[2]) __attribute__((always_inline)) {
+    const uint32_t base = (uint32_t)(uintptr_t)(lds_void_t*)(smem + 2 * STG) + (uint32_t)(kt / CONV_KTP) * 1024u;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(ro[q]) : "v"(base + offA[h][q]));
+  };
+  auto conv_issue = [&](int kt, int h, uint32_t (&ro)[2]) __attribute__((always_inline)) {
+    unsigned char* dst = smem + (kt & 1) * STG + (h ? OFF_A1 : OFF_A0) + wave * 2048;
+    const uint32_t c0 = (uint32_t)(kt % CONV_KTP) * (P8_BK * 2);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      asm volatile("" : "+v"(ro[q]));                                        // consumed only behind the phase's lgkmcnt(0)
+      const int lr = (wave * 2 + q) * 8 + (lane >> 3);
+      const uint32_t cb = (uint32_t)((lane & 7) ^ ((lr >> 1) & 7)) * 16u;
+      const unsigned char* src = ro[q] == 0xffffffffu ? Zb + cb : Ab + ro[q] + c0 + cb;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + q * 1024), 16, 0, 0);
+    }
+  };
+  uint32_t ia0[2] = {0u, 0u}, ia1[2] = {0u, 0u};
   auto issue_B = [&](int kt, int h) __attribute__((always_inline)) {
     unsigned char* dst = smem + (kt & 1) * STG + (h ? OFF_B1 : OFF_B0) + wave * (NIB * 1024);
     const unsigned char* src = Wb + (size_t)kt * (P8_BK * 2);
@@ -222,12 +252,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   };
   constexpr int INFLIGHT = 2 * NIB + 2;          // loads of the three youngest half-tiles at a phase-4 wait: B0, A0, B1
   // ---- prologue: K tile 0 complete, the first three half-tiles of K tile 1 in flight
+  if (CONV) {
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(smem + 2 * STG);
+    for (int e = tid; e < 9 * P8_BM; e += 512) {
+      const int row = e & (P8_BM - 1), tap = e >> 8;
+      const int gm = m0 + row;
+      uint32_t v = 0xffffffffu;
+      if (gm < p.M) {
+        const int y = gm / p.conv_w + tap / 3 - 1, x = gm % p.conv_w + tap % 3 - 1;
+        if (y >= 0 && y < p.conv_h && x >= 0 && x < p.conv_w) {
+          const int rs = y * p.conv_w + x;
+          v = (uint32_t)(p.conv_perm != nullptr ? p.conv_perm[rs] : rs) * (uint32_t)p.lda * 2u;
+        }
+      }
+      sidx[e] = v;
+    }
+    __syncthreads();                                   // the table is complete (and no LDS-DMA is in flight yet)
+    uint32_t r00[2], r01[2], r10[2];
+    conv_read(0, 0, r00); conv_read(0, 1, r01); conv_read(1, 0, r10); conv_read(1, 1, ia1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    issue_B(0, 0); conv_issue(0, 0, r00); issue_B(0, 1); conv_issue(0, 1, r01);
+    if (nk > 1) {
+      issue_B(1, 0); conv_issue(1, 0, r10); issue_B(1, 1);
+      p8_wait_vmcnt<INFLIGHT>();
+    } else {
+      p8_wait_vmcnt<0>();
+    }
+  } else {
   issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
   if (nk > 1) {
     issue_B(1, 0); issue_A(1, 0); issue_B(1, 1);
     p8_wait_vmcnt<INFLIGHT>();
   } else {
     p8_wait_vmcnt<0>();
+  }
   }
   barrier();
   if (STAGGER && wr == 1) barrier();
@@ -238,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     read_B(s, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_A(s, 0);
-    if (t + 1 < nk) issue_A(t + 1, 1);
+    if (t + 1 < nk) { if (CONV) conv_issue(t + 1, 1, ia1); else issue_A(t + 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads (issued first) are complete: B0 may be re-staged next phase
     barrier();
@@ -247,6 +305,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     barrier();
     // ---- phase 2
     read_B(s, 1);
+    if (CONV && t + 2 < nk) conv_read(t + 2, 0, ia0);          // for phase 3's issue; retired by this phase's lgkmcnt(0)
     if (t + 2 < nk) issue_B(t + 2, 0);
     if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(0); issue_rope(1); issue_rope(2); issue_rope(3); }
     barrier();
@@ -255,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     barrier();
     // ---- phase 3
     read_A(s, 1);
-    if (t + 2 < nk) issue_A(t + 2, 0);
+    if (t + 2 < nk) { if (CONV) { conv_issue(t + 2, 0, ia0); conv_read(t + 2, 1, ia1); } else issue_A(t + 2, 0); }   // ia1: next iteration's phase 1
     if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(4); issue_rope(5); issue_rope(6); issue_rope(7); }
     barrier();
     lgkm0();
@@ -385,6 +444,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
 // ------------------------------------------------------------------------------------------
 static bool p8_supported(const ApeGemmArgs& p) {
   if (!ape_is16(p.in_dt) || p.K % P8_BK != 0 || p.K < P8_BK) return false;
+  if (p.conv_h > 0 && (p.trans_out || p.rope_cos != nullptr)) return false;
   if (p.splitk > 1 || p.rowscale != nullptr && p.trans_out) return false;
   const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
   if (((uintptr_t)p.C) % 16 != 0 || ((size_t)p.ldc * esz) % 16 != 0) return false;
@@ -434,6 +494,21 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     }
   }
 #endif
+  if (p.conv_h > 0) {
+    // implicit 3 x 3 convolution: the 256 x 256 tile, staggered schedule, + 9 KiB of LDS for the source-row table
+    if (bn != 256 || p.K != 9 * 256 || p.lda < 256 || p.M != p.conv_h * p.conv_w || p.conv_zero == nullptr || ((uintptr_t)p.conv_zero) % 16 != 0)
+      return nullptr;
+    constexpr int CONV_LDS = 131072 + 9 * P8_BM * 4;
+    static bool cattr = false;
+    if (!cattr) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+      cattr = true;
+    }
+    if (f16) hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
+    return f16 ? "gemm_f16_p8_kernel<256, true, conv3x3>" : "gemm_bf16_p8_kernel<256, true, conv3x3>";
+  }
   if (bn == 256) {
     if (stagger) { if (f16) P8_LAUNCH(256, true, f16_t, 131072, "gemm_f16_p8_kernel<256, true>"); else P8_LAUNCH(256, true, bf16_t, 131072, "gemm_bf16_p8_kernel<256, true>"); }
     else { if (f16) P8_LAUNCH(256, false, f16_t, 131072, "gemm_f16_p8_kernel<256, false>"); else P8_LAUNCH(256, false, bf16_t, 131072, "gemm_bf16_p8_kernel<256, false>"); }

@@ -409,7 +409,7 @@ class DeformableDETRSegmVL(nn.Module):
             p2 = maps[self.mask_in_features[0]][0]
             lat = ops.gemm(p2, P["lat"][0], None)
             lat = ops.groupnorm(lat, P["lat"][1], P["lat"][2], P["lat"][3], P["lat"][4], add=memory[: H0 * W0])
-            y = ops.gemm(ops.im2col3x3(lat, None, H0, W0), P["outc"][0], None)
+            y = ops.conv3x3(lat, None, H0, W0, P["outc"][0], None)
             y = ops.groupnorm(y, P["outc"][1], P["outc"][2], P["outc"][3], P["outc"][4], act=ops.ACT_RELU)
             return ops.gemm(y, P["maskc"], None)                                                      # [H0*W0, 256]
 

@@ -522,8 +522,8 @@ class SimpleFeaturePyramid(Backbone):
     def _conv_ln_pair(self, x, perm, H, W, c1, c3, dt):
         """1x1 conv + LN (any row order), then 3x3 conv + LN through the gathering im2col -> raster [H*W, C]"""
         y = ops.layernorm(ops.gemm(x, c1[0], None), c1[1], c1[2], c1[3], out_dtype=dt)
-        cols = ops.im2col3x3(y, perm, H, W)
-        return ops.layernorm(ops.gemm(cols, c3[0], None), c3[1], c3[2], c3[3], out_dtype=dt)
+        # large 256-channel maps (p2: 256 x 256 pixels): implicit GEMM, the im2col matrix (302 MB) is never written; else im2col + gemm
+        return ops.layernorm(ops.conv3x3(y, perm, H, W, c3[0], None), c3[1], c3[2], c3[3], out_dtype=dt)
 
     def forward_tokens(self, image, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), vit_feat=None, stages=None):
         """-> dict name -> ([H*W, C] raster token-major map in the compute dtype, (H, W)).  vit_feat: this image's rows of a

@@ -508,6 +508,43 @@ def im2col3x3(x, perm, h, w, *, out=None):
     return out
 
 
+_ZERO_ROWS = {}
+
+
+def conv3x3_implicit_ok(x, w, h, wd):
+    """does `conv3x3` run as the implicit-GEMM flavour of the 256 x 256 tile kernel?  (16-bit, 256 channels, >= 200 tiles)"""
+    return (x.dtype in HALF16 and x.dtype == w.dtype and x.shape[1] == 256 and w.shape[1] == 9 * 256
+            and ((h * wd + 255) // 256) * ((w.shape[0] + 255) // 256) >= 200 and os.environ.get("APE_CONV_IM2COL") != "1")
+
+
+def conv3x3(x, perm, h, wd, w, bias=None, *, out_dtype=None):
+    """3 x 3 / stride 1 / zero padding 1 convolution of a token-major map: x [rows, C] (raster pixel r lives in row perm[r]; perm None:
+    row r), w [N, 9 C] in (ky, kx, ci) order -> [h * wd, N].  Large 256-channel maps in a 16-bit type run as an IMPLICIT GEMM (the tile
+    kernel stages its A operand from the shifted input rows: ApeGemmArgs.conv_*; the [h wd, 9 C] im2col matrix never exists);
+    everything else is im2col3x3 + gemm.  Bit-identical either way."""
+    _dev(x, perm, w, bias)
+    if not conv3x3_implicit_ok(x, w, h, wd):
+        return gemm(im2col3x3(x, perm, h, wd), w, bias, out_dtype=out_dtype)
+    _rowmajor(x, "x"), _rowmajor(w, "w")
+    M, N = h * wd, w.shape[0]
+    out = torch.empty((M, N), dtype=out_dtype or x.dtype, device=x.device)
+    key = (x.device, )
+    if key not in _ZERO_ROWS:
+        _ZERO_ROWS[key] = torch.zeros((256,), dtype=torch.uint8, device=x.device)
+    args = _lib.GemmArgs()
+    args.A, args.W, args.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    args.bias = _f32vec(bias, "bias").data_ptr() if bias is not None else None
+    args.M, args.N, args.K = M, N, 9 * 256
+    args.lda, args.ldw, args.ldc = _ld(x), _ld(w), _ld(out)
+    args.in_dt, args.out_dt = _dt(x), _dt(out)
+    args.act, args.mask_mode, args.alpha, args.tile64 = ACT_NONE, MASK_NONE, 1.0, 3
+    args.conv_perm = _i32(perm, "perm").data_ptr() if perm is not None else None
+    args.conv_zero, args.conv_h, args.conv_w = _ZERO_ROWS[key].data_ptr(), int(h), int(wd)
+    rc = _lib.load().ape_hip_gemm(ctypes.byref(args), _stream())
+    _lib.check(rc, "ape_hip_gemm(conv3x3)")
+    return out
+
+
 def maxpool2x2(x, perm, h, w):
     _dev(x, perm)
     _rowmajor(x, "x")

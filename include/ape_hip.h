@@ -98,6 +98,16 @@ typedef struct ApeGemmArgs {
   const float* ln_b;
   float ln_eps;
   int32_t reserved0;
+  /* implicit-GEMM 3 x 3 convolution (stride 1, zero padding 1; SimpleFeaturePyramid's / the mask head's 3 x 3 convs at 256 channels,
+   * vit_eva_clip.py:806-842, deformable_detr_segm_vl.py:728-750): conv_h > 0 makes A the conv INPUT -- a token-major [conv_h * conv_w,
+   * lda] map of C = K / 9 = 256 channels whose row of raster pixel r is conv_perm[r] (NULL: r) -- and W the [N, 9 C] weight in
+   * (ky, kx, ci) order; M = conv_h * conv_w.  The kernel stages each K tile's A operand from the shifted rows (a zero row outside the
+   * image: conv_zero, >= 128 zero bytes, 16-byte aligned), so the [M, 9 C] im2col matrix is never materialised; results are
+   * bit-identical to ape_hip_im2col3x3 + ape_hip_gemm.  16-bit operands, >= 200 tiles of 256 x 256 (else an argument error: callers
+   * fall back to im2col). */
+  const int32_t* conv_perm;
+  const void* conv_zero;
+  int32_t conv_h, conv_w;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */

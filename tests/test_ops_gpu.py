@@ -1055,3 +1055,42 @@ def test_panoptic_merge(ops, k, h, w, H, W, nthing, offset):
     none = torch.zeros_like(keep)
     seg, info, count = ops.panoptic_merge(masks, scores, none, classes, isthing, H, W, **kw)
     assert int(count.item()) == 0 and int(seg.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("dtype", H16)
+@pytest.mark.parametrize("use_perm,use_bias,N", [(False, False, 256), (True, True, 256), (True, False, 384)])
+def test_conv3x3_implicit_gemm(ops, dtype, use_perm, use_bias, N):
+    """the 3 x 3 convolutions of the pyramid / mask head at 256 x 256 pixels as an implicit GEMM (the tile kernel stages its A operand
+    from the shifted input rows, ApeGemmArgs.conv_*): bit-identical to im2col3x3 + gemm -- same tiles, same K order -- incl. the
+    zero rows outside the image, rows addressed through a permutation, and a map with a padded row stride"""
+    H = W = 256
+    C = 256
+    x_full = rnd(H * W + 7, C + 8, dtype=dtype, seed=1)
+    x = x_full[:, :C]                                                        # row stride 264: a view, like the model's maps
+    w = (rnd(N, 9 * C, seed=2) * (9 * C) ** -0.5).to(dtype)
+    bias = rnd(N, seed=3) if use_bias else None
+    perm = torch.randperm(H * W, generator=torch.Generator().manual_seed(4)).int().to(DEV) if use_perm else None
+    if not SELF:
+        assert ops.conv3x3_implicit_ok(x, w, H, W)
+    got = ops.conv3x3(x, perm, H, W, w, bias)
+    want = ops.gemm(ops.im2col3x3(x, perm, H, W), w, bias)
+    assert tuple(got.shape) == (H * W, N) and got.dtype == dtype
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    ref = ref_ops.conv3x3(x, perm, H, W, w, bias)
+    e = relerr(got, ref)
+    print(f"conv3x3 implicit {dtype} perm={use_perm} N={N}: identical to im2col + gemm; vs the definition {e:.2e}")
+    assert e < T16(dtype, 1e-2, 1e-5)
+    if not SELF:
+        def timed(fn, reps=10):
+            fn()
+            s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(reps):
+                fn()
+            t.record()
+            t.synchronize()
+            return s.elapsed_time(t) * 1e3 / reps
+        print(f"   implicit {timed(lambda: ops.conv3x3(x, perm, H, W, w, bias)):.1f} us vs im2col + gemm "
+              f"{timed(lambda: ops.gemm(ops.im2col3x3(x, perm, H, W), w, bias)):.1f} us")
+        small = ops.conv3x3(x[:64 * 64 + 7], None, 64, 64, w, bias)          # too few tiles: the im2col path behind the same entry
+        assert torch.equal(small, ops.gemm(ops.im2col3x3(x[:64 * 64 + 7], None, 64, 64), w, bias))
