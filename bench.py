@@ -108,7 +108,7 @@ class GemmMeter:
 
     def __init__(self, ops):
         from ape_amd import _lib
-        self.ops, self.orig, self.orig_ffn, self.records = ops, ops.gemm, ops.ffn_fused, []
+        self.ops, self.orig, self.orig_ffn, self.orig_conv, self.records = ops, ops.gemm, ops.ffn_fused, ops.conv3x3, []
         self.lib = _lib.load()
 
     def __enter__(self):
@@ -131,11 +131,24 @@ class GemmMeter:
             self.records.append((name, s, e, 2.0 * x.shape[0] * x.shape[1] * w1.shape[0] + 2.0 * x.shape[0] * w1.shape[0] * w2.shape[0],
                                  f"{x.shape[0]}x{x.shape[1]}x{w1.shape[0]}x{w2.shape[0]}"))
             return out
-        self.ops.gemm, self.ops.ffn_fused = wrapped, wrapped_ffn
+
+        def wrapped_conv(x, perm, h, wd, w, bias=None, **kw):
+            # the 3 x 3 convolutions as implicit GEMMs (the tile kernel stages A from the shifted input rows): the same 2 M N K flops as
+            # the im2col GEMM they replace, M = h * wd, K = 9 C.  When the im2col path is taken instead, its inner ops.gemm is metered.
+            if not self.ops.conv3x3_implicit_ok(x, w, h, wd):
+                return self.orig_conv(x, perm, h, wd, w, bias, **kw)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = self.orig_conv(x, perm, h, wd, w, bias, **kw)
+            e.record()
+            name = self.lib.ape_hip_gemm_last_kernel().decode()
+            self.records.append((name, s, e, 2.0 * h * wd * w.shape[0] * w.shape[1], f"{h * wd}x{w.shape[0]}x{w.shape[1]} (implicit 3x3 conv)"))
+            return out
+        self.ops.gemm, self.ops.ffn_fused, self.ops.conv3x3 = wrapped, wrapped_ffn, wrapped_conv
         return self
 
     def __exit__(self, *exc):
-        self.ops.gemm, self.ops.ffn_fused = self.orig, self.orig_ffn
+        self.ops.gemm, self.ops.ffn_fused, self.ops.conv3x3 = self.orig, self.orig_ffn, self.orig_conv
 
     @staticmethod
     def family(name):
