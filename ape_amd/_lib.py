@@ -60,6 +60,10 @@ SIGNATURES = {
     "ape_hip_sizeof_args": (c_int, [c_int]),
     "ape_hip_gemm": (c_int, [POINTER(GemmArgs), c_void_p]),
     "ape_hip_gemm_last_kernel": (c_char_p, []),
+    "ape_hip_meter_begin": (c_int, []),
+    "ape_hip_meter_count": (c_int, []),
+    "ape_hip_meter_end": (c_int, []),
+    "ape_hip_meter_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_float)]),
     "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),

@@ -397,8 +397,8 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
     APE_CHECK_ARG(!causal && HDV == 128 && (HD == 256 || HD == 288 || HD == 320), "ape_hip_attention_ext(16-bit): q.k width 256 / 288 / 320 with V width 128");
 #define ATT_WIDE(HD_)                                                                                                         \
     do {                                                                                                                      \
-      if (big) hipLaunchKernelGGL((attn_bf16_kernel<HD_, 2, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);              \
-      else hipLaunchKernelGGL((attn_bf16_kernel<HD_, 1, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);                  \
+      if (big) APE_LAUNCH((attn_bf16_kernel<HD_, 2, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);              \
+      else APE_LAUNCH((attn_bf16_kernel<HD_, 1, false, true, 1, H, 128>), grid, dim3(256), 0, s, p);                  \
     } while (0)
     if (HD == 256) ATT_WIDE(256); else if (HD == 288) ATT_WIDE(288); else ATT_WIDE(320);
 #undef ATT_WIDE
@@ -406,14 +406,14 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
   }
   if (causal) {
     APE_CHECK_ARG(HD == 64, "ape_hip_attention_causal(bf16): head dimension 64 (every CLIP text tower of the reference)");
-    if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, true, true, 1, H>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, true, true, 1, H>), grid, dim3(256), 0, s, p);
+    if (big) APE_LAUNCH((attn_bf16_kernel<64, 2, true, true, 1, H>), grid, dim3(256), 0, s, p);
+    else APE_LAUNCH((attn_bf16_kernel<64, 1, true, true, 1, H>), grid, dim3(256), 0, s, p);
   } else if (HD == 128) {           // ViT-e (head width 112 zero-padded to 128 by the packing)
-    if (big) hipLaunchKernelGGL((attn_bf16_kernel<128, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_bf16_kernel<128, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    if (big) APE_LAUNCH((attn_bf16_kernel<128, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    else APE_LAUNCH((attn_bf16_kernel<128, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
   } else if (natural) {
-    if (HD == 64) { if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
-    else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
+    if (HD == 64) { if (big) APE_LAUNCH((attn_bf16_kernel<64, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else APE_LAUNCH((attn_bf16_kernel<64, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
+    else { if (big) APE_LAUNCH((attn_bf16_kernel<32, 2, false, false, 1, H>), grid, dim3(256), 0, s, p); else APE_LAUNCH((attn_bf16_kernel<32, 1, false, false, 1, H>), grid, dim3(256), 0, s, p); }
   } else if (HD == 64) {
     static const bool occ4 = getenv("APE_ATTN_OCC4") != nullptr;       // A/B: cap the 128-query kernel at 128 registers (4 waves per SIMD)
     // 256 queries per workgroup (4 query tiles per wave: every K / V^T fragment read from LDS feeds four MFMAs) when that still
@@ -422,12 +422,12 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
     const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : false) && (size_t)ceil_div(N, 256) * nheads * B >= 512;
     if (qt4) {
       grid.x = ceil_div(N, 256);
-      hipLaunchKernelGGL((attn_bf16_kernel<64, 4, false, true, 1, H>), grid, dim3(256), 0, s, p);
-    } else if (big && occ4) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 4, H>), grid, dim3(256), 0, s, p);
-    else if (big) hipLaunchKernelGGL((attn_bf16_kernel<64, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_bf16_kernel<64, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
+      APE_LAUNCH((attn_bf16_kernel<64, 4, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    } else if (big && occ4) APE_LAUNCH((attn_bf16_kernel<64, 2, false, true, 4, H>), grid, dim3(256), 0, s, p);
+    else if (big) APE_LAUNCH((attn_bf16_kernel<64, 2, false, true, 1, H>), grid, dim3(256), 0, s, p);
+    else APE_LAUNCH((attn_bf16_kernel<64, 1, false, true, 1, H>), grid, dim3(256), 0, s, p);
   }
-  else { if (big) hipLaunchKernelGGL((attn_bf16_kernel<32, 2, false, true, 1, H>), grid, dim3(256), 0, s, p); else hipLaunchKernelGGL((attn_bf16_kernel<32, 1, false, true, 1, H>), grid, dim3(256), 0, s, p); }
+  else { if (big) APE_LAUNCH((attn_bf16_kernel<32, 2, false, true, 1, H>), grid, dim3(256), 0, s, p); else APE_LAUNCH((attn_bf16_kernel<32, 1, false, true, 1, H>), grid, dim3(256), 0, s, p); }
   return 0;
 }
 
@@ -449,12 +449,12 @@ static int attention_launch(const void* Q, int ldq, const void* K, int ldk, cons
                                     : attention_launch_h16<bf16_t>(p, grid, B, N, bstride, H, HD, HDV, causal, s);
     if (rc != 0) return rc;
   } else {
-    if (HD == 256) hipLaunchKernelGGL((attn_f32_kernel<256, 128>), grid, dim3(64), 0, s, p);
-    else if (HD == 288) hipLaunchKernelGGL((attn_f32_kernel<288, 128>), grid, dim3(64), 0, s, p);
-    else if (HD == 320) hipLaunchKernelGGL((attn_f32_kernel<320, 128>), grid, dim3(64), 0, s, p);
-    else if (HD == 128) hipLaunchKernelGGL(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
-    else if (HD == 64) hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
+    if (HD == 256) APE_LAUNCH((attn_f32_kernel<256, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 288) APE_LAUNCH((attn_f32_kernel<288, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 320) APE_LAUNCH((attn_f32_kernel<320, 128>), grid, dim3(64), 0, s, p);
+    else if (HD == 128) APE_LAUNCH(attn_f32_kernel<128>, grid, dim3(64), 0, s, p);
+    else if (HD == 64) APE_LAUNCH(attn_f32_kernel<64>, grid, dim3(64), 0, s, p);
+    else APE_LAUNCH(attn_f32_kernel<32>, grid, dim3(64), 0, s, p);
   }
   APE_CHECK_LAUNCH("ape_hip_attention");
   return 0;

@@ -28,7 +28,7 @@ extern "C" int ape_hip_box_refine(const float* delta, int ldd, const float* ref,
                                   float* new_ref, float* ref_in, void* stream) {
   APE_CHECK_ARG(ref && Q > 0 && (ref_in == nullptr || (vr4 != nullptr && L > 0)) && (new_ref || ref_in),
                 "ape_hip_box_refine: bad args");
-  hipLaunchKernelGGL(box_refine_kernel, dim3(ceil_div(Q * 4, 256)), dim3(256), 0, (hipStream_t)stream, delta, ldd, ref, vr4, L, Q, eps,
+  APE_LAUNCH(box_refine_kernel, dim3(ceil_div(Q * 4, 256)), dim3(256), 0, (hipStream_t)stream, delta, ldd, ref, vr4, L, Q, eps,
                      new_ref, ref_in);
   APE_CHECK_LAUNCH("ape_hip_box_refine");
   return 0;
@@ -72,10 +72,10 @@ extern "C" int ape_hip_query_init(const float* coords, const int64_t* topk, int 
                                   float* reference, void* pe, int ldpe, int pe_dt, int32_t* topk32, void* stream) {
   APE_CHECK_ARG(coords && topk && dim_t && reference && pe && T > 0 && P > 0 && Q > 0 && ldpe >= 4 * P, "ape_hip_query_init: bad args");
   hipStream_t s = (hipStream_t)stream;
-  if (pe_dt == APE_DT_F16) hipLaunchKernelGGL(query_init_kernel<f16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (f16_t*)pe, ldpe, topk32);
-  else if (pe_dt == APE_DT_BF16) hipLaunchKernelGGL(query_init_kernel<bf16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (bf16_t*)pe, ldpe, topk32);
+  if (pe_dt == APE_DT_F16) APE_LAUNCH(query_init_kernel<f16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (f16_t*)pe, ldpe, topk32);
+  else if (pe_dt == APE_DT_BF16) APE_LAUNCH(query_init_kernel<bf16_t>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (bf16_t*)pe, ldpe, topk32);
   else if (pe_dt == APE_DT_F32)
-    hipLaunchKernelGGL(query_init_kernel<float>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (float*)pe, ldpe, topk32);
+    APE_LAUNCH(query_init_kernel<float>, dim3(Q), dim3(256), 0, s, coords, topk, T, dim_t, P, scale, Q, reference, (float*)pe, ldpe, topk32);
   else
     APE_CHECK_ARG(false, "ape_hip_query_init: pe must be f32, bf16 or f16");
   APE_CHECK_LAUNCH("ape_hip_query_init");
@@ -136,12 +136,12 @@ extern "C" int ape_hip_query_finish(const float* pos, int ldpos, const float* pi
   APE_CHECK_ARG(E > 0 && E <= 512 && E % 64 == 0 && ldpos >= 2 * E && ldpix >= E && ldo >= E, "ape_hip_query_finish: E must be a multiple of 64, <= 512");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ceil_div(Q, 4)), block(256);
-  if (out_dt == APE_DT_F16) hipLaunchKernelGGL(query_finish_kernel<f16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
+  if (out_dt == APE_DT_F16) APE_LAUNCH(query_finish_kernel<f16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
                        (f16_t*)query_pos, (f16_t*)query, (f16_t*)query_sum, ldo);
-  else if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(query_finish_kernel<bf16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
+  else if (out_dt == APE_DT_BF16) APE_LAUNCH(query_finish_kernel<bf16_t>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
                        (bf16_t*)query_pos, (bf16_t*)query, (bf16_t*)query_sum, ldo);
   else if (out_dt == APE_DT_F32)
-    hipLaunchKernelGGL(query_finish_kernel<float>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
+    APE_LAUNCH(query_finish_kernel<float>, grid, block, 0, s, pos, ldpos, pix, ldpix, Q, E, wpos, bpos, eps_pos, wpix, bpix, eps_pix,
                        (float*)query_pos, (float*)query, (float*)query_sum, ldo);
   else
     APE_CHECK_ARG(false, "ape_hip_query_finish: outputs must be f32, bf16 or f16");
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void det_records_kernel(const float* __restri
 extern "C" int ape_hip_det_records(const float* boxes, const float* scores, const int64_t* classes, const int64_t* query,
                                    const float* frame, int k, float* rec, float* boxes_out, int32_t* order, void* stream) {
   APE_CHECK_ARG(boxes && scores && classes && query && frame && rec && boxes_out && order && k > 0, "ape_hip_det_records: bad args");
-  hipLaunchKernelGGL(det_records_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, classes, query, frame, k, rec,
+  APE_LAUNCH(det_records_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, boxes, scores, classes, query, frame, k, rec,
                      boxes_out, order);
   APE_CHECK_LAUNCH("ape_hip_det_records");
   return 0;

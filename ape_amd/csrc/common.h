@@ -144,6 +144,20 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- host side error plumbing (C-ABI: 0 = ok, negative = error, message via ape_hip_last_error) ----
 extern "C" const char* ape_hip_last_error(void);
 void ape_set_error(const char* fmt, ...);
+
+// ---- launches.  Every kernel of the library goes out through APE_LAUNCH: the plain triple-chevron launch, or -- while the calling
+// thread has metering on (meter.cpp, ape_hip_meter_begin) -- hipExtLaunchKernelGGL with the launch's own (start, stop) events, whose
+// elapsed time is the dispatch's begin-to-end duration (what rocprofv3's kernel trace reports).  KERNEL is stringified as the launch's
+// name in the meter's records: the template expression as written at the launch site.
+#include <hip/hip_ext.h>
+hipEvent_t* ape_meter_pair(const char* kernel);
+#define APE_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                                  \
+  do {                                                                                                                     \
+    hipEvent_t* ev__ = ape_meter_pair(#KERNEL);                                                                            \
+    if (ev__ != nullptr) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ev__[0], ev__[1], 0, __VA_ARGS__);        \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                                \
+  } while (0)
+
 #define APE_CHECK_ARG(cond, ...)            \
   do {                                      \
     if (!(cond)) {                          \

@@ -341,7 +341,7 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
       (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<W2P_, RT_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       attr__ = true;                                                                                                          \
     }                                                                                                                         \
-    hipLaunchKernelGGL((ffn_fused_kernel<W2P_, RT_, H_>), dim3(ceil_div(M, 64 * RT_)), dim3(256), lds, (hipStream_t)stream, p); \
+    APE_LAUNCH((ffn_fused_kernel<W2P_, RT_, H_>), dim3(ceil_div(M, 64 * RT_)), dim3(256), lds, (hipStream_t)stream, p); \
   } while (0)
   if (dt == APE_DT_F16) {
     if (w2_permuted && rt == 3) FF_LAUNCH(true, 3, f16_t); else if (w2_permuted) FF_LAUNCH(true, 2, f16_t); else FF_LAUNCH(false, 2, f16_t);

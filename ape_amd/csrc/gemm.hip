@@ -1059,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kres_ln_kernel(const GemmParams p
 // ------------------------------------------------------------------------------------------
 static thread_local const char* g_last_gemm_kernel = "";
 extern "C" const char* ape_hip_gemm_last_kernel(void) { return g_last_gemm_kernel; }
-#define LAUNCH_GEMM(NAME, KERNEL, GRID, LDS) do { g_last_gemm_kernel = NAME; hipLaunchKernelGGL(KERNEL, GRID, dim3(256), LDS, s, p); } while (0)
+#define LAUNCH_GEMM(NAME, KERNEL, GRID, LDS) do { g_last_gemm_kernel = NAME; APE_LAUNCH(KERNEL, GRID, dim3(256), LDS, s, p); } while (0)
 
 // 16-bit operand launches (H = bf16_t | f16_t): tile selection is the same for both flavours
 template <typename H>
@@ -1162,7 +1162,7 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
       else if (p.tile64) LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 2, 2>", (gemm_bf16_ring_kernel<false, 2, 2, H>), dim3(nblk64, p.splitk), GEMM_T64_LDS);
       else LAUNCH_GEMM("gemm_bf16_ring_kernel<false, 4, 4>", (gemm_bf16_ring_kernel<false, 4, 4, H>), dim3(nblk, p.splitk), GEMM_V2_LDS);
       const size_t groups = (size_t)p.M * ((p.N + 3) / 4);
-      hipLaunchKernelGGL(gemm_splitk_reduce_kernel<H>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
+      APE_LAUNCH(gemm_splitk_reduce_kernel<H>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, p);
     } else if (ring && p.tile64 == 2 && !p.trans_out) {
       // 128 x 64 tiles: twice the workgroups of a 128 x 128 tiling at 3/4 of its operand traffic per flop
       const int nblk_mn = ceil_div(p.M, 128) * ceil_div(p.N, 64);
@@ -1252,13 +1252,13 @@ static int launch_gemv(const float* x, int ldx, const void* W, int ldw, int w_dt
   hipStream_t s = (hipStream_t)stream;
   const int nblk = ceil_div(N, 4);
   if (w_dt == APE_DT_F16)
-    hipLaunchKernelGGL(gemv_kernel<f16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const f16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
+    APE_LAUNCH(gemv_kernel<f16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const f16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
                        scale, add, ldadd, out2, ldo2);
   else if (w_dt == APE_DT_BF16)
-    hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
+    APE_LAUNCH(gemv_kernel<bf16_t>, dim3(nblk), dim3(256), 0, s, x, ldx, (const bf16_t*)W, ldw, bias, out, ldo, M, N, K, alpha,
                        scale, add, ldadd, out2, ldo2);
   else
-    hipLaunchKernelGGL(gemv_kernel<float>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)W, ldw, bias, out, ldo, M, N, K, alpha,
+    APE_LAUNCH(gemv_kernel<float>, dim3(nblk), dim3(256), 0, s, x, ldx, (const float*)W, ldw, bias, out, ldo, M, N, K, alpha,
                        scale, add, ldadd, out2, ldo2);
   return 0;
 }

@@ -174,6 +174,7 @@ __device__ __forceinline__ bool epi_fast_ok(const GemmParams& p) {
   if (p.bias != nullptr && !(p.vec_ok & (2 | 16))) return false;
   if (p.rope_cos != nullptr && (!(p.vec_ok & 4) || p.rope_hd % 16 != 0 || p.rope_cols % 16 != 0 || p.act != APE_ACT_NONE)) return false;
   if (p.rowscale != nullptr && (!(p.vec_ok & 8) || p.act != APE_ACT_NONE)) return false;
+  if (p.rope_cos != nullptr && p.rowscale != nullptr) return false;   // no RoPE + folded-LayerNorm specialisation: the generic epilogue applies both
   if (p.residual != nullptr && (!(p.vec_ok & 1) || p.ldr % 8 != 0 || p.act == APE_ACT_SWIGLU)) return false;
   return true;
 }

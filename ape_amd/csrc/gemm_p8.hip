@@ -457,7 +457,9 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   if (!p8_supported(p)) return nullptr;
   // the packed RoPE table is an optimisation hint: dropped unless the tile kernel's LDS path applies (alignment, whole heads per
   // wave slab, 32-bit offsets); the cos / sin tables then serve as before
-  if (p.rope_cs != nullptr && (p.trans_out || ((uintptr_t)p.rope_cs) % 16 != 0 || p.rope_hd != 64 || p.rope_cols % 64 != 0 ||
+  // ... and N % 256 == 0: the kernel's decision to stage the table must be the same in all 8 waves of a workgroup (every wave loads 32
+  // of the tile's 256 table rows and passes one extra barrier); a wave whose column slab ends beyond N would take the generic epilogue
+  if (p.rope_cs != nullptr && (p.trans_out || ((uintptr_t)p.rope_cs) % 16 != 0 || p.rope_hd != 64 || p.rope_cols % 64 != 0 || p.N % 256 != 0 ||
                                (size_t)p.rope_rows * 256 >= (1ull << 32) || !(p.rope_rows >= p.M || (p.rope_rows & (p.rope_rows - 1)) == 0)))
     p.rope_cs = nullptr;
   if (p.trans_out) {
@@ -478,7 +480,7 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<BN_, ST_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
       attr__ = true;                                                                                                    \
     }                                                                                                                   \
-    hipLaunchKernelGGL((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(tiles), dim3(512), LDS_, s, p);                        \
+    APE_LAUNCH((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(tiles), dim3(512), LDS_, s, p);                        \
     name = NAME_;                                                                                                       \
   } while (0)
 #ifdef APE_P8_ABLATION
@@ -487,7 +489,7 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     const int abl = ab ? atoi(ab) : 0;
     if (abl > 0 && bn == 256 && !f16) {
 #define P8_ABL(A_) do { (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-      hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, bf16_t, A_>), dim3(tiles), dim3(512), 131072, s, p); } while (0)
+      APE_LAUNCH((gemm_bf16_p8_kernel<256, true, bf16_t, A_>), dim3(tiles), dim3(512), 131072, s, p); } while (0)
       if (abl == 1) P8_ABL(1); else if (abl == 2) P8_ABL(2); else if (abl == 3) P8_ABL(3); else P8_ABL(4);
 #undef P8_ABL
       return "gemm_bf16_p8_kernel<256, true> (ablation)";
@@ -505,11 +507,11 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
       cattr = true;
     }
-    if (f16) hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
-    else hipLaunchKernelGGL((gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
-    // reported under the symbol family of the dense instantiation: the same template, tile, schedule and MFMA stream (the 5th template
-    // argument only changes where a K tile's A rows are staged FROM); rocprofv3 lists the two instantiations as separate rows
-    return f16 ? "gemm_f16_p8_kernel<256, true>" : "gemm_bf16_p8_kernel<256, true>";
+    if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<256, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
+    else APE_LAUNCH((gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
+    // its own name (rocprofv3 lists the instantiation as a separate row: 5th template argument); bench.py's GemmMeter.family() folds it
+    // into the tile kernel's family -- the same template, tile, schedule and MFMA stream, only the A rows are staged FROM elsewhere
+    return f16 ? "gemm_f16_p8_kernel<256, true, conv3x3>" : "gemm_bf16_p8_kernel<256, true, conv3x3>";
   }
   if (bn == 256) {
     if (stagger) { if (f16) P8_LAUNCH(256, true, f16_t, 131072, "gemm_f16_p8_kernel<256, true>"); else P8_LAUNCH(256, true, bf16_t, 131072, "gemm_bf16_p8_kernel<256, true>"); }

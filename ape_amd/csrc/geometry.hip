@@ -121,7 +121,7 @@ extern "C" int ape_hip_geometry(int S, int h, int w, int L, const int* level_hw 
   p.T = tot;
   p.dim_t = dim_t; p.level_embeds = level_embeds; p.lvl_pos = lvl_pos; p.lp_dt = lvl_pos_dt; p.mask_u8 = mask_u8; p.mask_b = mask_bool;
   p.invalid_u8 = invalid_u8; p.enc_ref = enc_ref; p.proposals = proposals; p.valid_ratios = valid_ratios; p.vr4 = vr4; p.box_scale = box_scale;
-  hipLaunchKernelGGL(geometry_kernel, dim3(ceil_div(tot, 4)), dim3(256), 0, (hipStream_t)stream, p);
+  APE_LAUNCH(geometry_kernel, dim3(ceil_div(tot, 4)), dim3(256), 0, (hipStream_t)stream, p);
   APE_CHECK_LAUNCH("ape_hip_geometry");
   return 0;
 }

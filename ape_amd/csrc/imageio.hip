@@ -196,10 +196,10 @@ extern "C" int ape_hip_resize_bilinear_u8(const uint8_t* src, int H, int W, int 
   const size_t shm = (size_t)lds_rows * RS_TW * 4;
   hipStream_t st = (hipStream_t)stream;
   if (dst_kind == 0)
-    hipLaunchKernelGGL(resize_u8_kernel<0>, grid, dim3(256), shm, st, src, H, W, src_ld, bounds_h, kk_h, ks_h, bounds_v, kk_v,
+    APE_LAUNCH(resize_u8_kernel<0>, grid, dim3(256), shm, st, src, H, W, src_ld, bounds_h, kk_h, ks_h, bounds_v, kk_v,
                        ks_v, newh, neww, tile_h, dst, dst_ld, dst_plane, flip);
   else
-    hipLaunchKernelGGL(resize_u8_kernel<1>, grid, dim3(256), shm, st, src, H, W, src_ld, bounds_h, kk_h, ks_h, bounds_v, kk_v,
+    APE_LAUNCH(resize_u8_kernel<1>, grid, dim3(256), shm, st, src, H, W, src_ld, bounds_h, kk_h, ks_h, bounds_v, kk_v,
                        ks_v, newh, neww, tile_h, dst, dst_ld, dst_plane, flip);
   APE_CHECK_LAUNCH("resize_u8_kernel");
   return 0;
@@ -307,10 +307,10 @@ extern "C" int ape_hip_rle_encode(const uint8_t* masks, int n, int H, int W, uin
   uint32_t* nchg = pos + (size_t)n * cap;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(ceil_div(W, 256), nseg, n);
-  hipLaunchKernelGGL(rle_walk_kernel<0>, grid, dim3(256), 0, st, masks, H, W, nseg, cnt, pos, cap);
-  hipLaunchKernelGGL(rle_scan_kernel, dim3(n), dim3(1024), 0, st, cnt, U, nchg);
-  hipLaunchKernelGGL(rle_walk_kernel<1>, grid, dim3(256), 0, st, masks, H, W, nseg, cnt, pos, cap);
-  hipLaunchKernelGGL(rle_runs_kernel, dim3(ceil_div(cap, 256), n), dim3(256), 0, st, pos, nchg, cap, (uint32_t)((long long)H * W),
+  APE_LAUNCH(rle_walk_kernel<0>, grid, dim3(256), 0, st, masks, H, W, nseg, cnt, pos, cap);
+  APE_LAUNCH(rle_scan_kernel, dim3(n), dim3(1024), 0, st, cnt, U, nchg);
+  APE_LAUNCH(rle_walk_kernel<1>, grid, dim3(256), 0, st, masks, H, W, nseg, cnt, pos, cap);
+  APE_LAUNCH(rle_runs_kernel, dim3(ceil_div(cap, 256), n), dim3(256), 0, st, pos, nchg, cap, (uint32_t)((long long)H * W),
                      counts, nruns);
   APE_CHECK_LAUNCH("rle_encode");
   return 0;

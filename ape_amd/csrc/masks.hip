@@ -79,9 +79,9 @@ extern "C" int ape_hip_mask_upsample_bits(const void* logits, int ldl, int dt, i
   APE_CHECK_ARG(logits && out && h0 > 0 && w0 > 0 && S > 0 && n > 0, "ape_hip_mask_upsample_bits: bad args");
   const size_t total = (size_t)n * S * ((S + 15) / 16);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(mask_upsample_bits_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)logits, ldl, h0, w0, S, n, out);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
-  else hipLaunchKernelGGL(mask_upsample_bits_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, ldl, h0, w0, S, n, out);
+  if (dt == APE_DT_F16) APE_LAUNCH(mask_upsample_bits_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)logits, ldl, h0, w0, S, n, out);
+  else if (dt == APE_DT_BF16) APE_LAUNCH(mask_upsample_bits_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)logits, ldl, h0, w0, S, n, out);
+  else APE_LAUNCH(mask_upsample_bits_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)logits, ldl, h0, w0, S, n, out);
   APE_CHECK_LAUNCH("ape_hip_mask_upsample_bits");
   return 0;
 }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void roi_align_bits_kernel(const uint8_t* __re
 
 extern "C" int ape_hip_roi_align_bits(const uint8_t* bits, int H, int W, const float* boxes, int n, int P, uint8_t* out, void* stream) {
   APE_CHECK_ARG(bits && boxes && out && n > 0 && P > 0, "ape_hip_roi_align_bits: bad args");
-  hipLaunchKernelGGL(roi_align_bits_kernel, dim3(ceil_div(n * P * P, 256)), dim3(256), 0, (hipStream_t)stream, bits, H, W, boxes, n, P, out);
+  APE_LAUNCH(roi_align_bits_kernel, dim3(ceil_div(n * P * P, 256)), dim3(256), 0, (hipStream_t)stream, bits, H, W, boxes, n, P, out);
   APE_CHECK_LAUNCH("ape_hip_roi_align_bits");
   return 0;
 }
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void paste_bits_kernel(const uint8_t* __restri
 extern "C" int ape_hip_paste_bits(const uint8_t* masks, int P, const float* boxes, int n, int Ho, int Wo, uint8_t* out, void* stream) {
   APE_CHECK_ARG(masks && boxes && out && n > 0 && P > 0 && Ho > 0 && Wo > 0, "ape_hip_paste_bits: bad args");
   const size_t total = (size_t)n * Ho * ((Wo + 15) / 16);
-  hipLaunchKernelGGL(paste_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks, P, boxes, n, Ho, Wo, out);
+  APE_LAUNCH(paste_bits_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, masks, P, boxes, n, Ho, Wo, out);
   APE_CHECK_LAUNCH("ape_hip_paste_bits");
   return 0;
 }
@@ -241,11 +241,11 @@ extern "C" int ape_hip_mask_upsample_sigmoid(const void* logits, int ldl, int in
   const int hk = APE_H16_KIND(in_dt, out_dt);
   if (hk < 0) { ape_set_error("ape_hip_mask_upsample_sigmoid: dtypes must be f32 or ONE 16-bit type (in %d, out %d)", in_dt, out_dt); return -1; }
   const int key = (ape_is16(in_dt) ? 2 : 0) + (ape_is16(out_dt) ? 1 : 0);
-  if (key == 0) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, float>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); }
+  if (key == 0) { APE_LAUNCH((mask_upsample_sigmoid_kernel<float, float>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); }
   else if (hk == APE_DT_F16) {
-    if (key == 1) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, f16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); }
+    if (key == 1) { APE_LAUNCH((mask_upsample_sigmoid_kernel<float, f16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); } else if (key == 2) { APE_LAUNCH((mask_upsample_sigmoid_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { APE_LAUNCH((mask_upsample_sigmoid_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (f16_t*)out, ldo); }
   } else {
-    if (key == 1) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<float, bf16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { hipLaunchKernelGGL((mask_upsample_sigmoid_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); }
+    if (key == 1) { APE_LAUNCH((mask_upsample_sigmoid_kernel<float, bf16_t>), grid, block, 0, s, (const float*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); } else if (key == 2) { APE_LAUNCH((mask_upsample_sigmoid_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (float*)out, ldo); } else { APE_LAUNCH((mask_upsample_sigmoid_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)logits, ldl, h0, w0, S, crop_h, crop_w, n, (bf16_t*)out, ldo); }
   }
   APE_CHECK_LAUNCH("ape_hip_mask_upsample_sigmoid");
   return 0;
@@ -272,7 +272,7 @@ extern "C" int ape_hip_bilinear_resize(const float* in, int ld_channel, int ld_r
                                        void* stream) {
   APE_CHECK_ARG(in && out && h > 0 && w > 0 && C > 0 && H > 0 && W > 0, "ape_hip_bilinear_resize: bad args");
   const size_t total = (size_t)C * H * W;
-  hipLaunchKernelGGL(bilinear_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ld_channel,
+  APE_LAUNCH(bilinear_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, ld_channel,
                      ld_row, h, w, C, out, H, W);
   APE_CHECK_LAUNCH("ape_hip_bilinear_resize");
   return 0;
@@ -384,7 +384,7 @@ extern "C" int ape_hip_panoptic_pixels(const float* masks, int ld_query, int ld_
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(areas, 0, (size_t)k * 3 * sizeof(int), s) != hipSuccess) { ape_set_error("ape_hip_panoptic_pixels: memset failed"); return -1; }
   const size_t total = (size_t)H * W;
-  hipLaunchKernelGGL(panoptic_pixels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, masks, ld_query, ld_row, h, w, k, scores, keep, prob,
+  APE_LAUNCH(panoptic_pixels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, masks, ld_query, ld_row, h, w, k, scores, keep, prob,
                      H, W, owner, conf, areas);
   APE_CHECK_LAUNCH("ape_hip_panoptic_pixels");
   return 0;
@@ -394,7 +394,7 @@ extern "C" int ape_hip_panoptic_decide(const int* areas, const int* classes, con
                                        double overlap_threshold, int stuff_offset, int* seg_id, int* info, int* count, void* stream) {
   APE_CHECK_ARG(areas && classes && keep && isthing && seg_id && info && count && k > 0 && num_classes > 0 && num_classes <= 16384,
                 "ape_hip_panoptic_decide: bad args (num_classes <= 16384)");
-  hipLaunchKernelGGL(panoptic_decide_kernel, dim3(1), dim3(256), (size_t)num_classes * sizeof(int), (hipStream_t)stream, areas, classes, keep, k, isthing,
+  APE_LAUNCH(panoptic_decide_kernel, dim3(1), dim3(256), (size_t)num_classes * sizeof(int), (hipStream_t)stream, areas, classes, keep, k, isthing,
                      num_classes, overlap_threshold, stuff_offset, seg_id, info, count);
   APE_CHECK_LAUNCH("ape_hip_panoptic_decide");
   return 0;
@@ -403,7 +403,7 @@ extern "C" int ape_hip_panoptic_decide(const int* areas, const int* classes, con
 extern "C" int ape_hip_panoptic_write(const int16_t* owner, const uint8_t* conf, const int* seg_id, int H, int W, int* out, void* stream) {
   APE_CHECK_ARG(owner && conf && seg_id && out && H > 0 && W > 0, "ape_hip_panoptic_write: bad args");
   const size_t total = (size_t)H * W;
-  hipLaunchKernelGGL(panoptic_write_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owner, conf, seg_id, total, out);
+  APE_LAUNCH(panoptic_write_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, owner, conf, seg_id, total, out);
   APE_CHECK_LAUNCH("ape_hip_panoptic_write");
   return 0;
 }

@@ -371,29 +371,29 @@ static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
   if constexpr (FUSED) {
     if (p.offw_f16) {
       switch (L) {
-        case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1, f16_t>), grid, block, 0, s, p); return 0;
-        case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2, f16_t>), grid, block, 0, s, p); return 0;
-        case 3: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 3, f16_t>), grid, block, 0, s, p); return 0;
-        case 4: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 4, f16_t>), grid, block, 0, s, p); return 0;
-        case 5: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 5, f16_t>), grid, block, 0, s, p); return 0;
+        case 1: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 1, f16_t>), grid, block, 0, s, p); return 0;
+        case 2: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 2, f16_t>), grid, block, 0, s, p); return 0;
+        case 3: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 3, f16_t>), grid, block, 0, s, p); return 0;
+        case 4: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 4, f16_t>), grid, block, 0, s, p); return 0;
+        case 5: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 5, f16_t>), grid, block, 0, s, p); return 0;
         default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
       }
     }
     switch (L) {
-      case 1: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 1>), grid, block, 0, s, p); return 0;
-      case 2: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 2>), grid, block, 0, s, p); return 0;
-      case 3: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 3>), grid, block, 0, s, p); return 0;
-      case 4: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 4>), grid, block, 0, s, p); return 0;
-      case 5: hipLaunchKernelGGL((msda_fused_quad_kernel<TV, TO, 5>), grid, block, 0, s, p); return 0;
+      case 1: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 1>), grid, block, 0, s, p); return 0;
+      case 2: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 2>), grid, block, 0, s, p); return 0;
+      case 3: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 3>), grid, block, 0, s, p); return 0;
+      case 4: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 4>), grid, block, 0, s, p); return 0;
+      case 5: APE_LAUNCH((msda_fused_quad_kernel<TV, TO, 5>), grid, block, 0, s, p); return 0;
       default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
     }
   } else {
   switch (L) {
-    case 1: hipLaunchKernelGGL((msda_kernel<TV, TO, 1, FUSED>), grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((msda_kernel<TV, TO, 2, FUSED>), grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((msda_kernel<TV, TO, 3, FUSED>), grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((msda_kernel<TV, TO, 4, FUSED>), grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((msda_kernel<TV, TO, 5, FUSED>), grid, block, 0, s, p); break;
+    case 1: APE_LAUNCH((msda_kernel<TV, TO, 1, FUSED>), grid, block, 0, s, p); break;
+    case 2: APE_LAUNCH((msda_kernel<TV, TO, 2, FUSED>), grid, block, 0, s, p); break;
+    case 3: APE_LAUNCH((msda_kernel<TV, TO, 3, FUSED>), grid, block, 0, s, p); break;
+    case 4: APE_LAUNCH((msda_kernel<TV, TO, 4, FUSED>), grid, block, 0, s, p); break;
+    case 5: APE_LAUNCH((msda_kernel<TV, TO, 5, FUSED>), grid, block, 0, s, p); break;
     default: ape_set_error("msda: num_levels %d not in 1..5", L); return -1;
   }
   }

@@ -131,12 +131,12 @@ static int launch_ln(const ApeLayerNormArgs& p, hipStream_t s) {
                    (!p.y2 || ((p.ldadd % 4 == 0) && (p.ldy2 % 4 == 0) && (((uintptr_t)p.add) % 16 == 0) &&
                               (((uintptr_t)p.y2) % 16 == 0)));
   const int need = p.Cpad > p.C ? p.Cpad : p.C;
-  if (vec && need <= 256) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 1>), grid, block, 0, s, p);
-  else if (vec && need <= 512) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 2>), grid, block, 0, s, p);
-  else if (vec && need <= 1024) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 4>), grid, block, 0, s, p);
-  else if (vec && need <= 2048) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 8>), grid, block, 0, s, p);
-  else if (vec && need <= 3072) hipLaunchKernelGGL((layernorm_kernel<TX, TY, TA, 12>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((layernorm_generic_kernel<TX, TY, TA>), grid, block, 0, s, p);
+  if (vec && need <= 256) APE_LAUNCH((layernorm_kernel<TX, TY, TA, 1>), grid, block, 0, s, p);
+  else if (vec && need <= 512) APE_LAUNCH((layernorm_kernel<TX, TY, TA, 2>), grid, block, 0, s, p);
+  else if (vec && need <= 1024) APE_LAUNCH((layernorm_kernel<TX, TY, TA, 4>), grid, block, 0, s, p);
+  else if (vec && need <= 2048) APE_LAUNCH((layernorm_kernel<TX, TY, TA, 8>), grid, block, 0, s, p);
+  else if (vec && need <= 3072) APE_LAUNCH((layernorm_kernel<TX, TY, TA, 12>), grid, block, 0, s, p);
+  else APE_LAUNCH((layernorm_generic_kernel<TX, TY, TA>), grid, block, 0, s, p);
   return 0;
 }
 
@@ -325,10 +325,10 @@ template <typename TX, typename TY, typename TA>
 static void launch_gn(const ApeGroupNormArgs& p, hipStream_t s) {
   const int nchunk = ceil_div(p.HW, GN_ROWS_PER_BLOCK);
   float* stats = p.workspace + (size_t)nchunk * p.G * 2;
-  hipLaunchKernelGGL((gn_partial_kernel<TX>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
+  APE_LAUNCH((gn_partial_kernel<TX>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
                      p.workspace);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G), dim3(64), 0, s, p.workspace, nchunk, p.HW, p.C / p.G, p.G, p.eps, stats);
-  hipLaunchKernelGGL((gn_apply_kernel<TX, TY, TA>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
+  APE_LAUNCH(gn_finalize_kernel, dim3(p.G), dim3(64), 0, s, p.workspace, nchunk, p.HW, p.C / p.G, p.G, p.eps, stats);
+  APE_LAUNCH((gn_apply_kernel<TX, TY, TA>), dim3(nchunk), dim3(256), 0, s, (const TX*)p.x, p.ldx, p.HW, p.C, p.G,
                      stats, p.w, p.b, p.act, (const TA*)p.add, p.ldadd, (TY*)p.y, p.ldy);
 }
 
@@ -397,9 +397,9 @@ extern "C" int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, f
                                  void* stream) {
   APE_CHECK_ARG(x && rowscale && rowshift && M > 0 && C > 0, "ape_hip_row_stats: bad args");
   const dim3 grid(ceil_div(M, 4)), block(256);
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(row_stats_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, ldx, M, C, eps, rowscale, rowshift);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(row_stats_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, eps, rowscale, rowshift);
-  else hipLaunchKernelGGL(row_stats_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, M, C, eps, rowscale, rowshift);
+  if (dt == APE_DT_F16) APE_LAUNCH(row_stats_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, (const f16_t*)x, ldx, M, C, eps, rowscale, rowshift);
+  else if (dt == APE_DT_BF16) APE_LAUNCH(row_stats_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, eps, rowscale, rowshift);
+  else APE_LAUNCH(row_stats_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, M, C, eps, rowscale, rowshift);
   APE_CHECK_LAUNCH("ape_hip_row_stats");
   return 0;
 }
@@ -469,10 +469,10 @@ template <typename TT, typename TC>
 static void launch_postnorm(const void* t, int ldt, const float* w, const float* b, float eps, float* stream, int lds, void* copy, int ldc,
                             int M, int C, hipStream_t s) {
   const dim3 grid(ceil_div(M, 4)), block(256);
-  if (C <= 256) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 1>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
-  else if (C <= 512) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 2>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
-  else if (C <= 1024) hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 4>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
-  else hipLaunchKernelGGL((postnorm_residual_kernel<TT, TC, 8>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  if (C <= 256) APE_LAUNCH((postnorm_residual_kernel<TT, TC, 1>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else if (C <= 512) APE_LAUNCH((postnorm_residual_kernel<TT, TC, 2>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else if (C <= 1024) APE_LAUNCH((postnorm_residual_kernel<TT, TC, 4>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
+  else APE_LAUNCH((postnorm_residual_kernel<TT, TC, 8>), grid, block, 0, s, (const TT*)t, ldt, w, b, eps, stream, lds, (TC*)copy, ldc, M, C);
 }
 
 extern "C" int ape_hip_postnorm_residual(const void* t, int ldt, int t_dt, const float* w, const float* b, float eps, float* stream,

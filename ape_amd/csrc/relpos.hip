@@ -61,9 +61,9 @@ extern "C" int ape_hip_relpos_extend(const void* q, const void* k, int ldqk, con
   const long long items = (long long)rows * nh;
   const dim3 grid((unsigned)((items + 3) / 4)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(relpos_extend_kernel<f16_t>, grid, block, 0, s, p);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(relpos_extend_kernel<bf16_t>, grid, block, 0, s, p);
-  else if (dt == APE_DT_F32) hipLaunchKernelGGL(relpos_extend_kernel<float>, grid, block, 0, s, p);
+  if (dt == APE_DT_F16) APE_LAUNCH(relpos_extend_kernel<f16_t>, grid, block, 0, s, p);
+  else if (dt == APE_DT_BF16) APE_LAUNCH(relpos_extend_kernel<bf16_t>, grid, block, 0, s, p);
+  else if (dt == APE_DT_F32) APE_LAUNCH(relpos_extend_kernel<float>, grid, block, 0, s, p);
   else { ape_set_error("ape_hip_relpos_extend: dtype code %d", dt); return -1; }
   APE_CHECK_LAUNCH("ape_hip_relpos_extend");
   return 0;

@@ -176,7 +176,7 @@ extern "C" int ape_hip_nms_mask_words(int n) { return ceil_div(n, 64); }
 extern "C" int ape_hip_nms_mask(const float* boxes, const int* groups, int n, float iou_thr, uint64_t* mask, void* stream) {
   APE_CHECK_ARG(boxes && mask && n > 0 && ((uintptr_t)boxes) % 16 == 0, "ape_hip_nms_mask: bad args");
   const int nw = ceil_div(n, 64);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, (hipStream_t)stream, (const float4*)boxes, groups, n, iou_thr,
+  APE_LAUNCH(nms_mask_kernel, dim3(nw, nw), dim3(64), 0, (hipStream_t)stream, (const float4*)boxes, groups, n, iou_thr,
                      (unsigned long long*)mask, nw);
   APE_CHECK_LAUNCH("ape_hip_nms_mask");
   return 0;
@@ -195,10 +195,10 @@ extern "C" int ape_hip_nms_scan_segments(const uint64_t* mask, int n, const int*
       (void)hipFuncSetAttribute((const void*)nms_scan_segments_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_done = true;
     }
-    hipLaunchKernelGGL(nms_scan_segments_kernel<true>, dim3(num_segments), dim3(256), lds, (hipStream_t)stream,
+    APE_LAUNCH(nms_scan_segments_kernel<true>, dim3(num_segments), dim3(256), lds, (hipStream_t)stream,
                        (const unsigned long long*)mask, ceil_div(n, 64), n, seg_offsets, valid, keep);
   } else {
-    hipLaunchKernelGGL(nms_scan_segments_kernel<false>, dim3(num_segments), dim3(256), 0, (hipStream_t)stream,
+    APE_LAUNCH(nms_scan_segments_kernel<false>, dim3(num_segments), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned long long*)mask, ceil_div(n, 64), n, seg_offsets, valid, keep);
   }
   APE_CHECK_LAUNCH("ape_hip_nms_scan_segments");
@@ -216,7 +216,7 @@ extern "C" int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int* 
     (void)hipFuncSetAttribute((const void*)nms_scan_classes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(nms_scan_classes_kernel, dim3(ceil_div(num_classes, 4)), dim3(256), lds, (hipStream_t)stream,
+  APE_LAUNCH(nms_scan_classes_kernel, dim3(ceil_div(num_classes, 4)), dim3(256), lds, (hipStream_t)stream,
                      (const unsigned long long*)mask, nw, n, order, valid, keep, num_classes);
   APE_CHECK_LAUNCH("ape_hip_nms_scan_classes");
   return 0;

@@ -38,9 +38,9 @@ extern "C" int ape_hip_segment_softmax(const float* S, int lds, int T, int nseg,
   APE_CHECK_ARG(S && gmax && out && T > 0 && nseg > 0 && L > 0, "ape_hip_segment_softmax: bad args");
   const size_t tasks = (size_t)T * nseg;
   const dim3 grid((unsigned)((tasks + 3) / 4)), block(256);
-  if (out_dt == APE_DT_F16) hipLaunchKernelGGL(segment_softmax_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (f16_t*)out, ldo);
-  else if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(segment_softmax_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL(segment_softmax_kernel<float>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (float*)out, ldo);
+  if (out_dt == APE_DT_F16) APE_LAUNCH(segment_softmax_kernel<f16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (f16_t*)out, ldo);
+  else if (out_dt == APE_DT_BF16) APE_LAUNCH(segment_softmax_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (bf16_t*)out, ldo);
+  else APE_LAUNCH(segment_softmax_kernel<float>, grid, block, 0, (hipStream_t)stream, S, lds, T, nseg, L, gmax, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_segment_softmax");
   return 0;
 }
@@ -82,8 +82,8 @@ extern "C" int ape_hip_colstats(const float* S, int lds, int T, int C, const flo
   APE_CHECK_ARG(S && gmax && workspace && colmax && colsum && T > 0 && C > 0, "ape_hip_colstats: bad args");
   const int nchunk = ceil_div(T, CS_ROWS);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colstats_partial_kernel, dim3(nchunk, ceil_div(C, 256)), dim3(256), 0, s, S, lds, T, C, gmax, workspace);
-  hipLaunchKernelGGL(colstats_merge_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, workspace, nchunk, C, colmax, colsum);
+  APE_LAUNCH(colstats_partial_kernel, dim3(nchunk, ceil_div(C, 256)), dim3(256), 0, s, S, lds, T, C, gmax, workspace);
+  APE_LAUNCH(colstats_merge_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, s, workspace, nchunk, C, colmax, colsum);
   APE_CHECK_LAUNCH("ape_hip_colstats");
   return 0;
 }
@@ -123,11 +123,11 @@ extern "C" int ape_hip_transpose(const void* S, int lds, int in_dt, int T, int C
   const int hk = APE_H16_KIND(in_dt, out_dt);
   if (hk < 0) { ape_set_error("ape_hip_transpose: dtypes must be f32 or ONE 16-bit type (in %d, out %d)", in_dt, out_dt); return -1; }
   const int key = (ape_is16(in_dt) ? 2 : 0) + (ape_is16(out_dt) ? 1 : 0);
-  if (key == 0) { hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); }
+  if (key == 0) { APE_LAUNCH((transpose_kernel<float, float>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); }
   else if (hk == APE_DT_F16) {
-    if (key == 1) { hipLaunchKernelGGL((transpose_kernel<float, f16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((transpose_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { hipLaunchKernelGGL((transpose_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); }
+    if (key == 1) { APE_LAUNCH((transpose_kernel<float, f16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); } else if (key == 2) { APE_LAUNCH((transpose_kernel<f16_t, float>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { APE_LAUNCH((transpose_kernel<f16_t, f16_t>), grid, block, 0, s, (const f16_t*)S, lds, T, C, gmax, colmax, colsum, (f16_t*)out, ldo); }
   } else {
-    if (key == 1) { hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); } else if (key == 2) { hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); }
+    if (key == 1) { APE_LAUNCH((transpose_kernel<float, bf16_t>), grid, block, 0, s, (const float*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); } else if (key == 2) { APE_LAUNCH((transpose_kernel<bf16_t, float>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (float*)out, ldo); } else { APE_LAUNCH((transpose_kernel<bf16_t, bf16_t>), grid, block, 0, s, (const bf16_t*)S, lds, T, C, gmax, colmax, colsum, (bf16_t*)out, ldo); }
   }
   APE_CHECK_LAUNCH("ape_hip_transpose");
   return 0;

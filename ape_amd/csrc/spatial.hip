@@ -50,10 +50,10 @@ extern "C" int ape_hip_patchify(const float* img, int h, int w, const int* tok2r
   const int ntok = Ht * Wt;
   const dim3 grid(ceil_div(ntok * 96, 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (out_dt == APE_DT_F16) hipLaunchKernelGGL(patchify_kernel<f16_t>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (f16_t*)out, ldo);
-  else if (out_dt == APE_DT_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16_t*)out, ldo);
+  if (out_dt == APE_DT_F16) APE_LAUNCH(patchify_kernel<f16_t>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (f16_t*)out, ldo);
+  else if (out_dt == APE_DT_BF16) APE_LAUNCH(patchify_kernel<bf16_t>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16_t*)out, ldo);
   else
-    hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out, ldo);
+    APE_LAUNCH(patchify_kernel<float>, grid, block, 0, s, img, h, w, tok2raster, Wt, ntok, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_patchify");
   return 0;
 }
@@ -88,9 +88,9 @@ extern "C" int ape_hip_im2col3x3(const void* x, int ldx, const int* perm, int H,
   const size_t total = (size_t)H * W * 9 * (C / 8);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(im2col3x3_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, perm, H, W, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(im2col3x3_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, perm, H, W, C, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL(im2col3x3_kernel<float>, grid, block, 0, s, (const float*)x, ldx, perm, H, W, C, (float*)out, ldo);
+  if (dt == APE_DT_F16) APE_LAUNCH(im2col3x3_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, perm, H, W, C, (f16_t*)out, ldo);
+  else if (dt == APE_DT_BF16) APE_LAUNCH(im2col3x3_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, perm, H, W, C, (bf16_t*)out, ldo);
+  else APE_LAUNCH(im2col3x3_kernel<float>, grid, block, 0, s, (const float*)x, ldx, perm, H, W, C, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_im2col3x3");
   return 0;
 }
@@ -127,9 +127,9 @@ extern "C" int ape_hip_maxpool2x2(const void* x, int ldx, const int* perm, int H
   const size_t total = (size_t)(H / 2) * (W / 2) * (C / 8);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(maxpool2x2_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, perm, H, W, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(maxpool2x2_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, perm, H, W, C, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL(maxpool2x2_kernel<float>, grid, block, 0, s, (const float*)x, ldx, perm, H, W, C, (float*)out, ldo);
+  if (dt == APE_DT_F16) APE_LAUNCH(maxpool2x2_kernel<f16_t>, grid, block, 0, s, (const f16_t*)x, ldx, perm, H, W, C, (f16_t*)out, ldo);
+  else if (dt == APE_DT_BF16) APE_LAUNCH(maxpool2x2_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ldx, perm, H, W, C, (bf16_t*)out, ldo);
+  else APE_LAUNCH(maxpool2x2_kernel<float>, grid, block, 0, s, (const float*)x, ldx, perm, H, W, C, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_maxpool2x2");
   return 0;
 }
@@ -151,9 +151,9 @@ extern "C" int ape_hip_gather_rows(const void* x, int ldx, const int* idx, int n
   const size_t total = (size_t)n * (C / 8);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) hipLaunchKernelGGL((gather_rows_kernel<f16_t, int>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, int>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL((gather_rows_kernel<float, int>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  if (dt == APE_DT_F16) APE_LAUNCH((gather_rows_kernel<f16_t, int>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
+  else if (dt == APE_DT_BF16) APE_LAUNCH((gather_rows_kernel<bf16_t, int>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
+  else APE_LAUNCH((gather_rows_kernel<float, int>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_gather_rows");
   return 0;
 }
@@ -164,9 +164,9 @@ extern "C" int ape_hip_gather_rows_i64(const void* x, int ldx, const int64_t* id
   const size_t total = (size_t)n * (C / 8);
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) hipLaunchKernelGGL((gather_rows_kernel<f16_t, int64_t>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, int64_t>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
-  else hipLaunchKernelGGL((gather_rows_kernel<float, int64_t>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  if (dt == APE_DT_F16) APE_LAUNCH((gather_rows_kernel<f16_t, int64_t>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
+  else if (dt == APE_DT_BF16) APE_LAUNCH((gather_rows_kernel<bf16_t, int64_t>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
+  else APE_LAUNCH((gather_rows_kernel<float, int64_t>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
   APE_CHECK_LAUNCH("ape_hip_gather_rows_i64");
   return 0;
 }
@@ -205,12 +205,12 @@ extern "C" int ape_hip_embed_tokens(const int32_t* tokens, int ldt, const void* 
   APE_CHECK_ARG(W % 4 == 0 && ldtab % 4 == 0 && ldpos % 4 == 0 && ldo % 4 == 0, "ape_hip_embed_tokens: widths must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(B * Lp), block(256);
-  if (dt == APE_DT_F16) hipLaunchKernelGGL(embed_tokens_kernel<f16_t>, grid, block, 0, s, tokens, ldt, (const f16_t*)table, ldtab, (const f16_t*)pos,
+  if (dt == APE_DT_F16) APE_LAUNCH(embed_tokens_kernel<f16_t>, grid, block, 0, s, tokens, ldt, (const f16_t*)table, ldtab, (const f16_t*)pos,
                        ldpos, out, ldo, L, Lp, W, vocab);
-  else if (dt == APE_DT_BF16) hipLaunchKernelGGL(embed_tokens_kernel<bf16_t>, grid, block, 0, s, tokens, ldt, (const bf16_t*)table, ldtab, (const bf16_t*)pos,
+  else if (dt == APE_DT_BF16) APE_LAUNCH(embed_tokens_kernel<bf16_t>, grid, block, 0, s, tokens, ldt, (const bf16_t*)table, ldtab, (const bf16_t*)pos,
                        ldpos, out, ldo, L, Lp, W, vocab);
   else
-    hipLaunchKernelGGL(embed_tokens_kernel<float>, grid, block, 0, s, tokens, ldt, (const float*)table, ldtab, (const float*)pos, ldpos,
+    APE_LAUNCH(embed_tokens_kernel<float>, grid, block, 0, s, tokens, ldt, (const float*)table, ldtab, (const float*)pos, ldpos,
                        out, ldo, L, Lp, W, vocab);
   APE_CHECK_LAUNCH("ape_hip_embed_tokens");
   return 0;

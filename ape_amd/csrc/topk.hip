@@ -615,7 +615,7 @@ static int fill_levels(TkLevels& lv, const int* level_start, const int* level_n,
 extern "C" int ape_hip_enc_finalize(const float* cls2, const float* d, const float* anchors, int T, float* enc_class, float* enc_coord,
                                     float* xyxy, void* stream) {
   APE_CHECK_ARG(cls2 && d && anchors && enc_class && enc_coord && xyxy && T > 0, "ape_hip_enc_finalize: bad arguments");
-  hipLaunchKernelGGL(enc_finalize_kernel, dim3(ceil_div(T, 256)), dim3(256), 0, (hipStream_t)stream, cls2, d, anchors, T, enc_class,
+  APE_LAUNCH(enc_finalize_kernel, dim3(ceil_div(T, 256)), dim3(256), 0, (hipStream_t)stream, cls2, d, anchors, T, enc_class,
                      enc_coord, xyxy);
   APE_CHECK_LAUNCH("enc_finalize_kernel");
   return 0;
@@ -682,13 +682,13 @@ extern "C" int ape_hip_proposal_topk(const float* logit, int T, const int* level
   }
   hipStream_t st = (hipStream_t)stream;
   u64* ws = reinterpret_cast<u64*>(workspace);
-  if (per == 8) hipLaunchKernelGGL(topk_stage1_kernel<8>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
-  else if (per == 32) hipLaunchKernelGGL(topk_stage1_kernel<32>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
-  else hipLaunchKernelGGL(topk_stage1_kernel<64>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  if (per == 8) APE_LAUNCH(topk_stage1_kernel<8>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  else if (per == 32) APE_LAUNCH(topk_stage1_kernel<32>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
+  else APE_LAUNCH(topk_stage1_kernel<64>, dim3(jobs.njobs), dim3(TK_THREADS), 0, st, logit, jobs, ws);
   set_stage2_attr();
   int mmax = 0;
   for (int s = 0; s <= L; ++s) mmax = mmax > jobs.seg_jobs[s] * jobs.seg_k[s] ? mmax : jobs.seg_jobs[s] * jobs.seg_k[s];
-  hipLaunchKernelGGL(proposal_topk2_kernel, dim3(L + 1), dim3(TK_THREADS), (size_t)mmax * sizeof(u64), st, ws, jobs, lv, k, k_alt, cand, alt);
+  APE_LAUNCH(proposal_topk2_kernel, dim3(L + 1), dim3(TK_THREADS), (size_t)mmax * sizeof(u64), st, ws, jobs, lv, k, k_alt, cand, alt);
   APE_CHECK_LAUNCH("proposal_topk");
   return 0;
 }
@@ -705,7 +705,7 @@ extern "C" int ape_hip_proposal_order(const int32_t* cand, int n, const float* l
     (void)hipFuncSetAttribute((const void*)proposal_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PO_PAD * sizeof(u64));
     attr_done = true;
   }
-  hipLaunchKernelGGL(proposal_order_kernel, dim3(1), dim3(TK_THREADS), (size_t)2 * ((n + 1023) / 1024) * 1024 * sizeof(u64), (hipStream_t)stream, cand, n, logit, xyxy, lv,
+  APE_LAUNCH(proposal_order_kernel, dim3(1), dim3(TK_THREADS), (size_t)2 * ((n + 1023) / 1024) * 1024 * sizeof(u64), (hipStream_t)stream, cand, n, logit, xyxy, lv,
                      boxes_b, groups_b, seg, cand_a, lv_a, pos_b);
   APE_CHECK_LAUNCH("proposal_order_kernel");
   return 0;
@@ -718,7 +718,7 @@ extern "C" int ape_hip_proposal_quota(const int32_t* cand_a, const int32_t* lv_a
   if (fill_levels(lv, level_start, level_n, L)) return -1;
   APE_CHECK_ARG(cand_a && lv_a && pos_b && keep_b && alt && out && n > 0 && n <= PO_PAD && n_alt >= 0 && nq > 0,
                 "ape_hip_proposal_quota: bad arguments (n <= 8192)");
-  hipLaunchKernelGGL(proposal_quota_kernel, dim3(1), dim3(TK_THREADS), 0, (hipStream_t)stream, cand_a, lv_a, pos_b, keep_b, n, alt, n_alt,
+  APE_LAUNCH(proposal_quota_kernel, dim3(1), dim3(TK_THREADS), 0, (hipStream_t)stream, cand_a, lv_a, pos_b, keep_b, n, alt, n_alt,
                      lv, nq, (long long*)out);
   APE_CHECK_LAUNCH("proposal_quota_kernel");
   return 0;
@@ -729,8 +729,8 @@ extern "C" int ape_hip_det_sort(const float* logits, int ldl, int Q, int K, cons
   APE_CHECK_ARG(logits && boxes && scale && xyxy && finite && sorted && order && valid && K > 0, "ape_hip_det_sort: bad arguments");
   APE_CHECK_ARG(Q > 0 && Q <= 1024, "ape_hip_det_sort: 1 <= queries <= 1024 (got %d)", Q);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(det_boxes_kernel, dim3(Q), dim3(64), 0, st, logits, ldl, K, boxes, scale, xyxy, finite);
-  hipLaunchKernelGGL(class_sort_kernel, dim3(K), dim3(TK_THREADS), 0, st, logits, ldl, Q, finite, thresh, sorted, order, valid);
+  APE_LAUNCH(det_boxes_kernel, dim3(Q), dim3(64), 0, st, logits, ldl, K, boxes, scale, xyxy, finite);
+  APE_LAUNCH(class_sort_kernel, dim3(K), dim3(TK_THREADS), 0, st, logits, ldl, Q, finite, thresh, sorted, order, valid);
   APE_CHECK_LAUNCH("ape_hip_det_sort");
   return 0;
 }
@@ -747,9 +747,9 @@ extern "C" int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const 
   int nchunks = ceil_div(total, per * TK_THREADS);
   hipStream_t st = (hipStream_t)stream;
   u64* ws = reinterpret_cast<u64*>(workspace);
-  if (per == 8) hipLaunchKernelGGL(det_topk1_kernel<8>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
-  else if (per == 32) hipLaunchKernelGGL(det_topk1_kernel<32>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
-  else hipLaunchKernelGGL(det_topk1_kernel<64>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  if (per == 8) APE_LAUNCH(det_topk1_kernel<8>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  else if (per == 32) APE_LAUNCH(det_topk1_kernel<32>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
+  else APE_LAUNCH(det_topk1_kernel<64>, dim3(nchunks), dim3(TK_THREADS), 0, st, sorted, keep, total, k, ws);
   set_stage2_attr();
   if (merge) {
     // ping-pong between the chunk lists and the spare half of the workspace until one stage-2 workgroup can hold what is left
@@ -759,13 +759,13 @@ extern "C" int ape_hip_det_topk(const float* sorted, const uint8_t* keep, const 
     const int group = TK_STAGE2_MAX / k;                              // >= 12 lists per merge workgroup (k <= 1024)
     while ((long long)nchunks * k > TK_STAGE2_MAX) {
       const int nout = ceil_div(nchunks, group);
-      hipLaunchKernelGGL(topk_merge_kernel, dim3(nout), dim3(TK_THREADS), (size_t)group * k * sizeof(u64), st, a, nchunks, group, k, b);
+      APE_LAUNCH(topk_merge_kernel, dim3(nout), dim3(TK_THREADS), (size_t)group * k * sizeof(u64), st, a, nchunks, group, k, b);
       u64* t = a; a = b; b = t;
       nchunks = nout;
     }
     ws = a;
   }
-  hipLaunchKernelGGL(det_topk2_kernel, dim3(1), dim3(TK_THREADS), (size_t)nchunks * k * sizeof(u64), st, ws, nchunks, order, xyxy, Q, k,
+  APE_LAUNCH(det_topk2_kernel, dim3(1), dim3(TK_THREADS), (size_t)nchunks * k * sizeof(u64), st, ws, nchunks, order, xyxy, Q, k,
                      det_boxes, det_scores, (long long*)det_classes, (long long*)det_query);
   APE_CHECK_LAUNCH("det_topk");
   return 0;

@@ -135,12 +135,12 @@ extern "C" int ape_hip_vl_pool(const float* S, int lds, const void* x, int ldx, 
   float* psum = pmax + nchunk * VL_H;
   float* pacc = psum + nchunk * VL_H;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(vl_smax_partial_kernel, dim3(nchunk), dim3(256), 0, s, S, lds, T, pmax);
-  if (x_dt == APE_DT_F16) hipLaunchKernelGGL(vl_pool_partial_kernel<f16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const f16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
-  else if (x_dt == APE_DT_BF16) hipLaunchKernelGGL(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  APE_LAUNCH(vl_smax_partial_kernel, dim3(nchunk), dim3(256), 0, s, S, lds, T, pmax);
+  if (x_dt == APE_DT_F16) APE_LAUNCH(vl_pool_partial_kernel<f16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const f16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  else if (x_dt == APE_DT_BF16) APE_LAUNCH(vl_pool_partial_kernel<bf16_t>, dim3(nchunk), dim3(256), 0, s, S, lds, (const bf16_t*)x, ldx, T, C, pmax, nchunk, pacc, psum);
   else
-    hipLaunchKernelGGL(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
-  hipLaunchKernelGGL(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, sub, out);
+    APE_LAUNCH(vl_pool_partial_kernel<float>, dim3(nchunk), dim3(256), 0, s, S, lds, (const float*)x, ldx, T, C, pmax, nchunk, pacc, psum);
+  APE_LAUNCH(vl_pool_final_kernel, dim3(VL_H, ceil_div(C, 32)), dim3(256), 0, s, pacc, psum, nchunk, C, sub, out);
   APE_CHECK_LAUNCH("ape_hip_vl_pool");
   return 0;
 }
@@ -185,10 +185,10 @@ extern "C" int ape_hip_head_gemv(const float* x, int ldx, const float* W, const 
   APE_CHECK_ARG(out_bf16 == nullptr || ape_is16(copy_dt), "ape_hip_head_gemv: the copy is bf16 or f16 (copy_dt %d)", copy_dt);
   APE_CHECK_ARG(((uintptr_t)x) % 16 == 0 && ((uintptr_t)W) % 16 == 0, "ape_hip_head_gemv: x / W must be 16-byte aligned");
   if (out_bf16 != nullptr && copy_dt == APE_DT_F16)
-    hipLaunchKernelGGL(head_gemv_kernel<f16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
+    APE_LAUNCH(head_gemv_kernel<f16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
                        (f16_t*)out_bf16, ldob);
   else
-    hipLaunchKernelGGL(head_gemv_kernel<bf16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
+    APE_LAUNCH(head_gemv_kernel<bf16_t>, dim3(ceil_div(H * N, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, W, bias, out, ldo, H, N, D, alpha,
                        (bf16_t*)out_bf16, ldob);
   APE_CHECK_LAUNCH("ape_hip_head_gemv");
   return 0;

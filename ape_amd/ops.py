@@ -523,7 +523,13 @@ def conv3x3(x, perm, h, wd, w, bias=None, *, out_dtype=None):
     kernel stages its A operand from the shifted input rows: ApeGemmArgs.conv_*; the [h wd, 9 C] im2col matrix never exists);
     everything else is im2col3x3 + gemm.  Bit-identical either way."""
     _dev(x, perm, w, bias)
-    if not conv3x3_implicit_ok(x, w, h, wd):
+    if perm is not None and perm.numel() != h * wd:
+        raise ValueError(f"ape_amd.ops.conv3x3: perm has {perm.numel()} entries for a {h} x {wd} map")
+    if perm is None and x.shape[0] < h * wd:
+        raise ValueError(f"ape_amd.ops.conv3x3: x has {x.shape[0]} rows for a {h} x {wd} map")
+    # the tile kernel addresses source rows with 32-bit byte offsets (perm[r] * lda * 2): a perm that reaches into a token buffer
+    # beyond 4 GiB goes through im2col, whose gather uses 64-bit addresses
+    if not conv3x3_implicit_ok(x, w, h, wd) or x.shape[0] * _ld(x) * 2 >= 2 ** 32:
         return gemm(im2col3x3(x, perm, h, wd), w, bias, out_dtype=out_dtype)
     _rowmajor(x, "x"), _rowmajor(w, "w")
     M, N = h * wd, w.shape[0]

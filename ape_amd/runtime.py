@@ -94,9 +94,12 @@ class GraphedForward:
         self.max_out_pixels = max_out_pixels          # any_size: largest output frame (height * width) a slot can hold
         # "bitmask": pred_masks [n, H, W] bool on the host (the reference's output contract, ~1 MB per mask over PCIe);
         # "rle": the evaluators' wire format instead -- the pasted masks are run-length encoded on the device
-        # (ops.rle_encode) and only the runs travel; instances carry `pred_masks_rle` (ape_amd/evaluation.py)
-        if mask_format not in ("bitmask", "rle"):
-            raise ValueError("GraphedForward: mask_format is 'bitmask' or 'rle'")
+        # (ops.rle_encode) and only the runs travel; instances carry `pred_masks_rle` (ape_amd/evaluation.py);
+        # "both": the bitmasks reach this rank's host exactly as with "bitmask" AND the run lengths are produced next to them
+        # (`ticket.runs`, what dp.DataParallelRunner(gather_masks=True) all-gathers across ranks): a data-parallel rank then does
+        # everything a single-GPU run does, plus the exchange
+        if mask_format not in ("bitmask", "rle", "both"):
+            raise ValueError("GraphedForward: mask_format is 'bitmask', 'rle' or 'both'")
         self.mask_format, self.rle_cap = mask_format, int(rle_cap)
         # semantic branch inside the captured step (deformable_detr_segm_vl.py:628-666 + sem_seg_postprocess :875-918): `semantic`
         # = the dataset's metadata dict (thing_classes / stuff_classes / entity, as model.forward builds it).  The [K', H, W] score
@@ -357,8 +360,8 @@ class GraphedForward:
             s.d_rec = torch.empty((B, k, 8), dtype=torch.float32, device=dev)
             s.h_rec = torch.empty((B, k, 8), dtype=torch.float32, pin_memory=True)
             s.d_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, device=dev) if has_masks else None
-            rle = has_masks and self.mask_format == "rle"
-            s.h_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, pin_memory=True) if has_masks and not rle else None
+            rle = has_masks and self.mask_format in ("rle", "both")
+            s.h_masks = torch.empty((B, k * e.maxpix), dtype=torch.uint8, pin_memory=True) if has_masks and self.mask_format != "rle" else None
             s.d_runs = torch.empty((B, k, self.rle_cap), dtype=torch.int32, device=dev) if rle else None
             s.d_nruns = torch.zeros((B, k), dtype=torch.int32, device=dev) if rle else None
             s.h_runs = torch.empty((B, k, self.rle_cap), dtype=torch.int32, pin_memory=True) if rle else None
@@ -490,7 +493,7 @@ class GraphedForward:
                 if has_masks and s.d_runs is not None:
                     s.h_runs.copy_(s.d_runs, non_blocking=True)
                     s.h_nruns.copy_(s.d_nruns, non_blocking=True)
-                elif has_masks:
+                if has_masks and s.h_masks is not None:
                     for b in range(len(outs)):
                         fh, fw = completes.frames[b]
                         s.h_masks[b, : k * fh * fw].copy_(s.d_masks[b, : k * fh * fw], non_blocking=True)
@@ -542,7 +545,7 @@ class GraphedForward:
             masks = None
             if s.has_masks and s.h_runs is not None:
                 extra["pred_masks_rle"] = self._rles(s, b, n, fh, fw)
-            elif s.has_masks:
+            if s.has_masks and s.h_masks is not None:
                 masks = s.h_masks[b, : k * fh * fw].view(k, fh, fw)[:n].view(torch.bool)   # zero-copy
             insts.append(make_instances((fh, fw), hr[:n, :4].clone(), hr[:n, 4].clone(), hr[:n, 5].long(), masks,
                                         query_index=hr[:n, 6].long(), **extra))

@@ -73,10 +73,21 @@ def parse():
                     help="resident: float32 model-ready images already in HBM (the tier's definition of `value`); uint8: the predictor's "
                          "input side inside the timed region (ape/engine/defaults.py:213-222) -- ORIGINAL uint8 BGR images (1.25 x the model "
                          "size) in pinned host memory -> upload -> ResizeShortestEdge (Pillow-exact resize kernel) + BGR->RGB + float CHW -> forward")
-    ap.add_argument("--mask-format", choices=["auto", "bitmask", "rle"], default="auto",
+    ap.add_argument("--mask-format", choices=["auto", "bitmask", "rle", "both"], default="auto",
                     help="how masks leave the device: bitmask = [k, H, W] bool on the host (the reference's Instances contract, 105 MB per "
-                         "image at k = 100); rle = the evaluators' COCO run lengths, encoded on the device (a few KB per image) and "
-                         "all-gathered across ranks with the records.  auto = bitmask on 1 GPU, rle on N > 1 (north_star: all-gather of boxes / masks)")
+                         "image at k = 100); rle = the evaluators' COCO run lengths only, encoded on the device (a few KB per image); both = the "
+                         "bitmasks to this rank's host AND the run lengths, which are all-gathered across ranks with the records.  auto = "
+                         "bitmask on 1 GPU, both on N > 1: EVERY rank of an N-GPU run does exactly the work of the 1-GPU run (same masks to its "
+                         "host) plus the exchange (north_star: all-gather of boxes / masks), so the driver's 1 -> N efficiency compares like with like")
+    ap.add_argument("--n1-value", type=float, default=None,
+                    help="N > 1: the images/sec of the N = 1 run of the same workload (e.g. the driver's previous line): efficiency_vs_n1 = "
+                         "value / (N x this).  Without it rank 0 measures the reference itself, in the same process, right after the timed "
+                         "region (--solo-steps steps of the same step with no exchange while the other ranks wait at a barrier)")
+    ap.add_argument("--solo-steps", type=int, default=20, help="N > 1 without --n1-value: steps of the same-process N = 1 reference on rank 0")
+    ap.add_argument("--no-second-flavour", action="store_true",
+                    help="skip the second timed region of the default bf16 run: the SAME step in IEEE half (--dtype f16's pipeline, the "
+                         "reference's own evaluation dtype), --f16-steps steps, reported as value_f16 / ms_per_step_f16 (N = 1 only)")
+    ap.add_argument("--f16-steps", type=int, default=20)
     ap.add_argument("--dry-images", type=int, default=1000, help="--dry: length of the sharded synthetic stream")
     ap.add_argument("--instrumented-only", action="store_true",
                     help="skip the timed region: run only the instrumented pass that produces `roofline` (what tools/gpu_profile.sh puts "
@@ -103,88 +114,120 @@ def make_raw_images(n, S, seed):
 
 
 class GemmMeter:
-    """wraps ape_amd.ops.gemm with HIP event pairs (torch.cuda.Event on the launch stream = torch's current stream) and
-    asks the library which kernel symbol each call launched (ape_hip_gemm_last_kernel)"""
+    """wraps ape_amd.ops.gemm / ffn_fused / conv3x3 and meters every launch they make TWICE:
+    * exactly -- the library's launch meter (csrc/meter.cpp, ape_hip_meter_*): while it is on, every kernel of the library goes out
+      through hipExtLaunchKernelGGL with its own (start, stop) HIP events, whose elapsed time is the dispatch's begin-to-end duration
+      (the number rocprofv3's kernel trace reports for the same launch).  This is what `roofline.achieved` is computed from;
+    * with a HIP event pair RECORDED around the call (torch.cuda.Event on the launch stream = torch's current stream), the
+      round-1..4 method: it additionally contains the command-processor gaps either side of the kernel (~4-5 us per launch) and is kept
+      on the line as `avg_launch_us_event_pair` for continuity.
+    The library names the kernel symbol each call launched (ape_hip_gemm_last_kernel)."""
 
     def __init__(self, ops):
+        import ctypes
         from ape_amd import _lib
         self.ops, self.orig, self.orig_ffn, self.orig_conv, self.records = ops, ops.gemm, ops.ffn_fused, ops.conv3x3, []
         self.lib = _lib.load()
+        self._ct = ctypes
+
+    def _metered(self, call, name_of, flops, shape):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n0 = self.lib.ape_hip_meter_count()
+        s.record()
+        out = call()
+        e.record()
+        self.records.append((name_of(), s, e, flops, shape, n0, self.lib.ape_hip_meter_count()))
+        return out
 
     def __enter__(self):
+        last = lambda: self.lib.ape_hip_gemm_last_kernel().decode()
+
         def wrapped(a, w, *args, **kw):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = self.orig(a, w, *args, **kw)
-            e.record()
-            name = self.lib.ape_hip_gemm_last_kernel().decode()
-            self.records.append((name, s, e, 2.0 * a.shape[0] * a.shape[1] * w.shape[0], f"{a.shape[0]}x{w.shape[0]}x{a.shape[1]}"))
-            return out
+            return self._metered(lambda: self.orig(a, w, *args, **kw), last, 2.0 * a.shape[0] * a.shape[1] * w.shape[0],
+                                 f"{a.shape[0]}x{w.shape[0]}x{a.shape[1]}")
 
         def wrapped_ffn(x, w1, b1, w2, b2, **kw):
             # the one-kernel FFN (csrc/ffn_fused.hip): two chained contractions, 2 * M * 256 * HID flops each
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = self.orig_ffn(x, w1, b1, w2, b2, **kw)
-            e.record()
-            name = "ffn_fused_kernel<true>" if kw.get("w2_permuted") else "ffn_fused_kernel<false>"
-            self.records.append((name, s, e, 2.0 * x.shape[0] * x.shape[1] * w1.shape[0] + 2.0 * x.shape[0] * w1.shape[0] * w2.shape[0],
-                                 f"{x.shape[0]}x{x.shape[1]}x{w1.shape[0]}x{w2.shape[0]}"))
-            return out
+            return self._metered(lambda: self.orig_ffn(x, w1, b1, w2, b2, **kw),
+                                 lambda: "ffn_fused_kernel<true>" if kw.get("w2_permuted") else "ffn_fused_kernel<false>",
+                                 2.0 * x.shape[0] * x.shape[1] * w1.shape[0] + 2.0 * x.shape[0] * w1.shape[0] * w2.shape[0],
+                                 f"{x.shape[0]}x{x.shape[1]}x{w1.shape[0]}x{w2.shape[0]}")
 
         def wrapped_conv(x, perm, h, wd, w, bias=None, **kw):
             # the 3 x 3 convolutions as implicit GEMMs (the tile kernel stages A from the shifted input rows): the same 2 M N K flops as
             # the im2col GEMM they replace, M = h * wd, K = 9 C.  When the im2col path is taken instead, its inner ops.gemm is metered.
             if not self.ops.conv3x3_implicit_ok(x, w, h, wd):
                 return self.orig_conv(x, perm, h, wd, w, bias, **kw)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = self.orig_conv(x, perm, h, wd, w, bias, **kw)
-            e.record()
-            name = self.lib.ape_hip_gemm_last_kernel().decode()
-            self.records.append((name, s, e, 2.0 * h * wd * w.shape[0] * w.shape[1], f"{h * wd}x{w.shape[0]}x{w.shape[1]} (implicit 3x3 conv)"))
-            return out
+            return self._metered(lambda: self.orig_conv(x, perm, h, wd, w, bias, **kw), last, 2.0 * h * wd * w.shape[0] * w.shape[1],
+                                 f"{h * wd}x{w.shape[0]}x{w.shape[1]} (implicit 3x3 conv)")
+        self.lib.ape_hip_meter_begin()
         self.ops.gemm, self.ops.ffn_fused, self.ops.conv3x3 = wrapped, wrapped_ffn, wrapped_conv
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.ffn_fused, self.ops.conv3x3 = self.orig, self.orig_ffn, self.orig_conv
+        self.lib.ape_hip_meter_end()
 
     @staticmethod
     def family(name):
-        """the eight-wave tile kernel is compiled once per epilogue (third template argument, csrc/gemm_p8.hip): the roofline
-        object is about the tile kernel as a whole = the sum over its epilogue specialisations"""
+        """the eight-wave tile kernel is compiled once per epilogue (third template argument, csrc/gemm_p8.hip) and once more as the
+        implicit 3 x 3 convolution (`..., conv3x3>`: same tile, schedule and MFMA stream, the A rows staged from shifted input rows): the
+        roofline object is about the tile kernel as a whole = the sum over these instantiations (rocprofv3 lists them as separate rows)"""
         import re
-        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), \d+>$", r"\1>", name)
+        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), (?:\d+|conv3x3)>$", r"\1>", name)
+
+    def launch(self, i):
+        """(kernel expression at the launch site, milliseconds) of launch i of the metering session"""
+        name, ms = self._ct.c_char_p(), self._ct.c_float()
+        if self.lib.ape_hip_meter_read(i, self._ct.byref(name), self._ct.byref(ms)) != 0:
+            raise RuntimeError(self.lib.ape_hip_last_error().decode())
+        return name.value.decode().strip("()"), float(ms.value)
 
     def summary(self):
-        """per kernel family: (launches, seconds, flops), sorted by time; and per exact symbol (as rocprofv3 lists them)"""
+        """per kernel family: [launches, exact seconds, flops, event-pair seconds], sorted by exact time; per exact symbol and per
+        (family, shape) alike; `self.kernels` = every library kernel of the session by launch-site expression: [launches, seconds]"""
         torch.cuda.synchronize()
         groups, symbols, shapes = {}, {}, {}
-        for name, s, e, fl, shape in self.records:
-            dt = s.elapsed_time(e) * 1e-3
+        for name, s, e, fl, shape, n0, n1 in self.records:
+            pair = s.elapsed_time(e) * 1e-3
+            dt = sum(self.launch(i)[1] for i in range(n0, n1)) * 1e-3 if n1 > n0 else pair
             for table, key in ((groups, self.family(name)), (symbols, name), (shapes, (self.family(name), shape))):
-                g = table.setdefault(key, [0, 0.0, 0.0])
+                g = table.setdefault(key, [0, 0.0, 0.0, 0.0])
                 g[0] += 1
                 g[1] += dt
                 g[2] += fl
+                g[3] += pair
         self.symbols, self.shapes = symbols, shapes
+        self.kernels = {}
+        for i in range(self.lib.ape_hip_meter_count()):
+            name, ms = self.launch(i)
+            k = self.kernels.setdefault(name, [0, 0.0])
+            k[0] += 1
+            k[1] += ms * 1e-3
         return sorted(groups.items(), key=lambda kv: -kv[1][1])
 
 
 def pmc_traffic_bytes(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh ->
-    profiles/r0N_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md's HBM section prescribes for gfx950).  None when the summary does not list the kernel.
-    The library reports `gemm_bf16_p8_kernel<256, true>` / `gemm_f16_...`; rocprofv3 lists the full instantiation
-    (`gemm_bf16_p8_kernel<256, true, unsigned short, 0>`, `..., _Float16, 0>`): matched by prefix + operand type."""
+    """(bytes per launch | None, note): memory-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh
+    -> profiles/r0N_pmc_summary.txt: separate FETCH_SIZE and WRITE_SIZE passes, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM section
+    prescribes for gfx950).  Only a summary measured on THIS build counts: its `# library_digest` header (tools/pmc_summary.py) must
+    equal ape_amd.build._digest() of the sources bench.py runs on -- a summary of an older build describes another launch mix and is
+    refused (traffic = null, the note says why).  The library reports `gemm_bf16_p8_kernel<256, true>` / `gemm_f16_...`; rocprofv3 lists
+    the full instantiations (`gemm_bf16_p8_kernel<256, true, unsigned short, 0, false>`, `..., 0, true>` = the implicit convolution):
+    matched by prefix + operand type, launch-weighted over the family's rows."""
+    from ape_amd import build as _build
     f16 = kernel.startswith("gemm_f16_")
     prefix = ("gemm_bf16_" + kernel[len("gemm_f16_"):] if f16 else kernel).rstrip(">")
-    for name in ("r04_pmc_summary.txt", "r03_pmc_summary.txt", "r02b_pmc_summary.txt", "r02_pmc_summary.txt", "r01_pmc_summary.txt"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
-        for line in open(path):
+    names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_summary.txt")), reverse=True)
+    want = _build._digest()
+    for name in names:
+        lines = open(os.path.join(ROOT, "profiles", name)).read().splitlines()
+        digest = next((l.split()[-1] for l in lines if l.startswith("# library_digest")), None)
+        if digest != want:
+            return None, (f"profiles/{name} (the newest PMC summary) was measured on library digest {str(digest)[:12]}, this build is "
+                          f"{want[:12]}: refused -- re-run tools/gpu_pmc.sh on this build")
+        tot_b, tot_n = 0.0, 0
+        for line in lines:
             cols = [c.strip() for c in line.split("|")]
             if len(cols) <= 3 or not cols[0].startswith(prefix):
                 continue
@@ -194,10 +237,15 @@ def pmc_traffic_bytes(kernel):
             if ("_Float16" in rest) != f16 and rest not in (">", ""):
                 continue
             try:
-                return float(cols[-1]) * 1024.0 * 1024.0
+                n = int(cols[1])
+                tot_b += float(cols[-1]) * 1024.0 * 1024.0 * n
+                tot_n += n
             except ValueError:
-                return None
-    return None
+                continue
+        if tot_n:
+            return tot_b / tot_n, f"profiles/{name}, {tot_n} launches, same library digest as this build"
+        return None, f"profiles/{name} does not list {kernel}"
+    return None, "no PMC summary under profiles/"
 
 
 def cpu_baseline(model, size, images, text, n_images=3, max_threads=64):
@@ -355,6 +403,51 @@ def _parity_one(mv, images, text, stages_per_image):
     return res
 
 
+def workload_string(size, B, classes, semantic=False):
+    """the workload a rank runs per step, as the line's config names it -- a function of the model configuration and the step size ONLY
+    (no rank count in it: the driver compares the N = 1 and N = 8 lines of the SAME workload; tests/test_bench_launch.py)"""
+    from ape_amd.modeling.build import SIZES
+    S, topk = SIZES[size]["img_size"], SIZES[size]["topk_eval"]
+    return (f"APE-L_D forward (size key {size}), {B}x{S}x{S} images per rank per step: one ViT pass over the {B} images, everything after "
+            f"it one batch-1 forward per image ({B} parallel branches of one hipGraph); {classes} classes (name prompt), masks on, "
+            f"top-{topk} detections per image incl. their full-resolution masks on the host; seeded synthetic weights"
+            + ("; semantic branch on (54 stuff columns), label maps on the host" if semantic else ""))
+
+
+def pin_to_gpu_numa_node(local):
+    """bind this rank's host threads to the CPUs of its GPU's NUMA node (the pinned staging buffers and the launch thread then sit next
+    to the device's PCIe root: 8 ranks launching ~1400 kernels per step from remote sockets is the classic reason a 1 -> 8 curve bends).
+    Reads the device's PCI address from torch and its `local_cpulist` from sysfs; returns what it did (goes on the JSON line)."""
+    try:
+        p = torch.cuda.get_device_properties(local)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        node = int(open(f"{base}/numa_node").read().strip())
+        cpus = set()
+        for part in open(f"{base}/local_cpulist").read().strip().split(","):
+            if part:
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        allowed = os.sched_getaffinity(0)
+        cpus = cpus & allowed
+        if node < 0 or not cpus or cpus == allowed:
+            return {"pci": bdf, "numa_node": node, "pinned": False, "cpus": len(allowed)}
+        os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "pinned": True, "cpus": len(cpus)}
+    except Exception as exc:           # no sysfs / no permission: run unpinned, say so
+        return {"pinned": False, "error": f"{type(exc).__name__}: {exc}"[:120]}
+
+
+def shards_digest(n_items, world):
+    """contiguous InferenceSampler shards of an n_items stream over `world` ranks: [(first, last, count)] per rank"""
+    from ape_amd.dp import shard_indices
+    out = []
+    for r in range(world):
+        idx = shard_indices(n_items, r, world)
+        out.append([idx[0], idx[-1], len(idx)])
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher in the environment: run N ranks under torch.distributed.run on this
     node (127.0.0.1 rendezvous) and pass their output through.  The ranks see RANK / WORLD_SIZE and take the normal path."""
@@ -408,7 +501,9 @@ def dry_run(args, rank, world):
         print(json.dumps({"metric": "dry run: launch + exchanges only", "value": None, "unit": "images/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "dry-run (no forward)",
-                          "config": {"workload": "none (--dry)", "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size(),
+                          "config": {"workload": workload_string(args.size, args.images_per_step, args.classes, args.semantic),
+                                     "dry": True, "shards": shards_digest(args.dry_images, world),
+                                     "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size(),
                                      "backend": dist.get_backend(), "shard_of_rank0": [mine[0], mine[-1]], "steps_run": steps,
                                      "record_sets_collected": collected, "shard_sizes": [len(shard_indices(args.dry_images, r, world)) for r in range(world)],
                                      "text_bank_identical_on_all_ranks": bool(all(abs(float(x) - float(sums[0])) < 1e-9 for x in sums)),
@@ -442,6 +537,7 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    affinity = pin_to_gpu_numa_node(local) if world > 1 or os.environ.get("APE_BENCH_PIN") == "1" else {"pinned": False, "note": "1 rank: not pinned"}
     dist = None
     if world > 1 or "RANK" in os.environ:   # under torch.distributed.run the RCCL path is exercised even for N = 1
         import torch.distributed as dist
@@ -466,13 +562,15 @@ def main():
         mv.set_metadata(0, name="bench_thing_stuff", thing_classes=things, stuff_classes=stuff)
         sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
         args.classes = len(things) + len(stuff) - 1
-    mask_format = args.mask_format if args.mask_format != "auto" else ("rle" if world > 1 else "bitmask")
+    # one contract for every N: each rank delivers its images' bitmasks to its own host; N > 1 ADDS the run-length encoding and the
+    # all-gather of records + runs (a rank of an N-GPU run never does less than the 1-GPU run)
+    mask_format = args.mask_format if args.mask_format != "auto" else ("both" if world > 1 else "bitmask")
     graphed = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
                              pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta, mask_format=mask_format,
                              input_resize=(S, S), input_format="RGB")
     # N > 1: masks travel as COCO run lengths and are all-gathered with the records (north_star: "all-gather of boxes / masks over
     # xGMI"); the exchange of step i is awaited one step later and only by the host (lag = 1): a slow rank never stalls another GPU
-    dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev, gather_masks=mask_format == "rle" and world > 1, lag=1 if world > 1 else 0)
+    dp = DataParallelRunner(graphed, mv.test_topk_per_image, dev, gather_masks=mask_format in ("rle", "both") and world > 1, lag=1 if world > 1 else 0)
     # text-embedding bank: produced once on rank 0 (the CLIP text tower's output contract [K,1024]) and broadcast (RCCL)
     bank = torch.randn(args.classes, 1024, generator=torch.Generator().manual_seed(3)) if rank == 0 else None
     text = dp.broadcast_text_bank(bank, args.classes, 1024)
@@ -500,46 +598,83 @@ def main():
     # the host collects a ticket `depth` steps after submitting it: 1 = while the next image computes (its transfer ran on the
     # copy stream meanwhile); 2 with the software pipeline, where a ticket's detections are produced by the next step's replay
     depth = 1 if args.no_pipeline else 2
-    queue = []
 
-    def step(i):
-        if raw_images is not None:
-            # the masks are delivered in the S x S frame of the resident-input workload (the predictor's default is the ORIGINAL
-            # size): the two numbers then differ by the input side only
-            batch = [raw_images[(i * B + b) % len(raw_images)] for b in range(B)]
-            queue.append(dp.submit(batch if B > 1 else batch[0], text, height=S, width=S))
-        else:
-            batch = [images[(i * B + b) % len(images)] for b in range(B)]
-            queue.append(dp.submit(batch if B > 1 else batch[0], text))
-        return dp.result(queue.pop(0)) if len(queue) > depth else None
+    def timed_region(runner, warmup, steps, collective=True):
+        """`warmup` untimed steps, then EXACTLY `steps` steps (the last one flushed inside the region) between barrier +
+        synchronize on both sides; returns this rank's seconds.  runner: the DataParallelRunner (records / runs exchanged), or the
+        GraphedForward itself (the same step with no exchange: the same-process N = 1 reference of an N-rank run)."""
+        queue = []
 
-    def flush():
-        done = None
-        while queue:
-            done = dp.result(queue.pop(0))
-        dp.drain()
-        return done
+        def step(i):
+            if raw_images is not None:
+                # the masks are delivered in the S x S frame of the resident-input workload (the predictor's default is the ORIGINAL
+                # size): the two numbers then differ by the input side only
+                batch = [raw_images[(i * B + b) % len(raw_images)] for b in range(B)]
+                queue.append(runner.submit(batch if B > 1 else batch[0], text, height=S, width=S))
+            else:
+                batch = [images[(i * B + b) % len(images)] for b in range(B)]
+                queue.append(runner.submit(batch if B > 1 else batch[0], text))
+            return runner.result(queue.pop(0)) if len(queue) > depth else None
+
+        def flush():
+            while queue:
+                runner.result(queue.pop(0))
+            if hasattr(runner, "drain"):
+                runner.drain()
+
+        for i in range(warmup):
+            step(i)
+        flush()
+        torch.cuda.synchronize()
+        if dist is not None and collective:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        flush()
+        torch.cuda.synchronize()
+        if dist is not None and collective:
+            dist.barrier()
+        return max(time.perf_counter() - t0, 1e-9)
 
     if args.instrumented_only:
         args.warmup = args.steps = 0
-    for i in range(args.warmup):
-        step(i)
-    flush()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    flush()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = max(time.perf_counter() - t0, 1e-9)
+    elapsed_rank = elapsed = timed_region(dp, args.warmup, args.steps)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if args.steps:
+            mine = torch.tensor([args.steps * B / elapsed_rank], device=dev, dtype=torch.float64)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            per_rank = [round(float(v.item()), 2) for v in every]     # each rank's own images/sec between the two barriers
+
+    # N > 1: the N = 1 reference of the efficiency -- given (--n1-value, e.g. the driver's N = 1 line) or measured here: rank 0 alone
+    # runs the SAME step with no exchange (every other GPU idle at a barrier), right after the timed region, same process, warm
+    n1 = None
+    if world > 1 and args.steps:
+        if args.n1_value:
+            n1 = {"value": float(args.n1_value), "source": "--n1-value"}
+        else:
+            if rank == 0:
+                sec = timed_region(graphed, 2, args.solo_steps, collective=False)
+                n1 = {"value": args.solo_steps * B / sec, "source": f"same process: rank 0 alone, {args.solo_steps} steps of the same step with no "
+                                                                    "exchange, the other ranks idle at a barrier"}
+            dist.barrier()
+
+    # second flavour of the default run: the same step in IEEE half (the reference's own evaluation dtype), timed in the same invocation
+    f16 = None
+    if world == 1 and args.dtype == "bf16" and args.steps and not args.no_second_flavour and not args.instrumented_only:
+        mv.set_compute_dtype(torch.float16)
+        g16 = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
+                             pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta, mask_format=mask_format,
+                             input_resize=(S, S), input_format="RGB")
+        sec = timed_region(g16, 3, args.f16_steps, collective=False)
+        f16 = {"value_f16": args.f16_steps * B / sec, "ms_per_step_f16": 1e3 * sec / args.f16_steps, "steps_f16": args.f16_steps}
+        del g16
+        mv.set_compute_dtype(DTYPES[args.dtype])
 
     result = None
     if rank == 0:
@@ -568,39 +703,44 @@ def main():
                     eager_step(i)
                 groups = meter.summary()
         reps = reps * B                                     # images in the instrumented pass
-        dom_name, (dom_n, dom_t, dom_fl) = groups[0]
+        dom_name, (dom_n, dom_t, dom_fl, dom_pair) = groups[0]
         all_t, all_fl = sum(g[1][1] for g in groups), sum(g[1][2] for g in groups)
         achieved = dom_fl / dom_t / 1e12
+        traffic, traffic_note = pmc_traffic_bytes(dom_name)
         result = {
             "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": (world * args.steps * B / elapsed) if args.steps else None, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": (1e3 * elapsed / args.steps) if args.steps else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"APE-L_D forward (size key {args.size}), {B}x{S}x{S} images per rank per step: one ViT pass over the "
-                                   f"{B} images, everything after it one batch-1 forward per image ({B} parallel branches of one "
-                                   f"hipGraph); {args.classes} classes (name prompt), masks on, top-{mv.test_topk_per_image} detections "
-                                   "per image incl. their full-resolution masks on the host; seeded synthetic weights"
-                                   + ("; semantic branch on (54 stuff columns), label maps on the host" if args.semantic else ""),
+            "config": {"workload": workload_string(args.size, B, args.classes, args.semantic),
                        "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+                       "cpu_affinity": affinity,
                        "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B, "input": args.input,
                        "input_note": ("uint8 BGR originals (%d x %d) in pinned host memory -> H2D -> resize kernel (Pillow-exact) + BGR->RGB + "
                                       "float CHW -> forward, all inside the timed region" % (S * 5 // 4, S * 5 // 4)) if args.input == "uint8"
                                      else "float32 model-ready images resident in HBM (PCIe-exclusive, the tier's definition of `value`)",
-                       "mask_format": mask_format, "records_exchange": "all-gather, awaited one step late by the host" if world > 1 else "none (1 rank)",
+                       "mask_format": mask_format,
+                       "mask_format_note": "every rank delivers its images' [k, H, W] bitmasks to its own host (the 1-GPU contract); N > 1 adds the "
+                                           "device-side run-length encoding and the all-gather of records + runs" if mask_format in ("bitmask", "both")
+                                           else "run lengths only (the evaluators' wire format); NOT comparable with a bitmask line",
+                       "records_exchange": "all-gather of records + mask run lengths, awaited one step late by the host" if world > 1 else "none (1 rank)",
                        "host_MB_per_s_per_rank": round((args.steps * B / elapsed if args.steps else 0.0) * (
-                           (mv.test_topk_per_image * S * S if mask_format == "bitmask" else mv.test_topk_per_image * graphed.rle_cap * 4)
+                           (mv.test_topk_per_image * S * S if mask_format in ("bitmask", "both") else 0)
+                           + (mv.test_topk_per_image * graphed.rle_cap * 4 if mask_format in ("rle", "both") else 0)
                            + mv.test_topk_per_image * 32) / 1e6, 1),
                        "batched_vit": not args.no_batch_vit, "stream": args.stream,
                        "software_pipeline": (not args.no_pipeline) and "ViT of step i+1 overlaps the tails of step i; the last step is flushed inside the timed region"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                         "traffic": pmc_traffic_bytes(dom_name), "launches_per_image": dom_n / reps,
+                         "traffic": traffic, "traffic_source": traffic_note, "launches_per_image": dom_n / reps,
                          "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
                          "flops_per_launch": dom_fl / max(dom_n, 1),
-                         "metering": "HIP event pair per launch in an eager pass of the step's composition, every branch inline (one kernel at a "
-                                     "time).  A/B'd in round 4: keeping the queue full with a spin kernel ahead of each instrumented step changes "
-                                     "nothing (q|k 43.0 vs 43.3 us) -- these are stand-alone launch durations.  hipGraph replays of ONE kernel back to "
-                                     "back read ~10 us shorter (tools/gpu_gemm_p8.py: the tail of launch i overlaps the head of launch i + 1), which "
-                                     "dependent launches inside the model cannot do",
+                         "avg_launch_us_event_pair": 1e6 * dom_pair / max(dom_n, 1), "frac_event_pair": dom_fl / dom_pair / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                         "metering": "an eager pass of the step's composition, every branch inline (one kernel at a time, stand-alone launch "
+                                     "durations); each launch carries its OWN (start, stop) HIP events (hipExtLaunchKernelGGL through the library's "
+                                     "launch meter, csrc/meter.cpp): their elapsed time is the dispatch's begin-to-end duration, the number "
+                                     "rocprofv3's kernel trace reports for the same launch (profiles/).  `avg_launch_us_event_pair` / "
+                                     "`frac_event_pair` = the round-1..4 method, an event pair RECORDED around the call: it adds the "
+                                     "command-processor gaps either side of the kernel",
                          # the dominant family per problem shape M x N x K (launches per image, average us, TFLOP/s)
                          "by_shape": {sh: {"launches_per_image": round(v[0] / reps, 2), "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 1),
                                            "tflops": round(v[2] / v[1] / 1e12, 1)}
@@ -611,10 +751,23 @@ def main():
                                               "by_kernel_tflops": {k: round(v[2] / v[1] / 1e12, 1) for k, v in groups},
                                               "by_kernel_launches_per_image": {k: round(v[0] / reps, 2) for k, v in groups},
                                               # every (kernel family, M x N x K) with >= 0.05 ms per image: launches, average us, TFLOP/s
+                                              # every kernel the library launched in the instrumented pass, by launch-site expression
+                                              # (non-GEMM kernels included): [launches per image, average us, ms per image], >= 0.05 ms
+                                              "library_kernels": {k: [round(v[0] / reps, 2), round(1e6 * v[1] / max(v[0], 1), 1), round(1e3 * v[1] / reps, 3)]
+                                                                  for k, v in sorted(meter.kernels.items(), key=lambda kv: -kv[1][1])
+                                                                  if 1e3 * v[1] / reps >= 0.05},
                                               "by_kernel_and_shape": {f"{fam} {sh}": [round(v[0] / reps, 2), round(1e6 * v[1] / max(v[0], 1), 1), round(v[2] / v[1] / 1e12, 1)]
                                                                       for (fam, sh), v in sorted(meter.shapes.items(), key=lambda kv: -kv[1][1])
                                                                       if 1e3 * v[1] / reps >= 0.05}}},
         }
+        if args.steps:
+            result["per_rank_images_per_s"] = per_rank if per_rank is not None else [round(result["value"], 2)]
+        if n1 is not None:
+            # T_1 / (n T_n) of SURVEY 8d config 4, as throughput: whole-job images/sec over N x the 1-GPU images/sec of the same workload
+            result["n1_reference"] = n1
+            result["efficiency_vs_n1"] = result["value"] / (world * n1["value"])
+        if f16 is not None:
+            result.update(f16)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 timed = [im.contiguous() for im in images[:max(1, args.cpu_images)]]

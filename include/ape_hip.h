@@ -113,6 +113,17 @@ int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */
 const char* ape_hip_gemm_last_kernel(void);
 
+/* Launch metering (measurement aid: bench.py's `roofline` object and per-kernel table) -- csrc/meter.cpp.  Between ape_hip_meter_begin()
+ * and ape_hip_meter_end() every kernel the CALLING THREAD launches through this library goes out with its own (start, stop) HIP event
+ * pair (hipExtLaunchKernelGGL): hipEventElapsedTime of the pair is the dispatch's begin-to-end duration, the number rocprofv3's kernel
+ * trace reports, free of the command-processor gaps an event pair recorded AROUND a launch includes.  Eager launches only (not inside a
+ * stream capture).  ape_hip_meter_count(): launches recorded so far; ape_hip_meter_read(i, &name, &ms): kernel expression (a static
+ * string, the template instantiation as written at the launch site) and duration in milliseconds of launch i (waits for it). */
+int ape_hip_meter_begin(void);
+int ape_hip_meter_count(void);
+int ape_hip_meter_end(void);
+int ape_hip_meter_read(int i, const char** name, float* ms);
+
 /* per-row LayerNorm statistics of x [M, C] (row stride ldx): rowscale[m] = rsqrt(var_m + eps), rowshift[m] = -mean_m * rowscale[m]
  * (biased variance, two passes) -- the row terms of the folded LayerNorm above.  -- csrc/norm.hip */
 int ape_hip_row_stats(const void* x, int ldx, int dt, int M, int C, float eps, float* rowscale, float* rowshift, void* stream);

@@ -49,3 +49,37 @@ def test_uneven_shards_of_a_coco_shaped_stream_run_the_same_number_of_steps():
     c = r["config"]
     assert c["shard_sizes"] == [4, 4] and c["shard_of_rank0"] == [0, 3]
     assert c["steps_run"] == 4 and c["record_sets_collected"] == 4 and c["gathered_rank_ids"] == [0, 1]
+
+
+def test_gpus_8_shards_the_1000_image_stream_like_the_reference_sampler_and_names_the_same_workload_as_n1():
+    """`--gpus 8 --dry --stream coco`: eight ranks start, the 1000-image COCO-shaped stream is cut into the reference's InferenceSampler
+    blocks (ape/data/samplers/distributed_sampler_multi_dataset.py:160-170: contiguous, total // world each, the first total % world
+    ranks one more), every rank runs the same number of steps -- and the line's workload string is the one the N = 1 line carries
+    (the driver computes 1 -> N efficiency from lines it must be able to tell are the same workload)"""
+    p8, lines8 = _run("--gpus", "8", "--stream", "coco")
+    assert p8.returncode == 0, p8.stderr[-2000:]
+    r8 = json.loads(lines8[0])
+    c8 = r8["config"]
+    assert r8["n_gpus"] == 8 and c8["rccl_ranks"] == 8 and c8["parallelism"] == "dp8"
+    # the reference's rule, restated: shard_size = total // world, left = total % world, rank r gets shard_size + (r < left) items from
+    # the running sum on
+    total, world = 1000, 8
+    size, left = total // world, total % world
+    sizes = [size + int(r < left) for r in range(world)]
+    want = [[sum(sizes[:r]), sum(sizes[:r + 1]) - 1, sizes[r]] for r in range(world)]
+    assert c8["shards"] == want and c8["shard_sizes"] == sizes
+    assert c8["steps_run"] == (sizes[0] + 1) // 2 and c8["record_sets_collected"] == c8["steps_run"]      # 2 images per step
+    assert c8["gathered_rank_ids"] == list(range(8)) and c8["text_bank_identical_on_all_ranks"] is True
+    p1, lines1 = _run("--gpus", "1", "--stream", "coco")
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    c1 = json.loads(lines1[0])["config"]
+    assert c1["workload"] == c8["workload"] and "1024x1024" in c1["workload"] and "rank" in c1["workload"]
+    assert c1["shards"] == [[0, 999, 1000]]
+
+
+def test_mask_format_default_is_the_same_contract_for_every_rank_count():
+    """the timed step of an N-GPU run is the 1-GPU step plus the exchange: `auto` resolves to bitmasks on the host for N = 1 and to
+    bitmasks on the host + all-gathered run lengths ("both") for N > 1 -- never to run lengths INSTEAD of bitmasks (round 4's bench.py:469)"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '("both" if world > 1 else "bitmask")' in src
+    assert '"rle" if world > 1' not in src

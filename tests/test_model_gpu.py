@@ -334,10 +334,15 @@ def test_runtime_rle_mask_format_and_predictor_pipeline():
     model, orc, image, text, gold, image_c, text_c = _run("tiny_padded", torch.float32)
     plain = GraphedForward(model.model_vision)
     rle = GraphedForward(model.model_vision, mask_format="rle", rle_cap=512)
+    both = GraphedForward(model.model_vision, mask_format="both", rle_cap=512)     # a data-parallel rank: bitmasks to its host + runs to gather
     h, w = image.shape[-2:]
     for fh, fw in [(h, w), (2 * h + 3, w + 17)]:
         a, _ = plain(image, text, fh, fw)
         b, _ = rle(image, text, fh, fw)
+        tk = both.submit(image, text, fh, fw)
+        c, _ = both.result(tk)
+        assert c.has("pred_masks") and c.has("pred_masks_rle") and tk.runs is not None
+        assert torch.equal(c.pred_masks, a.pred_masks) and [r["counts"] for r in c.pred_masks_rle] == [r["counts"] for r in b.pred_masks_rle]
         assert len(a) == len(b) > 0 and b.has("pred_masks_rle") and not b.has("pred_masks")
         assert torch.equal(a.pred_classes, b.pred_classes)
         for i in range(len(a)):

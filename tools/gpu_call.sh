@@ -1,0 +1,48 @@
+#!/bin/bash
+# ONE parametrised runner for the GPU calls of a round (replaces the per-call scripts of rounds 3 / 4):
+#     gpurun --timeout T -- 'tools/gpu_call.sh <tag> <recipe> [<recipe> ...]'
+# Every recipe writes under gpurun_out/<tag>/ (scratch; what is to be judged is copied into profiles/ afterwards).  Recipes:
+#   sweep          bench at 2 / 4 / 8 images per step (no CPU baseline): throughput + the tile kernel's roofline by shape
+#   meter          the instrumented pass of the default bench under rocprofv3 --kernel-trace --stats: the launch meter's per-kernel
+#                  durations on the JSON line next to rocprofv3's kernel_stats.csv of the SAME launches
+#   ops            tests/test_ops_gpu.py (+ -k expression in $APE_K)
+#   model          tests/test_model_gpu.py tests/test_teacher_forced.py (+ -k expression in $APE_K)
+#   suite          the whole -m gpu suite with durations, measured regression values written to the tag directory
+#   smoke          __graft_entry__.smoke()
+#   bench          the driver's default bench (cpu_baseline + parity) -> bench_default.json
+#   benches        the other configurations / flavours (no CPU baseline)
+#   profile        tools/gpu_profile.sh (rocprofv3 kernel stats: instrumented pass alone + pipelined graph run)
+#   pmc            tools/gpu_pmc.sh (separate FETCH_SIZE / WRITE_SIZE / SQ passes) + summary
+#   py:<script>    python tools/<script> (a probe), output -> <script>.log
+TAG=$1; shift
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+O=gpurun_out/$TAG
+mkdir -p $O
+b() { name=$1; shift; timeout 400 python bench.py --no-cpu-baseline "$@" 2> $O/bench_$name.err | tail -1 > $O/bench_$name.json; cut -c1-200 $O/bench_$name.json; tail -2 $O/bench_$name.err | cut -c1-200; }
+for recipe in "$@"; do
+  echo "=== $recipe"
+  case $recipe in
+    sweep)
+      for B in ${APE_SWEEP:-2 4 8}; do b ips$B --images-per-step $B --steps $((60 / B)) --warmup 4; done
+      python tools/bench_digest.py $O/bench_ips*.json | tee $O/sweep_digest.txt ;;
+    meter)
+      (cd /tmp && rm -rf /tmp/prof_m && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o eager -- python $GRAFT_REPO_ROOT/bench.py --instrumented-only --no-cpu-baseline ${APE_BENCH_ARGS} > $GRAFT_REPO_ROOT/$O/bench_instrumented_under_rocprof.json 2> /tmp/prof_m.err; tail -2 /tmp/prof_m.err)
+      find /tmp/prof_m -name "*kernel_stats.csv" -exec cp {} $O/instrumented_kernel_stats.csv \;
+      python tools/bench_digest.py --vs-rocprof $O/instrumented_kernel_stats.csv $O/bench_instrumented_under_rocprof.json | tee $O/meter_vs_rocprof.txt ;;
+    ops)   timeout 900 python -m pytest tests/test_ops_gpu.py -q -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_ops.log; tail -4 $O/pytest_ops.log | cut -c1-300 ;;
+    model) timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_teacher_forced.py -q -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_model.log; tail -4 $O/pytest_model.log | cut -c1-300 ;;
+    suite) APE_WRITE_PINS=$O timeout 1700 python -m pytest tests -q -m gpu --durations=40 2>&1 | grep -v Warning > $O/pytest_gpu.log; tail -50 $O/pytest_gpu.log | cut -c1-200 ;;
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 | tee $O/smoke.log ;;
+    bench) timeout 900 python bench.py ${APE_BENCH_ARGS} 2> $O/bench_default.err | tail -1 > $O/bench_default.json; cut -c1-300 $O/bench_default.json; python tools/bench_digest.py $O/bench_default.json | tee $O/bench_default_digest.txt ;;
+    benches)
+      b f16 --dtype f16; b input_uint8 --input uint8; b lvis1203_top300 --classes 1203 --size L_D; b stream_coco --stream coco
+      b 1536_semantic --size L_D_1536 --semantic --steps 30; b one_image_per_step --images-per-step 1; b L_A --size L_A
+      timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_torchrun_n1.json; cut -c1-160 $O/bench_torchrun_n1.json ;;
+    profile) ./tools/gpu_profile.sh $TAG ${APE_BENCH_ARGS} 2>&1 | tail -3 | cut -c1-160; mv gpurun_out/${TAG}_* $O/ 2>/dev/null; rm -f $O/*kernel_trace.csv.gz ;;
+    pmc) ./tools/gpu_pmc.sh $TAG ${APE_PMC_GROUPS:-2} 2>&1 | tail -14 | cut -c1-220; cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_summary.txt 2>/dev/null ;;
+    py:*) s=${recipe#py:}; timeout 900 python tools/$s ${APE_PY_ARGS} > $O/${s%.py}.log 2>&1; tail -40 $O/${s%.py}.log | cut -c1-220 ;;
+    *) echo "unknown recipe $recipe" ;;
+  esac
+done
+find gpurun_out -name "*kernel_trace.csv" -delete; find gpurun_out -name "*counter_collection.csv" -delete
+du -sh gpurun_out | tail -1

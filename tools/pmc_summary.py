@@ -4,7 +4,13 @@ import csv
 import glob
 import sys
 
+import os
+
 root = sys.argv[1]
+# which build of the library these passes measured: bench.py refuses a `roofline.traffic` from a summary whose digest is not the
+# digest of the sources it runs on (ape_amd/build.py _digest(): every csrc file + the header + the flags)
+_stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ape_amd", "lib", "libape_hip.sha256")
+print("# library_digest " + (open(_stamp).read().strip() if os.path.exists(_stamp) else "unknown"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
