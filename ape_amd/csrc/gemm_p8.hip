@@ -55,8 +55,13 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
 // pixels to -- through the index table `conv_perm` when the map's rows are not in raster order -- or from a zero row outside the
 // image.  The [H * W, 9 C] im2col matrix (302 MB for a 256 x 256 map) is never written or read; the 33.5 MB input is re-read nine
 // times out of L2 / the Infinity Cache.  Same schedule, same MFMA order: results are bit-identical to im2col + the ordinary kernel.
-template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0, bool CONV = false>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
+// PERSIST: the persistent SwiGLU flavour (one workgroup per CU walking several tiles; the launcher selects it for the up-projection of
+// the ViT's SwiGLU, the one launch of the forward with more 256 x 256 tiles than CUs).  A separate instantiation with ONLY that
+// epilogue: the tile loop costs registers, and a kernel that spills even outside its main loop runs at half speed on this chip
+// (any scratch use at all: measured, profiles/r05_p8_persistent_probe.log) -- the one-tile kernels stay exactly as they were.
+template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0, bool CONV = false, bool PERSIST = false>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
+  static_assert(!PERSIST || (BN == 256 && ABL == 0 && !CONV), "the persistent flavour is the dense 256 x 256 kernel");
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
   constexpr int TNH = TN / 2;             // n tiles per half: 2 | 1
@@ -71,52 +76,67 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   const int wr = wave >> 2, wc = wave & 3;
   const int frow = lane & 15, fq = lane >> 4;
 
-  // ---- tile of this workgroup
+  // ---- tiles of this workgroup.  PERSISTENT launches (gridDim.x < number of tiles; the launcher picks one workgroup per CU when a
+  // launch has more tiles than CUs): the workgroup walks the virtual block indices v = blockIdx.x, + gridDim.x, ... -- the tiles a
+  // plain launch would have given to the workgroups dispatched to this CU one after another (gridDim.x % 8 == 0 keeps v's XCD) -- and
+  // stages the NEXT tile's first K tiles while the current tile's epilogue runs (see the end of the tile loop).
   const int tiles_m = (p.M + P8_BM - 1) / P8_BM, tiles_n = (p.N + BN - 1) / BN;
-  int id;
-  {
-    const int nblk = gridDim.x, b = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = b & 7, j = b >> 3;
-    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective: XCD x owns a contiguous id range
-  }
-  int tm, tn;
-  {
-    const int per_group = 8 * tiles_n;           // 8 row-tiles x all column-tiles, column-major inside the group
-    const int g = id / per_group, rem = id - g * per_group;
-    const int rows = min(8, tiles_m - g * 8);
-    tm = g * 8 + rem % rows;
-    tn = rem / rows;
-  }
-  const int m0 = tm * P8_BM, n0 = tn * BN;
-
-  // ---- LDS-DMA source offsets (bytes from A / W), one per (half, instruction); LDS row lr = e * 8 + lane / 8
+  const int ntiles = tiles_m * tiles_n;
   const unsigned char* __restrict__ Ab = reinterpret_cast<const unsigned char*>(p.A);
   const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(p.W);
+  int m0, n0;
+  constexpr int W = TN * 4;
+  const bool fast_launch = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0;
+  bool fast;
+  // ---- LDS-DMA source offsets (bytes from A / W), one per (half, instruction); LDS row lr = e * 8 + lane / 8
   uint32_t offA[2][2], offB[2][NIB];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int lr = (wave * 2 + q) * 8 + (lane >> 3);                   // 0..127: wave row lr / 64, row lr % 64 of its half
-      const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
-      int gm = m0 + trow; gm = gm < p.M ? gm : p.M - 1;
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      // CONV: the byte address (in LDS) of this lane's row in the tap-0 slice of the source-row table; the chunk offset rides in bits 0-6
-      offA[h][q] = CONV ? (uint32_t)trow * 4u : (uint32_t)gm * (uint32_t)p.lda * 2u + (uint32_t)c * 16u;
+  auto set_tile = [&](int v) __attribute__((always_inline)) {
+    // (through an opaque copy of the thread index: hipcc otherwise hoists the tile-invariant per-lane terms of these offsets out of the
+    // tile loop and keeps them alive across the main loop, whose 250 registers have no room for them)
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, wave = tl >> 6, wc = wave & 3;
+    int id;
+    {
+      const int q = ntiles >> 3, r = ntiles & 7;
+      const int xcd = v & 7, j = v >> 3;
+      id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;   // bijective: XCD x owns a contiguous id range
     }
-#pragma unroll
-    for (int q = 0; q < NIB; ++q) {
-      const int lr = (wave * NIB + q) * 8 + (lane >> 3);                 // 0..BN/2-1: wave column lr / (WN/2)
-      const int wcs = lr / (WN / 2), within = lr % (WN / 2);
-      const int rho = h * (WN / 2) + within;                             // row of the wave's WN-row slab
-      const int col = WN == 64 ? (((rho >> 2) & 3) * 16 + (rho >> 4) * 4 + (rho & 3))
-                               : (((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3));
-      int gn = n0 + wcs * WN + col; gn = gn < p.N ? gn : p.N - 1;
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
-      offB[h][q] = (uint32_t)gn * (uint32_t)p.ldw * 2u + (uint32_t)c * 16u;
+    int tm, tn;
+    {
+      const int per_group = 8 * tiles_n;           // 8 row-tiles x all column-tiles, column-major inside the group
+      const int g = id / per_group, rem = id - g * per_group;
+      const int rows = min(8, tiles_m - g * 8);
+      tm = g * 8 + rem % rows;
+      tn = rem / rows;
     }
-  }
+    m0 = tm * P8_BM; n0 = tn * BN;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int lr = (wave * 2 + q) * 8 + (lane >> 3);                   // 0..127: wave row lr / 64, row lr % 64 of its half
+        const int trow = (lr >> 6) * 128 + h * 64 + (lr & 63);
+        int gm = m0 + trow; gm = gm < p.M ? gm : p.M - 1;
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        // CONV: the byte address (in LDS) of this lane's row in the tap-0 slice of the source-row table; the chunk offset rides in bits 0-6
+        offA[h][q] = CONV ? (uint32_t)trow * 4u : (uint32_t)gm * (uint32_t)p.lda * 2u + (uint32_t)c * 16u;
+      }
+#pragma unroll
+      for (int q = 0; q < NIB; ++q) {
+        const int lr = (wave * NIB + q) * 8 + (lane >> 3);                 // 0..BN/2-1: wave column lr / (WN/2)
+        const int wcs = lr / (WN / 2), within = lr % (WN / 2);
+        const int rho = h * (WN / 2) + within;                             // row of the wave's WN-row slab
+        const int col = WN == 64 ? (((rho >> 2) & 3) * 16 + (rho >> 4) * 4 + (rho & 3))
+                                 : (((rho >> 2) & 3) * 8 + (rho >> 4) * 4 + (rho & 3));
+        int gn = n0 + wcs * WN + col; gn = gn < p.N ? gn : p.N - 1;
+        const int c = (lane & 7) ^ ((lr >> 1) & 7);
+        offB[h][q] = (uint32_t)gn * (uint32_t)p.ldw * 2u + (uint32_t)c * 16u;
+      }
+    }
+    fast = fast_launch && n0 + wc * WN + WN <= p.N;
+  };
+  set_tile(blockIdx.x);
   // half-tile j of K tile kt: 0 = B0, 1 = A0, 2 = B1, 3 = A1
   auto issue_A = [&](int kt, int h) __attribute__((always_inline)) {
     unsigned char* dst = smem + (kt & 1) * STG + (h ? OFF_A1 : OFF_A0) + wave * 2048;
@@ -180,36 +200,56 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   };
   // wave-uniform: the wave's whole column slab is inside N and the launch's epilogue is one of the specialised ones (else the
   // generic, bounds-checked path)
-  constexpr int W = TN * 4;
-  const int nb = n0 + wc * WN + fq * W;                        // first of this lane's W consecutive GEMM columns
-  const bool fast = epi_fast_ok(p) && ((size_t)p.ldc * (p.out_dt == APE_DT_F32 ? 4 : 2)) % 16 == 0 && n0 + wc * WN + WN <= p.N;
+  // (nb = n0 + wc * WN + fq * W: first of a lane's W consecutive GEMM columns)
   // The accumulators START from the bias (fast epilogues without the folded LayerNorm, whose row scale comes first): the
   // epilogue then has no bias loads at all -- re-read per accumulator row they were, with the RoPE tables, 11.7 of the 46.9 us of
   // the q|k projection (profiles/r04_p8_ablation.log) -- and no registers are held for it across the main loop.
   f32x4_t acc[8][TN];
-  if (fast && p.bias != nullptr && p.rowscale == nullptr) {
-    if (p.vec_ok & P8_BIAS_BY_ROW) {
+  // Persistent launches: the NEXT tile's column bias travels through LDS -- one LDS-DMA instruction per wave in front of that tile's
+  // prefetch (its own 64 / 32 columns, 1 KB behind the two stages), read back behind the counted wait that retires the prefetch.
+  // (An ordinary load beside LDS-DMA traffic makes hipcc's wait-count pass answer with vmcnt(0); registers filled by an inline-asm
+  // load must never be spilled, and sixteen more live registers across the epilogue were.)
+  unsigned char* const bias_lds = smem + 2 * STG + wave * 1024;
+  auto init_acc = [&](bool from_lds) __attribute__((always_inline)) {
+    if (from_lds) {
+      f32x4_t bq[TN];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + frow;
-        const float b = p.bias[m < p.M ? m : p.M - 1];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b, b, b, b};
+      for (int j = 0; j < TN; ++j) {
+        const uint32_t a = (uint32_t)(uintptr_t)(lds_void_t*)(bias_lds + (fq * TN + j) * 16);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bq[j]) : "v"(a));
       }
-    } else {
-      float b[W];
-      ldrow_f32<W>(p.bias + nb, b);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bq[j]));       // consumed only behind the wait
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3]};
+        for (int j = 0; j < TN; ++j) acc[i][j] = bq[j];
+    } else if (fast && p.bias != nullptr && p.rowscale == nullptr) {
+      if (p.vec_ok & P8_BIAS_BY_ROW) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = m0 + wr * 128 + i * 16 + frow;
+          const float b = p.bias[m < p.M ? m : p.M - 1];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b, b, b, b};
+        }
+      } else {
+        float b[W];
+        ldrow_f32<W>(p.bias + n0 + wc * WN + fq * W, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){b[4 * j], b[4 * j + 1], b[4 * j + 2], b[4 * j + 3]};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
+  };
   auto mma = [&](int ha, int hb) __attribute__((always_inline)) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   // h(x) = x ^ ((x & 4) << 1) -- the 16 lanes of a ds_read_b128 lane group (two fq values, the frow sets {0-3, 12-15} / {4-11})
   // then hit 16 different slots.  Free stage: K tile nk would live in stage nk & 1; its halves were last read in iteration
   // nk - 2 (or never), and every wave is past those reads one phase into iteration nk - 1.
-  const bool rope_lds = BN == 256 && p.rope_cs != nullptr && p.rope_cos != nullptr && p.rope_hd == 64 && fast;
+  const bool rope_lds = !PERSIST && BN == 256 && p.rope_cs != nullptr && p.rope_cos != nullptr && p.rope_hd == 64 && fast_launch;   // launcher: N % 256 == 0
   auto hswz = [](int x) __attribute__((always_inline)) { return x ^ ((x & 4) << 1); };
   // (the source offsets are computed at issue time: eight more live registers across the main loop would spill)
   auto issue_rope = [&](int jj) __attribute__((always_inline)) {
@@ -251,6 +291,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const unsigned char*>(p.rope_cs) + off), (lds_void_t*)dst, 16, 0, 0);
   };
   constexpr int INFLIGHT = 2 * NIB + 2;          // loads of the three youngest half-tiles at a phase-4 wait: B0, A0, B1
+  // the seven half-tile loads in front of a tile's main loop: K tile 0 complete, the first three half-tiles of K tile 1
+  auto issue_first_tiles = [&]() __attribute__((always_inline)) {
+    issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
+    if (nk > 1) { issue_B(1, 0); issue_A(1, 0); issue_B(1, 1); }
+  };
+  auto wait_first_tiles = [&]() __attribute__((always_inline)) {
+    if (nk > 1) p8_wait_vmcnt<INFLIGHT>(); else p8_wait_vmcnt<0>();
+  };
   // ---- prologue: K tile 0 complete, the first three half-tiles of K tile 1 in flight
   if (CONV) {
     uint32_t* sidx = reinterpret_cast<uint32_t*>(smem + 2 * STG);
@@ -279,15 +327,17 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       p8_wait_vmcnt<0>();
     }
   } else {
-  issue_B(0, 0); issue_A(0, 0); issue_B(0, 1); issue_A(0, 1);
-  if (nk > 1) {
-    issue_B(1, 0); issue_A(1, 0); issue_B(1, 1);
-    p8_wait_vmcnt<INFLIGHT>();
-  } else {
-    p8_wait_vmcnt<0>();
+    issue_first_tiles();
+    wait_first_tiles();
   }
-  }
+  init_acc(false);
+
+  // ================================================================== tile loop (one pass unless the launch is persistent)
+  bool prefetched = false;          // this tile's first K tiles (and its bias) were staged behind the previous tile's main loop
+  bool acc_from_lds = false;        // ... and its bias waits in this wave's LDS slot
+  for (int v = blockIdx.x;;) {
   barrier();
+  if (PERSIST && acc_from_lds) init_acc(true); // behind the barrier: LDS-DMA data is ordered for a ds_read by the counted wait AND a barrier
   if (STAGGER && wr == 1) barrier();
 
   for (int t = 0; t < nk; ++t) {
@@ -340,6 +390,40 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     barrier();
   }
 
+  // ---- the epilogue works on THIS tile's coordinates; m0 / n0 / nb / fast / the source offsets move on to the next tile first
+  // (lane coordinates through an opaque copy of the thread index, for the same reason as in set_tile: nothing of the epilogue's
+  // addressing may be hoisted above the main loop)
+  int te = tid;
+  asm volatile("" : "+v"(te));
+  const int efrow = te & 15, efq = (te & 63) >> 4, ewr = te >> 8, ewc = (te >> 6) & 3;
+  const int em0 = m0, enb = n0 + ewc * WN + efq * W;
+  const bool efast = fast;
+  // ---- PERSISTENT launches: stage the next tile before the epilogue.  Every wave is past its last fragment read of this tile (the
+  // re-synchronising barrier above), so both LDS stages are free (not with the RoPE table, which occupies one through the epilogue;
+  // not for the implicit convolution, whose source-row table is per tile): the seven half-tile loads of the next tile's prologue go
+  // out NOW and fly while the epilogue computes, and so does the next tile's bias (bq).  The wait that retires K tile 0 comes
+  // behind the epilogue arithmetic -- and, in the SwiGLU specialisation that the multi-round launches of the forward use, IN
+  // FRONT of its stores (packed outputs wait in registers the fragments no longer need), so the counted wait sees only these
+  // loads; the stores then drain under the next tile's first K phases (vmcnt retires in order: that tile's first phase-4 wait
+  // covers them).  What a plain launch pays per tile and this does not: workgroup launch, the prologue's exposed HBM / L2 latency,
+  // and the store drain in front of s_endpgm.
+  const int vn = v + (int)gridDim.x;
+  const bool has_next = PERSIST && vn < ntiles;
+  prefetched = false;
+  bool bias_in_bq = false;
+  if (PERSIST && has_next) {
+    set_tile(vn);
+    if (fast && p.bias != nullptr && p.rowscale == nullptr && !(p.vec_ok & P8_BIAS_BY_ROW)) {
+      // lanes l and l + WN / 4 fetch the same 16 bytes: the wave's WN floats land (replicated) in its 1 KB, lane-linear
+      const float* bp = p.bias + n0 + ewc * WN + (te & (WN / 4 - 1)) * 4;
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)bp, (lds_void_t*)bias_lds, 16, 0, 0);
+      bias_in_bq = true;
+    }
+    issue_first_tiles();
+    prefetched = true;
+  }
+  bool waited = false;              // the counted wait for the prefetch was taken inside the epilogue (in front of its stores)
+
   // ---- epilogue from registers: lane (frow, fq) owns rows tile_i * 16 + frow, TN * 4 consecutive columns
   if (ABL == 3) {
 #pragma unroll
@@ -349,24 +433,26 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     return;
   }
   // one specialisation per launch (wave-uniform): the unrolled body stays short
-  auto run = [&](auto rope_t, auto norm_t, auto act_t, auto lds_t) __attribute__((always_inline)) {
+  auto run = [&](auto rope_t, auto norm_t, auto act_t, auto lds_t, auto defer_t) __attribute__((always_inline)) {
     constexpr bool ROPE = decltype(rope_t)::value, NORM = decltype(norm_t)::value, RLDS = decltype(lds_t)::value;
     constexpr int ACT = decltype(act_t)::value;
-    asm volatile("; p8 epilogue specialisation %0" ::"n"(ACT * 8 + ROPE * 4 + NORM * 2 + RLDS) : "memory");   // distinct per branch: the column
+    constexpr bool DEFER = decltype(defer_t)::value;     // SwiGLU, 16-bit output, prefetch in flight: outputs packed, stored behind the wait
+    asm volatile("; p8 epilogue specialisation %0" ::"n"(DEFER * 16 + ACT * 8 + ROPE * 4 + NORM * 2 + RLDS) : "memory");   // distinct per branch: the column
     // vectors are loaded HERE (identical code in every branch is hoisted above the dispatch, where they were spilled across it
     EpiCols<W> cols;
-    epi_cols_load<W, NORM>(p, nb, cols);
+    epi_cols_load<W, NORM>(p, enb, cols);
     const unsigned char* tbl = smem + (nk & 1) * STG;
-    const int c0 = (nb & 63) >> 2;                               // first 16-byte chunk (2 pairs) of this lane's columns in a table row
+    const int c0 = (enb & 63) >> 2;                              // first 16-byte chunk (2 pairs) of this lane's columns in a table row
+    uint32_t pk[DEFER ? 8 : 1][DEFER ? W / 4 : 1];
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + frow;
+      const int m = em0 + ewr * 128 + i * 16 + efrow;
       float cs[RLDS ? W : 1];
       if (RLDS) {
         // table reads through inline asm: left to hipcc, every row's ds_read gets an `s_waitcnt vmcnt(0)` in front (its wait-count
         // pass cannot rule out an LDS-DMA in flight behind the run-time dispatch) -- and with the stores of the previous row
         // counting on vmcnt, that is one store round trip per accumulator row
-        const int r = wr * 128 + i * 16 + frow;
+        const int r = ewr * 128 + i * 16 + efrow;
         f32x4_t t4[W / 4];
 #pragma unroll
         for (int k = 0; k < W / 4; ++k) {
@@ -381,7 +467,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
           cs[4 * k] = t4[k][0]; cs[4 * k + 1] = t4[k][1]; cs[4 * k + 2] = t4[k][2]; cs[4 * k + 3] = t4[k][3];
         }
       }
-      if (m < p.M) {
+      if (DEFER || m < p.M) {
         float o[W];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -400,42 +486,75 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
             for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], c, sn);
           }
         } else {
-          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, nb, o, cols, cs);
+          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, enb, o, cols, cs);
         }
-        if (ABL == 2) {
+        if (DEFER) {
+#pragma unroll
+          for (int e = 0; e < W / 4; ++e) pk[i][e] = h16<H>::pack2(o[2 * e], o[2 * e + 1]);
+        } else if (ABL == 2) {
 #pragma unroll
           for (int e = 0; e < W; ++e) asm volatile("" ::"v"(o[e]));
-        } else if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, nb >> 1, o);
-        else store_row<W, H>(p, m, nb, o);
+        } else if (ACT == EPI_ACT_SWIGLU) store_row<W / 2, H>(p, m, enb >> 1, o);
+        else store_row<W, H>(p, m, enb, o);
       }
       __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: the scheduler otherwise starts several rows' loads ahead
     }                                         // and spills the column vectors
-  };
-  using T = std::true_type; using F = std::false_type;
-  if (!fast) {
-    // generic path: any epilogue combination, one quad at a time (not unrolled over the row tiles: code size)
+    if (DEFER) {
+      // only the prefetch (and bq) is outstanding here: the counted wait retires the next tile's K tile 0 exactly as the prologue's
+      wait_first_tiles();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0 + wr * 128 + i * 16 + frow;
-      if (m < p.M) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          epi_n4<H>(p, m, nb + 4 * j, v);
+      for (int i = 0; i < 8; ++i) {
+        const int m = em0 + ewr * 128 + i * 16 + efrow;
+        if (m < p.M) {
+          H* dst = reinterpret_cast<H*>(p.C) + (size_t)m * p.ldc + (enb >> 1);
+          static_assert(!DEFER || W == 16, "deferred stores: 8 outputs = one 16-byte piece per row");
+          *reinterpret_cast<uint4*>(dst) = make_uint4(pk[i][0], pk[i][1], pk[i][DEFER ? 2 : 0], pk[i][DEFER ? 3 : 0]);
         }
       }
     }
+  };
+  using T = std::true_type; using F = std::false_type;
+  if (!efast) {
+    // generic path: any epilogue combination, one quad at a time (not unrolled over the row tiles: code size)
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 8; ++i) {
+      const int m = em0 + ewr * 128 + i * 16 + efrow;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          epi_n4<H>(p, m, enb + 4 * j, v4);
+        }
+      }
+    }
+  } else if (PERSIST) {
+    // the launcher's contract for this flavour: SwiGLU, 16-bit output, no RoPE / folded LayerNorm / residual
+    if (prefetched) {
+      run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{}, std::integral_constant<bool, PERSIST>{});
+      waited = true;
+    } else {
+      run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{}, F{});
+    }
   } else if (p.rope_cos != nullptr) {
-    if (BN == 256 && rope_lds) run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, T{});
-    else run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
+    if (BN == 256 && rope_lds) run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, T{}, F{});
+    else run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{}, F{});
   } else if (p.rowscale != nullptr) {
-    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
+    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{}, F{});
   } else if (p.act == APE_ACT_SWIGLU) {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{}, F{});
   } else if (p.act == APE_ACT_RELU) {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{}, F{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_RELU>{}, F{}, F{});
   } else {
-    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{});
+    run(F{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{}, F{});
+  }
+  if (!has_next) break;
+  // ---- next tile (PERSIST only): a wave that took the generic epilogue (its column slab ends beyond N) has stores younger than the
+  // prefetch in flight, so nothing short of a full drain retires K tile 0 for certain
+  if (!waited) p8_wait_vmcnt<0>();
+  acc_from_lds = bias_in_bq;
+  if (!bias_in_bq) init_acc(false);
+  v = vn;
   }
 }
 
@@ -473,6 +592,34 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
   const bool f16 = p.in_dt == APE_DT_F16;
   const char* name = nullptr;
+  // PERSISTENT grid: a launch with more tiles than CUs gets one workgroup per CU (rounded down to a multiple of 8: the tile order is
+  // XCD-aware), each walking the tiles the plain launch would have sent to that CU one workgroup after another -- and staging tile
+  // i + 1's first K tiles under tile i's epilogue (see the kernel's tile loop).  APE_P8_PERSIST=0 restores one workgroup per tile.
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n & ~7;
+  }();
+  const char* pe = getenv("APE_P8_PERSIST");
+  // ... for the launches the persistent flavour is compiled for: 256 x 256 tiles, staggered schedule, SwiGLU into a 16-bit output,
+  // bias by column or none, nothing else in the epilogue (the kernel's PERSIST contract)
+  const bool persist = !(pe != nullptr && atoi(pe) == 0) && p.conv_h == 0 && tiles > ncu && bn == 256 && stagger && p.act == APE_ACT_SWIGLU &&
+                       p.out_dt != APE_DT_F32 && p.rope_cos == nullptr && p.rowscale == nullptr && p.residual == nullptr && p.rowmask == nullptr &&
+                       p.alpha == 1.f && !(p.clamp > 0.f) && (p.bias == nullptr || ((uintptr_t)p.bias) % 16 == 0);
+  constexpr int P8_BIAS_LDS = 8 * 1024;            // persistent launches: 1 KB per wave behind the two stages (the next tile's bias)
+  if (persist) {
+    static bool pattr = false;
+    if (!pattr) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + P8_BIAS_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + P8_BIAS_LDS);
+      pattr = true;
+    }
+    if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<256, true, f16_t, 0, false, true>), dim3(ncu), dim3(512), 131072 + P8_BIAS_LDS, s, p);
+    else APE_LAUNCH((gemm_bf16_p8_kernel<256, true, bf16_t, 0, false, true>), dim3(ncu), dim3(512), 131072 + P8_BIAS_LDS, s, p);
+    // its own name, like the convolution flavour (rocprofv3 lists the instantiation as a separate row); GemmMeter.family() folds it
+    return f16 ? "gemm_f16_p8_kernel<256, true, persistent>" : "gemm_bf16_p8_kernel<256, true, persistent>";
+  }
+  const int grid = tiles;
 #define P8_LAUNCH(BN_, ST_, H_, LDS_, NAME_)                                                                            \
   do {                                                                                                                  \
     static bool attr__ = false;                                                                                         \
@@ -480,7 +627,7 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<BN_, ST_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
       attr__ = true;                                                                                                    \
     }                                                                                                                   \
-    APE_LAUNCH((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(tiles), dim3(512), LDS_, s, p);                        \
+    APE_LAUNCH((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(grid), dim3(512), LDS_, s, p);                                  \
     name = NAME_;                                                                                                       \
   } while (0)
 #ifdef APE_P8_ABLATION

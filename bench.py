@@ -174,7 +174,7 @@ class GemmMeter:
         implicit 3 x 3 convolution (`..., conv3x3>`: same tile, schedule and MFMA stream, the A rows staged from shifted input rows): the
         roofline object is about the tile kernel as a whole = the sum over these instantiations (rocprofv3 lists them as separate rows)"""
         import re
-        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), (?:\d+|conv3x3)>$", r"\1>", name)
+        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), (?:\d+|conv3x3|persistent)>$", r"\1>", name)
 
     def launch(self, i):
         """(kernel expression at the launch site, milliseconds) of launch i of the metering session"""

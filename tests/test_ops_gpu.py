@@ -886,6 +886,41 @@ def test_gemm_p8(ops, tile, stagger, monkeypatch, bf):
     assert out[:, :256].abs().max().item() == 0 and out[:, 768:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("bf", H16)
+def test_gemm_p8_persistent(ops, monkeypatch, bf):
+    """the PERSISTENT flavour of the 256 x 256 tile kernel (one workgroup per CU walking several tiles, the next tile's first K tiles
+    and bias staged under the current tile's epilogue, SwiGLU outputs stored behind the counted wait): taken by SwiGLU launches with
+    more tiles than CUs -- the ViT's up-projection (vit_eva_clip.py:125-132) -- bit-identical to one workgroup per tile
+    (APE_P8_PERSIST=0) and inside the GEMM tolerance of the torch definition; ragged M / N edges (partial row tiles, a half-empty last
+    column tile whose waves take the generic epilogue), with and without bias, one and many K tiles"""
+    if SELF:
+        pytest.skip("kernel selection: HIP library only")
+    from ape_amd import _lib
+    lib = _lib.load()
+    for (M, N, K, use_bias) in [(8192, 5504, 1024, True), (8000, 5504, 256, True), (4096, 4096 + 64, 64, False), (9000, 2176, 128, True), (16384, 5504, 1024, True)]:
+        a, w = rnd(M, K, dtype=bf, seed=21), rnd(N, K, dtype=bf, scale=K ** -0.5, seed=22)
+        bias = rnd(N, seed=23) if use_bias else None
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        assert tiles > 256
+        monkeypatch.setenv("APE_P8_PERSIST", "0")
+        plain = ops.gemm(a, w, bias, tile64=3, act=ref_ops.ACT_SWIGLU)
+        assert b"persistent" not in lib.ape_hip_gemm_last_kernel()
+        monkeypatch.setenv("APE_P8_PERSIST", "1")
+        got = ops.gemm(a, w, bias, tile64=3, act=ref_ops.ACT_SWIGLU)
+        assert b"persistent" in lib.ape_hip_gemm_last_kernel(), (M, N, K)
+        assert torch.equal(got, plain), (M, N, K)
+        if M <= 9000:
+            e = relerr(got, ref_ops.gemm(a, w, bias, act=ref_ops.ACT_SWIGLU))
+            print(f"gemm p8 persistent M{M} N{N} K{K}: {e:.3e}")
+            assert e < TOL[bf]
+        # outside the flavour's contract the launcher keeps one workgroup per tile
+        ops.gemm(a, w, bias, tile64=3, act=ref_ops.ACT_SWIGLU, out_dtype=torch.float32)
+        assert b"persistent" not in lib.ape_hip_gemm_last_kernel()
+    monkeypatch.delenv("APE_P8_PERSIST")
+    ops.gemm(a, w, bias, tile64=3, act=ref_ops.ACT_SWIGLU)
+    assert b"persistent" in lib.ape_hip_gemm_last_kernel()            # the default
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_geometry_kernel(ops, dt):
     """csrc/geometry.hip (per-image-size constants written into the graph's fixed buffers) == the tensor-level definition
