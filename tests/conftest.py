@@ -13,6 +13,29 @@ if TESTS not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow_gpu: the widened model families at full size (ViT-e / EVA-01 ViT-g) and the IEEE-half "
+                                       "repetitions of the full-size cases -- still part of -m gpu, ordered LAST (see below)")
+
+
+# Inside `-m gpu` the cases of BASELINE's own configurations (APE-L_D / APE-Ti, bf16) run first; the widened families (APE on ViT-e,
+# EVA-01 ViT-g: *_E_D_*, *_V_A_*, *_G_A_*) and the f16 repetitions of full-size cases are marked slow_gpu and moved to the END of the
+# session: if the driver's wall-clock limit ever cuts the run, what it cuts is the breadth, not the hot path's own parity cases.
+# Within each group the collection order is kept (it also keeps tests of one model configuration adjacent: tests/model_util.py shares
+# built models between them).
+_SLOW_KEYS = ("E_D_coco80", "V_A_coco80", "G_A_1536", "E_D_full_size")
+
+
+def pytest_collection_modifyitems(config, items):
+    fast, slow = [], []
+    for it in items:
+        nid = it.nodeid
+        full_size_f16 = nid.endswith("-f16]") and ("test_L_D_bf16_pipeline" in nid or "test_L_D_bf16_teacher_forced" in nid)
+        if any(k in nid for k in _SLOW_KEYS) or full_size_f16:
+            it.add_marker(pytest.mark.slow_gpu)
+            slow.append(it)
+        else:
+            fast.append(it)
+    items[:] = fast + slow
 
 
 @pytest.fixture

@@ -23,16 +23,75 @@ def build_pair(case, device="cpu", dtype=torch.float32):
     return model, orc, image, text, gold
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Built full-size models are SHARED between the GPU tests that use the same (configuration, weight seed): the fp32 / bf16 / f16
+# pipeline tests and the teacher-forced tests of one case -- and the cases that differ only in image / vocabulary (L_D_coco80,
+# L_D_padded, L_D_phrase256, L_D_jpeg) -- all run on one set of seeded weights; generating them, building the modules and packing
+# the GEMM operands per dtype was ~5 s x 40 tests of the round-4 suite.  A cache hit hands the model back in the state of a fresh
+# build: every plain attribute of model_vision (flags, metadata lists, thresholds ...) and its small buffers (the phrase bank)
+# are restored from a snapshot taken right after the build, so what one test switches on never reaches the next.
+# GPU only (the CPU tests build tiny models), least-recently-used, bounded by APE_TEST_MODEL_CACHE_GB (default 28 GB of the 288).
+# ------------------------------------------------------------------------------------------------------------------
+import collections
+import copy
+import os
+
+_MODELS = collections.OrderedDict()      # (cfg_name, wseed, device) -> (model, plain snapshot, key set, buffer snapshot, bytes)
+_MODEL_CACHE_BYTES = int(float(os.environ.get("APE_TEST_MODEL_CACHE_GB", "28")) * (1 << 30))
+
+
+def _is_plain(v, depth=0):
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return True
+    if depth > 6:
+        return False
+    if isinstance(v, (list, tuple)):
+        return all(_is_plain(x, depth + 1) for x in v)
+    if isinstance(v, dict):
+        return all(_is_plain(k, depth + 1) and _is_plain(x, depth + 1) for k, x in v.items())
+    return False
+
+
+def _snapshot(mv):
+    plain = {k: copy.deepcopy(v) for k, v in vars(mv).items() if not k.startswith("_") and _is_plain(v)}
+    bufs = {k: b.detach().clone() for k, b in mv._buffers.items() if b is not None and b.numel() <= (1 << 22)}
+    return plain, set(vars(mv)), bufs
+
+
+def _restore(mv, plain, keys, bufs):
+    for k in [k for k, v in vars(mv).items() if k not in keys and not k.startswith("_") and _is_plain(v)]:
+        delattr(mv, k)                     # a plain attribute a test added
+    for k, v in plain.items():
+        setattr(mv, k, copy.deepcopy(v))
+    with torch.no_grad():
+        for k, b in bufs.items():
+            if mv._buffers.get(k) is not None and mv._buffers[k].shape == b.shape:
+                mv._buffers[k].copy_(b)
+
+
 def build_model(case, device="cpu", dtype=torch.float32):
     """(our model with the fixture's seeded weights, image, text, golden) -- no oracle (full-size cases)"""
     gold = U.load_golden(case)
     cfg_name, wseed, image, text = U.case_inputs(gold)
-    sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
-    model = build_ape(cfg_name)
-    missing, unexpected = model.load_state_dict(sd, strict=False)
-    assert not unexpected and all(m.endswith(("freqs_cos", "freqs_sin")) for m in missing), (missing, unexpected)
-    del sd
-    model.to(device)
+    key = (cfg_name, wseed, str(device))
+    cached = _MODELS.get(key) if str(device).startswith("cuda") and os.environ.get("APE_TEST_MODEL_CACHE", "1") != "0" else None
+    if cached is not None:
+        _MODELS.move_to_end(key)
+        model = cached[0]
+        _restore(model.model_vision, cached[1], cached[2], cached[3])
+    else:
+        sd = weights.make_state_dict(U.load_spec(cfg_name), wseed)
+        model = build_ape(cfg_name)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        assert not unexpected and all(m.endswith(("freqs_cos", "freqs_sin")) for m in missing), (missing, unexpected)
+        del sd
+        model.to(device)
+        if str(device).startswith("cuda") and os.environ.get("APE_TEST_MODEL_CACHE", "1") != "0":
+            nbytes = sum(p.numel() * p.element_size() for p in model.parameters())
+            while _MODELS and sum(v[4] for v in _MODELS.values()) + nbytes > _MODEL_CACHE_BYTES:
+                _MODELS.popitem(last=False)
+            if nbytes <= _MODEL_CACHE_BYTES:
+                _MODELS[key] = (model,) + _snapshot(model.model_vision) + (nbytes,)
     model.model_vision.set_compute_dtype(dtype)
     model.model_vision.text_feature_bank_reset = U.case_prompt(gold) == "phrase"
     return model, image, text, gold
@@ -184,11 +243,14 @@ def check_pins(group, values):
     if pins is None:
         assert out_dir or os.environ.get("APE_TEST_SELFCHECK") == "1", f"no regression pins committed for {group} (run with APE_WRITE_PINS=<dir>)"
         return
-    slack = PIN_SLACK if group.startswith("forced/") else PIN_SLACK_FREE
+    # forced/ : one stage's own rounding; pipeline/ : the end-to-end quantities of the free-running 16-bit pipeline against the fp32
+    # reference fixture (rms of p2 / memory / logits / boxes, mask-sign mismatch, unmatched detections) -- the kernels are
+    # deterministic, so these reproduce to the last bit on unchanged code: 1.5 x the committed measurement, no looser fallback
+    slack = PIN_SLACK if group.startswith(("forced/", "pipeline/")) else PIN_SLACK_FREE
 
     def limit(k):
-        if k == "detections_unmatched":            # a count out of ~100: a handful of borderline detections may move
-            return pins[k] + 0.08
+        if k == "detections_unmatched":            # a count out of ~100 detections: 1.5 x the pin, at least two detections of slack
+            return max(PIN_SLACK * pins[k], pins[k] + 0.02)
         if group.startswith("free/") and (k in ("init_reference", "query_pos", "pred_boxes") or (k.startswith("dec") and k.endswith("_ref"))):
             return max(PIN_SLACK_DISCRETE * pins[k], PIN_FLOOR)
         return max(slack * pins[k], PIN_FLOOR)

@@ -617,3 +617,19 @@ def test_graph_retirement_is_bounded(monkeypatch):
     run._retire(SimpleNamespace(graph=object(), pool_bytes=3 << 30), strict=False)      # destructors park unconditionally
     rep = run.memory_report()
     assert rep["retired_graphs"] == 4 and rep["retired_bytes"] == 12 << 30 and rep["retire_limit_bytes"] == 10 << 30
+
+
+def test_vectorised_class_nms_reference_equals_the_per_class_oracle_nms():
+    """tests/ref_ops.nms_classes (all classes at once; what the GPU test of the class-wise NMS kernel compares against) == the oracle's
+    greedy NMS run class by class, on heavily overlapping boxes, with and without a validity mask"""
+    import ref_ops
+    g = torch.Generator().manual_seed(11)
+    for (K, n, thr) in [(9, 120, 0.7), (4, 257, 0.5), (1, 64, 0.9)]:
+        c = torch.rand(n, 2, generator=g) * 100
+        wh = torch.rand(n, 2, generator=g) * 80 + 10                      # boxes cover ~a quarter of the frame: many suppressions
+        boxes = torch.cat([c, c + wh], 1)
+        order = torch.stack([torch.randperm(n, generator=g) for _ in range(K)]).int()
+        valid = (torch.rand(K, n, generator=g) > 0.25).to(torch.uint8)
+        for v in (None, valid):
+            a, b = ref_ops.nms_classes(boxes, order, thr, v), ref_ops.nms_classes_one_by_one(boxes, order, thr, v)
+            assert torch.equal(a, b) and 0 < int(a.sum()) < (K * n if v is None else int(v.sum()))

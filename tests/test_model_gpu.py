@@ -465,6 +465,23 @@ def _ld_mask_sign_mismatch(stages, out, gold):
     return bad / max((~tie).float().sum().item(), 1.0), len(rows)
 
 
+def _ld_mask_sign_pixels(stages, out, gold):
+    """the same comparison in PIXELS: (mismatching non-tie pixels, non-tie pixels, shared detections, the largest |our logit| / absmax
+    among the mismatching pixels -- how far outside the fixture's tie band (|reference logit| < 1e-3 absmax) a flipped pixel sits)"""
+    q_ref = gold["full"]["det_query"][:100].tolist()
+    logits = stages["det_mask_logits"].float().cpu()
+    npix = logits.shape[1]
+    sign_ref = M.unpack_bits(gold["full"]["mask_sign_kept"].flatten(1), npix)
+    tie_ref = M.unpack_bits(gold["full"]["mask_tie_kept"].flatten(1), npix)
+    ours = {int(q): i for i, q in enumerate(out["det_query"].cpu().tolist())}
+    rows = [(ours[q], j) for j, q in enumerate(q_ref) if q in ours]
+    mine = logits[[i for i, _ in rows]]
+    ref, tie = sign_ref[[j for _, j in rows]], tie_ref[[j for _, j in rows]]
+    wrong = ((mine > 0) != ref) & ~tie
+    margin = float((mine.abs() / mine.abs().amax(dim=1, keepdim=True).clamp_min(1e-30))[wrong].max()) if bool(wrong.any()) else 0.0
+    return int(wrong.sum()), int((~tie).sum()), len(rows), margin
+
+
 @pytest.mark.parametrize("case", ["Ti_512", "L_D_coco80", "L_D_padded", "L_D_lvis1203", "L_D_1536_sseg", "L_D_phrase256", "L_A_coco80", "L_D_jpeg", "V_A_coco80", "G_A_1536"])
 def test_L_D_fp32_matches_reference(case):
     """T1 at the benchmarked sizes: fp32 HIP kernels vs the reference run; north_star tolerance 1e-3 on logits / boxes,
@@ -480,7 +497,16 @@ def test_L_D_fp32_matches_reference(case):
         mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"])
         sem = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
     stages = {}
-    mv.forward_single(image, text, stages=stages, prompt=prompt)        # own proposal selection
+    own = mv.forward_single(image, text, stages=stages, prompt=prompt)        # own proposal selection
+    if "mask_sign_kept" in gold["full"] and "det_mask_logits" in stages:
+        # north_star: "identical argmax masks" -- fp32 kernels, OWN proposal selection, the kept detections' mask logits against the
+        # reference run's sign bits, pixel by pixel.  Excluded: the pixels the FIXTURE marks as ties (|reference logit| < 1e-3 of the
+        # mask's largest).  A pixel that still flips must be a near-tie that fp32 summation order decides (our logit within 5e-3 of
+        # zero relative to the mask's largest): the count and the margin are printed, anything farther from zero fails.
+        bad, total, shared, margin = _ld_mask_sign_pixels(stages, own, gold)
+        print(f"[L_D fp32 {case}] argmax masks with own proposal selection: {bad} of {total} non-tie pixels differ over {shared} shared "
+              f"detections; largest |logit| / absmax among them {margin:.2e}")
+        assert shared >= 95 and bad <= 1e-4 * total and margin < 5e-3, (bad, total, shared, margin)
     for k in LD_STAGES:
         if k not in gold["stages"]:
             continue                    # L_A_coco80 (plain family): no fusion stage
@@ -646,5 +672,5 @@ def test_L_D_bf16_pipeline(case, dt):
         # table), but the free-running refinement of this random-weight decoder multiplies whatever reaches it by ~1.7 per layer
         assert t3["memory"][1] < 2e-3 and rms_l < 2.5e-3, (t3["memory"], rms_l)
         assert frac >= 0.85 and mm < 8e-3, (frac, mm)
-    else:
-        assert frac >= 0.5 and mm < 5e-2          # sanity floors (a broken kernel gives ~0 / ~0.5); the regression pins above are the bounds
+    # bf16: no absolute floor to fall back to -- every end-to-end quantity above (incl. mask_sign_mismatch and detections_unmatched) is
+    # held to 1.5 x its committed MI355X measurement by check_pins, which also fails when the group has no committed pins
