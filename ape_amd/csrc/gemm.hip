@@ -1081,10 +1081,12 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
   const int use_ring_always = ring_env ? atoi(ring_env) : 0;
   const bool ring = v2_ok && !no_glds && !no_ring && p.K % GR_K == 0;
   if (p.conv_h > 0) {
-    // implicit-GEMM 3 x 3 convolution: the 256 x 256 tile kernel only (callers fall back to im2col + gemm when this is refused)
-    APE_CHECK_ARG(p.conv_w > 0 && p.splitk <= 1 && !p.trans_out && ceil_div(p.M, 256) * ceil_div(p.N, 256) >= 200,
-                  "ape_hip_gemm(conv3x3): needs >= 200 tiles of 256 x 256 (M = %d, N = %d), no split-K / transposed output", p.M, p.N);
-    const char* name = ape_gemm_p8_launch(p, 256, 1, s);
+    // implicit-GEMM 3 x 3 convolution: the eight-wave tile kernel only (callers fall back to im2col + gemm when this is refused): 256 x 256
+    // tiles when they fill the chip, else 256 x 128 tiles when there are at least 100 of them (the 128 x 128-pixel p3 map: 128)
+    const int t256 = ceil_div(p.M, 256) * ceil_div(p.N, 256), t128 = ceil_div(p.M, 256) * ceil_div(p.N, 128);
+    APE_CHECK_ARG(p.conv_w > 0 && p.splitk <= 1 && !p.trans_out && (t256 >= 200 || t128 >= 100),
+                  "ape_hip_gemm(conv3x3): needs >= 200 tiles of 256 x 256 or >= 100 of 256 x 128 (M = %d, N = %d), no split-K / transposed output", p.M, p.N);
+    const char* name = ape_gemm_p8_launch(p, t256 >= 200 ? 256 : 128, 1, s);
     APE_CHECK_ARG(name != nullptr, "ape_hip_gemm(conv3x3): K = 9 * 256 channels of 16-bit operands, lda >= 256, M == conv_h * conv_w, a 16-byte aligned zero row");
     g_last_gemm_kernel = name;
     return 0;

@@ -644,15 +644,23 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   }
 #endif
   if (p.conv_h > 0) {
-    // implicit 3 x 3 convolution: the 256 x 256 tile, staggered schedule, + 9 KiB of LDS for the source-row table
-    if (bn != 256 || p.K != 9 * 256 || p.lda < 256 || p.M != p.conv_h * p.conv_w || p.conv_zero == nullptr || ((uintptr_t)p.conv_zero) % 16 != 0)
+    // implicit 3 x 3 convolution: staggered schedule, + 9 KiB of LDS for the source-row table; 256 x 256 tiles for the large maps (p2, the
+    // mask head: 256 x 256 pixels = 256 tiles), 256 x 128 tiles for the 128 x 128-pixel p3 map (64 row tiles: 128 workgroups instead of 64)
+    if ((bn != 256 && bn != 128) || p.K != 9 * 256 || p.lda < 256 || p.M != p.conv_h * p.conv_w || p.conv_zero == nullptr || ((uintptr_t)p.conv_zero) % 16 != 0)
       return nullptr;
-    constexpr int CONV_LDS = 131072 + 9 * P8_BM * 4;
+    constexpr int CONV_LDS = 131072 + 9 * P8_BM * 4, CONV_LDS128 = 98304 + 9 * P8_BM * 4;
     static bool cattr = false;
     if (!cattr) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, bf16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS128);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS128);
       cattr = true;
+    }
+    if (bn == 128) {
+      if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<128, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS128, s, p);
+      else APE_LAUNCH((gemm_bf16_p8_kernel<128, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS128, s, p);
+      return f16 ? "gemm_f16_p8_kernel<128, true, conv3x3>" : "gemm_bf16_p8_kernel<128, true, conv3x3>";
     }
     if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<256, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);
     else APE_LAUNCH((gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS, s, p);

@@ -111,9 +111,10 @@ class GraphedForward:
         # panoptic branch inside the captured step (:671-690 + _postprocess_panoptic :921-998): `panoptic` = the evaluation dataset's
         # metadata dict (thing_classes, stuff_classes, thing_dataset_id_to_contiguous_id).  The merge runs on the device without a host
         # round trip (csrc/masks.hip panoptic_*), so it is part of the graph; `ticket.panoptic` = [(panoptic_seg, segments_info)].
+        # With any_size the captured step produces the panoptic queries' mask logits over the whole S x S pad and their class
+        # logits (fixed shapes); the merge itself -- crop to the image's own (h, w), resize to its output frame, the walk over
+        # the queries: three launches, no host round trip -- runs behind the replay with the ticket's sizes, like the mask paste.
         self.panoptic = panoptic
-        if panoptic is not None and self.any_size:
-            raise NotImplementedError("GraphedForward: the panoptic branch needs per-size graphs (any_size=False)")
         # pipelined steps: start the ViT branch behind the tails' encoders (see _run_entry); APE_PIPE_LATE_VIT=0|1 overrides
         self.late_vit = os.environ.get("APE_PIPE_LATE_VIT", "0") == "1"
         self._graphs = {}
@@ -159,7 +160,11 @@ class GraphedForward:
         if self.semantic is not None:
             # any_size: (height, width) = the pad; the scores stay [K', S, S] here and become labels in _replay (ticket sizes)
             labels = out["sem_seg"] if self.any_size else self._sem_labels(out["sem_seg"], height, width)
-        pan = mv.panoptic_device(out, height, width, self.panoptic) if self.panoptic is not None else None
+        pan = None
+        if self.panoptic is not None:
+            # any_size: (height, width) = the pad; the pieces stay fixed-shape here and are merged in _replay (ticket sizes)
+            pan = ({k: out[k] for k in ("pan_masks", "pan_cls", "pan_valid")} if self.any_size
+                   else mv.panoptic_device(out, height, width, self.panoptic))
         # boxes in the output frame, keep flags, records with the kept detections first (stable) -- the host then takes PREFIX
         # views of the pinned buffers instead of gathering ~1 MB per mask with a boolean index; dropped rows (empty slots, empty
         # boxes after the rescale) carry score -1, so the 6-column view that is all-gathered across ranks tells kept from dropped
@@ -473,6 +478,9 @@ class GraphedForward:
                         labels = self._sem_labels(labels[:, :mh, :mw], *completes.frames[b])
                     s.d_sem[b, : labels.numel()].copy_(labels.reshape(-1), non_blocking=True)
                 if pan is not None:
+                    if self.any_size:           # mask logits over the pad -> this image's region -> merged in its output frame
+                        mh, mw = completes.model_hw[b]
+                        pan = self.mv.panoptic_device(dict(pan, pan_masks=pan["pan_masks"][:, :mh, :mw]), *completes.frames[b], self.panoptic)
                     s.d_pan[b, : pan[0].numel()].copy_(pan[0].reshape(-1), non_blocking=True)
                     s.d_paninfo[b, : pan[1].shape[0]].copy_(pan[1], non_blocking=True)
                     s.d_paninfo[b, -1, 0:1].copy_(pan[2], non_blocking=True)        # last row, column 0: the segment count

@@ -423,8 +423,29 @@ def test_panoptic_merge_in_graph_runtime(kw):
         for seg, info in t.panoptic:
             assert seg.shape == (H, W) and seg.dtype == torch.int32
             assert torch.equal(seg, seg_ref.cpu()) and info == info_ref, (len(info), len(info_ref))
-    with pytest.raises(NotImplementedError):
-        GraphedForward(mv, panoptic=mv.metadata_list[0], any_size=True)
+    # any_size: ONE size-agnostic graph; the merge (crop to the image's own region, resize to its frame, walk) runs behind the replay
+    # with the ticket's sizes.  Different sizes inside one step, each against model.forward() on that image
+    g = torch.Generator().manual_seed(9)
+    h0, w0 = image_c.shape[-2:]
+    imgs = [image_c, image_c[:, : h0 - 32, : w0 - 48].contiguous(), torch.randint(0, 256, (3, h0 - 16, w0), generator=g).float().cuda(), image_c]
+    frames = [(H, W), (H - 20, W + 8), (2 * (h0 - 16), w0 + 4), (H, W)]
+    want = []
+    for im, (fh, fw) in zip(imgs, frames):
+        r = model([{"image": im, "height": fh, "width": fw}])[0]["panoptic_seg"]
+        want.append((r[0].cpu().clone(), r[1]))
+    S = mv.backbone.padding_constraints["square_size"]
+    run = GraphedForward(mv, panoptic=mv.metadata_list[0], any_size=True, images_per_step=2, max_out_pixels=max(fh * fw for fh, fw in frames))
+    got = []
+    for rnd_ in range(2):                                                # the second round replays the captured graph
+        for i in range(0, len(imgs), 2):
+            t = run.submit(imgs[i:i + 2], feats, [f[0] for f in frames[i:i + 2]], [f[1] for f in frames[i:i + 2]], prompt)
+            run.result(t)
+            got.extend((seg.clone(), info) for seg, info in t.panoptic)
+    assert len(run._graphs) == 1 and len(got) == 2 * len(imgs)
+    for i, (seg, info) in enumerate(got):
+        seg_w, info_w = want[i % len(imgs)]
+        assert seg.shape == seg_w.shape and [(d["isthing"], d["category_id"]) for d in info] == [(d["isthing"], d["category_id"]) for d in info_w], i
+        assert (seg != seg_w).float().mean().item() < 1e-3, i            # the canvas path rounds the geometry constants differently
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1129,3 +1129,26 @@ def test_conv3x3_implicit_gemm(ops, dtype, use_perm, use_bias, N):
               f"{timed(lambda: ops.gemm(ops.im2col3x3(x, perm, H, W), w, bias)):.1f} us")
         small = ops.conv3x3(x[:64 * 64 + 7], None, 64, 64, w, bias)          # too few tiles: the im2col path behind the same entry
         assert torch.equal(small, ops.gemm(ops.im2col3x3(x[:64 * 64 + 7], None, 64, 64), w, bias))
+
+
+@pytest.mark.parametrize("dtype", H16)
+def test_conv3x3_implicit_gemm_p3_map(ops, dtype):
+    """the 128 x 128-pixel p3 convolution (vit_eva_clip.py:806-842): 64 row tiles are too few for 256 x 256 tiles, so the implicit
+    flavour runs on 256 x 128 tiles (128 workgroups) -- bit-identical to im2col3x3 + the same tile kernel on the materialised operand"""
+    H = W = 128
+    C = N = 256
+    x = rnd(H * W, C, dtype=dtype, seed=5)
+    w = (rnd(N, 9 * C, seed=6) * (9 * C) ** -0.5).to(dtype)
+    bias = rnd(N, seed=7)
+    perm = torch.randperm(H * W, generator=torch.Generator().manual_seed(8)).int().to(DEV)
+    got = ops.conv3x3(x, perm, H, W, w, bias)
+    if not SELF:
+        from ape_amd import _lib
+        assert ops.conv3x3_implicit_ok(x, w, H, W)
+        assert b"p8_kernel<128, true, conv3x3>" in _lib.load().ape_hip_gemm_last_kernel()
+        want = ops.gemm(ops.im2col3x3(x, perm, H, W), w, bias, tile64=4)
+        assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+    e = relerr(got, ref_ops.conv3x3(x, perm, H, W, w, bias))
+    print(f"conv3x3 implicit p3 {dtype}: vs the definition {e:.2e}")
+    assert e < T16(dtype, 1e-2, 1e-5)
+
