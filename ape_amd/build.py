@@ -34,7 +34,10 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for f in _sources() + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ape_hip.h")]:
+    # EVERY header of csrc/ (round 5: gemm_epi.h was missing here -- an edit of the shared epilogue did not rebuild the library, and one GPU
+    # run validated a stale .so)
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for f in _sources() + headers + [os.path.join(HERE, "..", "include", "ape_hip.h")]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -189,16 +189,11 @@ template <int W> __device__ __forceinline__ void ldrow_f32(const float* src, flo
 
 // silu(g) * u with the reciprocal instruction (v_rcp_f32, 1 ulp) instead of an IEEE division (a ~10-instruction expansion):
 // the SwiGLU epilogue of the ViT up projection was VALU bound on it (ablation: 17 of the launch's 99 us were epilogue arithmetic)
-// The two products go through single-instruction asm: hipcc's SLP vectoriser otherwise pairs them across outputs into v_pk_mul_f32 and pays
-// three v_mov per pair to line the operands up (the gate / up values of neighbouring outputs are not register-adjacent): 16 -> 12 VALU
-// instructions per two outputs in an epilogue that is VALU bound (two quarter-rate transcendentals per output)
-__device__ __forceinline__ float silu_mul_fast(float g, float u) {
-  const float r = __builtin_amdgcn_rcpf(1.f + __expf(-g));
-  float t, o;
-  asm("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(g), "v"(r));
-  asm("v_mul_f32 %0, %1, %2" : "=v"(o) : "v"(t), "v"(u));
-  return o;
-}
+__device__ __forceinline__ float silu_mul_fast(float g, float u) { return g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * u; }
+// (Round 5 tried the two products as single-instruction inline asm, to keep hipcc's SLP vectoriser from pairing them into v_pk_mul_f32
+// behind three v_mov per pair: the asm reads v_rcp_f32's result in the very next VALU slot, and the hazard recogniser does not see
+// inside inline asm -- gfx950 needs a wait state between a transcendental and its consumer -- so every SwiGLU output was garbage at
+// random (caught by the bf16 pipeline pins: p2 0.69 rms instead of 1.0e-2).  No measurable gain either: 88.2 vs 88.0 us.  Reverted.)
 
 // row-invariant vectors of a lane's W columns, loaded ONCE per tile (the unrolled row loop re-read them per accumulator row:
 // the stores in between keep the compiler from merging the loads)

@@ -379,10 +379,9 @@ class DeformableDETRSegmVL(nn.Module):
         level_shapes = [maps[f][1] for f in names]
         if geo is None:
             geo = self.geometry((h, w), level_shapes)
-        elif panoptic:
-            # the semantic branch is size-agnostic (class scores over the whole pad; the caller crops / resizes with the image's
-            # sizes, runtime.GraphedForward._sem_labels); the panoptic branch crops its masks to (h, w) here
-            raise NotImplementedError("ape_amd: the size-agnostic (static geometry) forward covers the instance and semantic branches")
+        # (a given geometry = the size-agnostic forward: `image` is the S x S canvas, so (h, w) is the pad.  The semantic branch then yields
+        # class scores over the whole pad and the panoptic branch its queries' mask logits over the whole pad; the caller crops / resizes /
+        # merges with the image's own sizes behind the replay: runtime.GraphedForward._sem_labels, ._replay)
         t0 = time.perf_counter()
         src = torch.empty((geo.T, self.transformer.embed_dim), dtype=dt, device=image.device)
         def neck_level(i, f):

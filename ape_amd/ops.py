@@ -516,7 +516,8 @@ def conv3x3_implicit_ok(x, w, h, wd):
     -- the 256 x 256-pixel maps -- or >= 100 tiles of 256 x 128: the 128 x 128-pixel p3 map)"""
     rows = (h * wd + 255) // 256
     return (x.dtype in HALF16 and x.dtype == w.dtype and x.shape[1] == 256 and w.shape[1] == 9 * 256
-            and (rows * ((w.shape[0] + 255) // 256) >= 200 or rows * ((w.shape[0] + 127) // 128) >= 100)
+            and (rows * ((w.shape[0] + 255) // 256) >= 200
+                 or (rows * ((w.shape[0] + 127) // 128) >= 100 and os.environ.get("APE_CONV_P3_IM2COL") != "1"))
             and os.environ.get("APE_CONV_IM2COL") != "1")
 
 

@@ -95,6 +95,9 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
                     help="16-bit flavour of the timed pipeline: bf16 = BASELINE's dtype (default); f16 = IEEE half operands, the reference's "
                          "own evaluation dtype (tools/train_net.py:642) -- same kernels, v_mfma_f32_16x16x32_f16, 3 more mantissa bits")
+    ap.add_argument("--ablate", default="", metavar="KEY=INT[,KEY=INT]",
+                    help="EXPERIMENT ONLY (the line is marked invalid): override integer fields of the model configuration, e.g. dec_layers=1 or "
+                         "depth=12 -- the marginal cost of a stage inside the pipelined step = the step time with and without it")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="no software pipeline over steps (ViT of step i+1 || tails of step i inside one graph)")
     return ap.parse_args()
@@ -548,7 +551,8 @@ def main():
     from ape_amd.modeling.build import build_ape, init_synthetic
     from ape_amd.runtime import GraphedForward
 
-    model = init_synthetic(build_ape(args.size), seed=0).to(dev)
+    ablate = {k: int(v) for k, v in (kv.split("=") for kv in args.ablate.split(",") if kv)}
+    model = init_synthetic(build_ape(args.size, **ablate), seed=0).to(dev)
     mv = model.model_vision
     mv.set_compute_dtype(DTYPES[args.dtype])
     S = mv.backbone.padding_constraints["square_size"]
@@ -711,7 +715,7 @@ def main():
             "metric": f"images/sec @{S}^2 APE-L_D fwd", "value": (world * args.steps * B / elapsed) if args.steps else None, "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": (1e3 * elapsed / args.steps) if args.steps else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workload_string(args.size, B, args.classes, args.semantic),
+            "config": {"workload": workload_string(args.size, B, args.classes, args.semantic) + (f" -- ABLATED {ablate}: NOT the benchmark" if ablate else ""),
                        "parallelism": f"dp{world}", "rccl_ranks": dist.get_world_size() if dist is not None else 1,
                        "cpu_affinity": affinity,
                        "graph": not args.no_graph, "pipelined_d2h": True, "images_per_step": B, "input": args.input,

@@ -522,12 +522,16 @@ def test_L_D_fp32_matches_reference(case):
     if "mask_sign_kept" in gold["full"] and "det_mask_logits" in stages:
         # north_star: "identical argmax masks" -- fp32 kernels, OWN proposal selection, the kept detections' mask logits against the
         # reference run's sign bits, pixel by pixel.  Excluded: the pixels the FIXTURE marks as ties (|reference logit| < 1e-3 of the
-        # mask's largest).  A pixel that still flips must be a near-tie that fp32 summation order decides (our logit within 5e-3 of
-        # zero relative to the mask's largest): the count and the margin are printed, anything farther from zero fails.
+        # mask's largest).  Measured on MI355X (profiles/r05_*): 0 of 6.53 million non-tie pixels differ over all 100 kept detections at
+        # L_D_coco80, L_D_padded and Ti_512 -- so the assertion is ZERO for the hot path's own configurations.  The widened families and the
+        # phrase / LVIS / 1536^2 cases keep the fractional bound (< 1e-4) with the flipped pixels required to be near-ties (|logit| within
+        # 5e-3 of zero relative to the mask's largest), count and margin printed.
         bad, total, shared, margin = _ld_mask_sign_pixels(stages, own, gold)
         print(f"[L_D fp32 {case}] argmax masks with own proposal selection: {bad} of {total} non-tie pixels differ over {shared} shared "
               f"detections; largest |logit| / absmax among them {margin:.2e}")
         assert shared >= 95 and bad <= 1e-4 * total and margin < 5e-3, (bad, total, shared, margin)
+        if case in ("L_D_coco80", "L_D_padded", "Ti_512"):
+            assert bad == 0 and shared == 100, (bad, shared)
     for k in LD_STAGES:
         if k not in gold["stages"]:
             continue                    # L_A_coco80 (plain family): no fusion stage

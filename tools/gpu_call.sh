@@ -25,13 +25,27 @@ for recipe in "$@"; do
     sweep)
       for B in ${APE_SWEEP:-2 4 8}; do b ips$B --images-per-step $B --steps $((60 / B)) --warmup 4; done
       python tools/bench_digest.py $O/bench_ips*.json | tee $O/sweep_digest.txt ;;
+    ablate)
+      # marginal cost of whole stages INSIDE the pipelined step (what a stage costs when it overlaps the rest): the step with fewer layers
+      b abl_full --steps 30 --warmup 4 --no-second-flavour
+      for a in ${APE_ABLATE:-dec_layers=1 enc_layers=1 depth=12}; do b abl_$a --steps 30 --warmup 4 --no-second-flavour --ablate $a; done
+      python - <<PY | tee $O/ablate_digest.txt
+import json, glob
+for f in sorted(glob.glob("$O/bench_abl_*.json")):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][0])
+        print(f.split("bench_abl_")[1][:-5].ljust(16), round(d["value"], 2), "images/s", round(d["ms_per_step"], 3), "ms/step")
+    except Exception as e:
+        print(f, "failed", e)
+PY
+      ;;
     meter)
       (cd /tmp && rm -rf /tmp/prof_m && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_m -o eager -- python $GRAFT_REPO_ROOT/bench.py --instrumented-only --no-cpu-baseline ${APE_BENCH_ARGS} > $GRAFT_REPO_ROOT/$O/bench_instrumented_under_rocprof.json 2> /tmp/prof_m.err; tail -2 /tmp/prof_m.err)
       find /tmp/prof_m -name "*kernel_stats.csv" -exec cp {} $O/instrumented_kernel_stats.csv \;
       python tools/bench_digest.py --vs-rocprof $O/instrumented_kernel_stats.csv $O/bench_instrumented_under_rocprof.json | tee $O/meter_vs_rocprof.txt ;;
-    ops)   timeout 900 python -m pytest tests/test_ops_gpu.py -q -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_ops.log; tail -4 $O/pytest_ops.log | cut -c1-300 ;;
-    model) timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_teacher_forced.py -q -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_model.log; tail -4 $O/pytest_model.log | cut -c1-300 ;;
-    suite) APE_WRITE_PINS=$O timeout 1700 python -m pytest tests -q -m gpu --durations=40 2>&1 | grep -v Warning > $O/pytest_gpu.log; tail -50 $O/pytest_gpu.log | cut -c1-200 ;;
+    ops)   timeout 900 python -m pytest tests/test_ops_gpu.py -q -s -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_ops.log; tail -4 $O/pytest_ops.log | cut -c1-300 ;;
+    model) timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_teacher_forced.py -q -s -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_model.log; tail -4 $O/pytest_model.log | cut -c1-300 ;;
+    suite) APE_WRITE_PINS=$O timeout 1700 python -m pytest tests -q -s -m gpu --durations=40 2>&1 | grep -v Warning > $O/pytest_gpu.log; tail -50 $O/pytest_gpu.log | cut -c1-200 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 | tee $O/smoke.log ;;
     bench) timeout 900 python bench.py ${APE_BENCH_ARGS} 2> $O/bench_default.err | tail -1 > $O/bench_default.json; cut -c1-300 $O/bench_default.json; python tools/bench_digest.py $O/bench_default.json | tee $O/bench_default_digest.txt ;;
     benches)
