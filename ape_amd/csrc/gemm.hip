@@ -671,9 +671,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
   const int nch_total = (p.N + KR_CH - 1) / KR_CH;
-  const int per = (nch_total + gridDim.y - 1) / gridDim.y;
-  const int cbeg = blockIdx.y * per;
-  const int nch = min(per, nch_total - cbeg);
+  // TAIL SPLIT (launcher: p.reserved0 = row blocks that take all columns | column parts of the rest << 16; 0 = off).  Two workgroups
+  // fit a CU, so 87 296 rows = 682 row blocks run as one full round of 512 workgroups and a second round of 170 -- a third of the
+  // slots -- which costs as much time as the first.  The launcher therefore cuts the LAST round's row blocks into S column parts each
+  // (S x 170 <= 512 workgroups, all resident at once, each with 1 / S of the columns behind its own copy of the A rows).
+  int row_block = blockIdx.x, cbeg, nch;
+  const int nfull = p.reserved0 & 0xffff, tparts = p.reserved0 >> 16;
+  if (tparts > 0 && (int)blockIdx.x >= nfull) {
+    const int t = blockIdx.x - nfull;
+    row_block = nfull + t / tparts;
+    const int part = t % tparts;
+    cbeg = part * nch_total / tparts;                              // balanced: every part gets floor or ceil of nch_total / tparts
+    nch = (part + 1) * nch_total / tparts - cbeg;
+  } else {
+    const int per = (nch_total + gridDim.y - 1) / gridDim.y;
+    cbeg = blockIdx.y * per;
+    nch = min(per, nch_total - cbeg);
+  }
   if (nch <= 0) return;
   const int nbeg = cbeg * KR_CH;
   for (int i = tid; i < nch * KR_CH; i += 256) sbias[i] = (p.bias != nullptr && nbeg + i < p.N) ? p.bias[nbeg + i] : 0.f;
@@ -681,8 +695,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kres_kernel(const GemmParams
 
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* __restrict__ W = reinterpret_cast<const bf16_t*>(p.W);
-  const int m_wave = blockIdx.x * KR_BM + wave * 32;
-  const bool rows_full = (blockIdx.x + 1) * KR_BM <= p.M;
+  const int m_wave = row_block * KR_BM + wave * 32;
+  const bool rows_full = (row_block + 1) * KR_BM <= p.M;
 
   // ---- A: 2 row tiles x 8 k-steps of B-operand fragments (lane: row = frow, k = s*32 + fq*8 .. +8)
   bf16x8_t af[2][8];
@@ -1148,7 +1162,24 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
       const int nch = ceil_div(p.N, KR_CH);
       int ysplit = ceil_div(nch, KR_MAXN / KR_CH);                  // bias slab in LDS holds KR_MAXN columns
       while (mblk * ysplit < 512 && ysplit * 2 <= nch) ysplit *= 2;   // few row blocks: spread the column chunks as well
-      const dim3 grid(mblk, ysplit);
+      dim3 grid(mblk, ysplit);
+      // tail split (see the kernel): the row blocks of a last round that would fill less than half of the 512 resident workgroups are
+      // cut into column parts so that the round is full and short.  APE_KRES_TAILSPLIT=0 restores the plain grid.
+      p.reserved0 = 0;
+      {
+        const char* te = getenv("APE_KRES_TAILSPLIT");
+        constexpr int slots = 512;                                  // 2 workgroups per CU x 256 CUs
+        const int nfull = (mblk / slots) * slots, tail = mblk - nfull;
+        // from 8 column chunks on (measured, profiles/r05_kres_probe.log: 1536 columns 120 -> 109 us, 2048: 154 -> 142; with 2 - 4 chunks the
+        // extra copies of the A rows cost more than the shorter last round gains: 480 columns 52.7 -> 56.1 us, 256: 31.8 -> 32.9)
+        if (!(te != nullptr && atoi(te) == 0) && ysplit == 1 && nfull > 0 && nfull < 65536 && tail > 0 && tail * 2 <= slots && nch >= 8) {
+          const int parts = min(nch, slots / tail);
+          if (parts >= 2) {
+            p.reserved0 = nfull | (parts << 16);
+            grid = dim3(nfull + tail * parts, 1);
+          }
+        }
+      }
       const bool res = p.residual != nullptr;          // bf16 residual only (an fp32 one does not fit the register budget)
       const bool of32 = p.out_dt == APE_DT_F32;
       if (!HF && p.out_dt == APE_DT_F16) LAUNCH_GEMM("gemm_bf16_kres_kernel<0, false, true>", (gemm_bf16_kres_kernel<0, false, true, H>), grid, KR_LDS);

@@ -97,7 +97,7 @@ typedef struct ApeGemmArgs {
   const float* ln_w;
   const float* ln_b;
   float ln_eps;
-  int32_t reserved0;
+  int32_t reserved0;      /* callers pass 0 (the library uses the field of ITS copy for a grid hint of the K = 256 kernel) */
   /* implicit-GEMM 3 x 3 convolution (stride 1, zero padding 1; SimpleFeaturePyramid's / the mask head's 3 x 3 convs at 256 channels,
    * vit_eva_clip.py:806-842, deformable_detr_segm_vl.py:728-750): conv_h > 0 makes A the conv INPUT -- a token-major [conv_h * conv_w,
    * lda] map of C = K / 9 = 256 channels whose row of raster pixel r is conv_perm[r] (NULL: r) -- and W the [N, 9 C] weight in

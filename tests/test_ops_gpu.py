@@ -184,6 +184,35 @@ def test_gemm_kres(ops, bf):
 
 
 @pytest.mark.parametrize("bf", H16)
+def test_gemm_kres_tail_split(ops, monkeypatch, bf):
+    """the K == 256 kernel's TAIL SPLIT: 87 296 encoder tokens are 682 row blocks = one full round of 512 resident workgroups + 170;
+    the launcher cuts those 170 into column parts (csrc/gemm.hip) -- bit-identical to the plain grid (APE_KRES_TAILSPLIT=0) for every
+    column count the forward uses (offsets | logits 480, value / output 256, the decoder's 6 x 256 value projection, 2048), incl. a ragged
+    last row block, a residual, IEEE-half output and a masked value projection"""
+    if SELF:
+        pytest.skip("grid selection: HIP library only")
+    K = 256
+    for (M, N) in [(87296, 480), (87296, 1024), (87296, 1536), (87000, 2048), (65536 + 128 * 3 + 5, 1280)]:
+        a, w = rnd(M, K, dtype=bf, seed=31), rnd(N, K, dtype=bf, scale=K ** -0.5, seed=32)
+        bias = rnd(N, seed=33)
+        mask = (torch.arange(M) % 7 == 1).to(DEV)
+        cases = [dict(), dict(rowmask=mask, mask_mode=ref_ops.MASK_ZERO_OUTPUT)]
+        if N <= 1024:
+            cases += [dict(residual=rnd(M, N, dtype=bf, seed=34)), dict(out_dtype=torch.float32)]
+        if bf == torch.bfloat16 and N in (480, 1536):
+            cases.append(dict(out_dtype=torch.float16))
+        for kw in cases:
+            monkeypatch.setenv("APE_KRES_TAILSPLIT", "0")
+            plain = ops.gemm(a, w, bias, **kw)
+            monkeypatch.setenv("APE_KRES_TAILSPLIT", "1")
+            got = ops.gemm(a, w, bias, **kw)
+            assert torch.equal(got, plain), (M, N, list(kw))
+        e = relerr(ops.gemm(a, w, bias), ref_ops.gemm(a, w, bias))
+        print(f"gemm kres tail split M{M} N{N}: identical to the plain grid; vs the definition {e:.3e}")
+        assert e < TOL[bf]
+
+
+@pytest.mark.parametrize("bf", H16)
 def test_gemm_kres_layernorm_epilogue(ops, bf):
     """K = N = 256 linear + bias + residual + LayerNorm in one launch (the encoder's attention output projection and the norm behind
     it) vs the two-step definition; ragged last row block; statistics on the fp32 sums"""
