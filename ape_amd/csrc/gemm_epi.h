@@ -217,7 +217,10 @@ __device__ __forceinline__ void epi_cols_load(const GemmParams& p, int nb, EpiCo
 // Without NORM the bias is already inside v: the tile kernel starts its accumulators from it (the bias is added before everything else
 // in the epilogue order, and "+ bias" commutes with the accumulation up to fp32 rounding) -- no loads, no live registers.
 template <int W, bool ROPE, bool NORM, int ACT, typename H = bf16_t, bool ROPE_LDS = false>
-__device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb, float (&v)[W], const EpiCols<W>& cols, const float* cs = nullptr) {
+// skip_residual: the caller adds the residual itself, LAST, like this function does (gemm_p8.hip fetches the fp32 residual of its
+// 256 x 128 tiles ahead of the epilogue and holds it in registers)
+__device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb, float (&v)[W], const EpiCols<W>& cols, const float* cs = nullptr,
+                                             bool skip_residual = false) {
   if (NORM) {
     const float rs = p.rowscale[m], sh = p.rowshift[m];
 #pragma unroll
@@ -267,7 +270,7 @@ __device__ __forceinline__ void epi_row_fast(const GemmParams& p, int m, int nb,
     for (int e = 0; e < W / 2; ++e) v[e] = silu_mul_fast(v[2 * e], v[2 * e + 1]);
     return;
   }
-  if (p.residual != nullptr) {
+  if (!skip_residual && p.residual != nullptr) {
     const size_t roff = (size_t)m * p.ldr + nb;
     if (p.res_dt == APE_DT_F32) {
       float r[W];

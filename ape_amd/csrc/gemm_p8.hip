@@ -332,6 +332,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   }
   init_acc(false);
 
+  // ---- fp32 RESIDUAL ahead of the epilogue (256 x 128 tiles: 138 of 256 registers in use).  The N = 1024 projections of the ViT add
+  // the fp32 residual stream: 256 tiles = one per CU, so every CU reaches its epilogue at the same moment and the chip then reads
+  // 33.5 MB and writes 33.5 MB with nothing to overlap -- half of the 29 us launch.  The tile's residual values (8 rows x 8 floats per
+  // lane) are therefore requested HERE, behind the prologue, and arrive under the main loop (vmcnt retires in order: the first
+  // phase-4 wait of the loop covers them); the epilogue finds them in registers and only the store burst is left at the end.
+  // Inline-asm loads: invisible to hipcc's wait-count pass (an ordinary load beside LDS-DMA traffic is answered with vmcnt(0)); the
+  // registers are touched again only behind the main loop.  APE_P8_RESPF=0 (read by the launcher -> ApeGemmArgs.reserved0 bit 30) off.
+  constexpr bool RESPF = BN == 128 && !CONV && !PERSIST && ABL == 0;
+  f32x4_t rpre[RESPF ? 8 : 1][RESPF ? 2 : 1];
+  bool respf = false;
+  if (RESPF) {
+    respf = fast && p.residual != nullptr && p.res_dt == APE_DT_F32 && p.rope_cos == nullptr && p.act != APE_ACT_SWIGLU && !(p.reserved0 & (1 << 30));
+    if (respf) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int m = m0 + wr * 128 + i * 16 + frow;
+        m = m < p.M ? m : p.M - 1;
+        const float* rp = reinterpret_cast<const float*>(p.residual) + (size_t)m * p.ldr + n0 + wc * WN + fq * W;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rpre[i][k]) : "v"(rp + 4 * k) : "memory");
+      }
+    }
+  }
+
   // ================================================================== tile loop (one pass unless the launch is persistent)
   bool prefetched = false;          // this tile's first K tiles (and its bias) were staged behind the previous tile's main loop
   bool acc_from_lds = false;        // ... and its bias waits in this wave's LDS slot
@@ -486,7 +510,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
             for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], c, sn);
           }
         } else {
-          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, enb, o, cols, cs);
+          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, enb, o, cols, cs, RESPF && respf);
+          if (RESPF && respf) {                // the residual fetched ahead of the main loop: landed long ago (in-order vmcnt, main-loop waits)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              asm volatile("" : "+v"(rpre[RESPF ? i : 0][RESPF ? k : 0]));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o[RESPF ? 4 * k + r : 0] += rpre[RESPF ? i : 0][RESPF ? k : 0][r];
+            }
+          }
         }
         if (DEFER) {
 #pragma unroll
@@ -591,6 +623,10 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   }
   const int tiles = ceil_div(p.M, P8_BM) * ceil_div(p.N, bn);
   const bool f16 = p.in_dt == APE_DT_F16;
+  {
+    const char* re = getenv("APE_P8_RESPF");       // 0: no residual prefetch in the 256 x 128 tile kernel (A/B, tests)
+    p.reserved0 = (re != nullptr && atoi(re) == 0) ? (1 << 30) : 0;
+  }
   const char* name = nullptr;
   // PERSISTENT grid: a launch with more tiles than CUs gets one workgroup per CU (rounded down to a multiple of 8: the tile order is
   // XCD-aware), each walking the tiles the plain launch would have sent to that CU one workgroup after another -- and staging tile

@@ -950,6 +950,30 @@ def test_gemm_p8_persistent(ops, monkeypatch, bf):
     assert b"persistent" in lib.ape_hip_gemm_last_kernel()            # the default
 
 
+@pytest.mark.parametrize("bf", H16)
+def test_gemm_p8_residual_prefetch(ops, monkeypatch, bf):
+    """the 256 x 128 tile kernel requests a tile's fp32 RESIDUAL ahead of its main loop (inline-asm loads into registers the epilogue
+    reads; the N = 1024 projections of the ViT, vit_eva_clip.py:264-268,125-132): bit-identical to the epilogue loading it
+    (APE_P8_RESPF=0), for fp32 and 16-bit outputs, with the folded LayerNorm of the down projection, ragged M / N edges, repeated
+    launches (a register read before its load has landed would differ from run to run)"""
+    if SELF:
+        pytest.skip("kernel-internal data path: HIP library only")
+    for (M, N, K) in [(8192, 1024, 1024), (8192, 1024, 2752 // 64 * 64), (4096 + 100, 1024, 512), (8192, 896 + 64, 256), (300, 384, 64)]:
+        a, w = rnd(M, K, dtype=bf, seed=41), rnd(N, K, dtype=bf, scale=K ** -0.5, seed=42)
+        bias, res = rnd(N, seed=43), rnd(M, N, seed=44)
+        rs, sh, cv = rnd(M, seed=45).abs() + 0.5, rnd(M, seed=46), rnd(N, seed=47)
+        for kw in (dict(out_dtype=torch.float32), dict(out_dtype=bf), dict(out_dtype=torch.float32, rownorm=(rs, sh, cv)), dict(out_dtype=torch.float32, act=ref_ops.ACT_RELU)):
+            monkeypatch.setenv("APE_P8_RESPF", "0")
+            plain = ops.gemm(a, w, bias, residual=res, tile64=4, **kw)
+            monkeypatch.setenv("APE_P8_RESPF", "1")
+            for rep in range(3):
+                got = ops.gemm(a, w, bias, residual=res, tile64=4, **kw)
+                assert torch.equal(got, plain), (M, N, K, list(kw), rep)
+        e = relerr(ops.gemm(a, w, bias, residual=res, tile64=4, out_dtype=torch.float32), ref_ops.gemm(a, w, bias, residual=res, out_dtype=torch.float32))
+        print(f"gemm p8<128> residual prefetch M{M} N{N} K{K}: identical; vs the definition {e:.3e}")
+        assert e < 3e-4
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])
 def test_geometry_kernel(ops, dt):
     """csrc/geometry.hip (per-image-size constants written into the graph's fixed buffers) == the tensor-level definition

@@ -46,6 +46,50 @@ def make(M, N, K, kind, dt, dev):
     return a, w, bias, kw
 
 
+def respf_table(dev, lib):
+    """the fp32-residual prefetch of the 256 x 128 tile kernel (APE_P8_RESPF): stand-alone and back-to-back, cold operands"""
+    import time
+    print(f"\n{'M':>6} {'N':>5} {'K':>5} | residual prefetch: stand-alone us  off / on | back-to-back us  off / on")
+    for (M, N, K) in [(8192, 1024, 1024), (8192, 1024, 2752 // 64 * 64), (16384, 1024, 1024)]:
+        g = torch.Generator().manual_seed(M + K)
+        R = 6
+        As = [torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev) for _ in range(R)]
+        Rs = [torch.randn(M, N, generator=g).to(dev) for _ in range(R)]
+        Cs = [torch.empty(M, N, device=dev) for _ in range(R)]
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        st = [0]
+
+        def run():
+            i = st[0] = (st[0] + 1) % R
+            return ops.gemm(As[i], w, bias, residual=Rs[i], out=Cs[i], tile64=4)
+        alone, b2b = {}, {}
+        ts = {"0": [], "1": []}
+        for rnd in range(4):
+            for mode in ("0", "1"):
+                os.environ["APE_P8_RESPF"] = mode
+                run(); torch.cuda.synchronize()
+                lib.ape_hip_meter_begin()
+                for _ in range(6):
+                    run(); torch.cuda.synchronize()
+                n = lib.ape_hip_meter_end()
+                ms, nm = ctypes.c_float(), ctypes.c_char_p()
+                for i in range(n):
+                    lib.ape_hip_meter_read(i, ctypes.byref(nm), ctypes.byref(ms))
+                    ts[mode].append(ms.value * 1e3)
+        for mode in ("0", "1"):
+            os.environ["APE_P8_RESPF"] = mode
+            alone[mode] = sorted(ts[mode])[len(ts[mode]) // 2]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            run(); s.record()
+            for _ in range(24):
+                run()
+            e.record(); e.synchronize()
+            b2b[mode] = s.elapsed_time(e) * 1e3 / 24
+        print(f"{M:6d} {N:5d} {K:5d} | {alone['0']:30.1f} / {alone['1']:.1f} | {b2b['0']:18.1f} / {b2b['1']:.1f}", flush=True)
+    os.environ.pop("APE_P8_RESPF", None)
+
+
 def main():
     dev = torch.device("cuda")
     lib = _lib.load()
@@ -97,6 +141,7 @@ def main():
             d = (outs["0"].float() - outs["1"].float()).abs()
             print(f"   MISMATCH: max abs diff {float(d.max()):.4g}, {int((d > 0).sum())} elements, first at {torch.nonzero(d > 0)[0].tolist()}")
     os.environ.pop("APE_P8_PERSIST", None)
+    respf_table(dev, lib)
 
 
 if __name__ == "__main__":
