@@ -51,7 +51,11 @@ PY
     benches)
       b f16 --dtype f16; b input_uint8 --input uint8; b lvis1203_top300 --classes 1203 --size L_D; b stream_coco --stream coco
       b 1536_semantic --size L_D_1536 --semantic --steps 30; b one_image_per_step --images-per-step 1; b L_A --size L_A
-      timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_torchrun_n1.json; cut -c1-160 $O/bench_torchrun_n1.json ;;
+      timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_torchrun_n1.json; cut -c1-160 $O/bench_torchrun_n1.json
+      # the N > 1 code path end to end on a 1-GPU box: two ranks SHARE the device (gloo: RCCL refuses two ranks on one GPU) -- mask format
+      # "both", lagged all-gather of records + run lengths, per-rank rates, the same-process N = 1 reference and efficiency_vs_n1.  The
+      # throughput of such a run means nothing; that every field is produced does
+      APE_BENCH_SHARE_GPU=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --solo-steps 6 --no-cpu-baseline 2> $O/bench_n2_shared_gpu_gloo.err | tail -1 > $O/bench_n2_shared_gpu_gloo.json; cut -c1-200 $O/bench_n2_shared_gpu_gloo.json; tail -2 $O/bench_n2_shared_gpu_gloo.err | cut -c1-200 ;;
     profile) ./tools/gpu_profile.sh $TAG ${APE_BENCH_ARGS} 2>&1 | tail -3 | cut -c1-160; mv gpurun_out/${TAG}_* $O/ 2>/dev/null; rm -f $O/*kernel_trace.csv.gz ;;
     pmc) ./tools/gpu_pmc.sh $TAG ${APE_PMC_GROUPS:-2} 2>&1 | tail -14 | cut -c1-220; cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_summary.txt 2>/dev/null ;;
     py:*) s=${recipe#py:}; timeout 900 python tools/$s ${APE_PY_ARGS} > $O/${s%.py}.log 2>&1; tail -40 $O/${s%.py}.log | cut -c1-220 ;;

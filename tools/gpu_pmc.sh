@@ -10,7 +10,7 @@ groups=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ
 ngrp=${2:-3}
 for grp in "${groups[@]:0:$ngrp}"; do
   name=$(echo $grp | tr ' ' '+' | cut -c1-40)
-  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-graph --no-pipeline --images-per-step 2 > $out/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-second-flavour --no-graph --no-pipeline --images-per-step 2 > $out/$name.log 2>&1
   echo "pass [$grp] rc=$?"
 done
 cd $GRAFT_REPO_ROOT

@@ -13,7 +13,7 @@ rm -rf /tmp/prof_e /tmp/prof_g
 # `roofline.avg_launch_us` must agree with
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_e -o eager -- python $R/bench.py --instrumented-only --no-cpu-baseline "$@" > $R/gpurun_out/${TAG}_bench_eager_under_rocprof.json 2> /tmp/prof_e.err
 find /tmp/prof_e -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_eager_kernel_stats.csv \;
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_g -o graph -- python $R/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_bench_graph_under_rocprof.json 2> /tmp/prof_g.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_g -o graph -- python $R/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline --no-second-flavour > $R/gpurun_out/${TAG}_bench_graph_under_rocprof.json 2> /tmp/prof_g.err
 find /tmp/prof_g -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${TAG}_graph_kernel_stats.csv \;
 find /tmp/prof_g -name "*kernel_trace.csv" -exec python $R/tools/trace_busy.py {} \; > $R/gpurun_out/${TAG}_graph_busy.txt 2>&1
 find /tmp/prof_g -name "*kernel_trace.csv" -exec gzip -c {} \; > $R/gpurun_out/${TAG}_graph_kernel_trace.csv.gz
