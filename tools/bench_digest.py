@@ -48,7 +48,8 @@ def main():
             print(path, "no JSON line")
             continue
         r = d["roofline"]
-        print(f"{path}: {d['value']:.2f} {d['unit']}  {d['ms_per_step']:.2f} ms/step  B={d['config'].get('images_per_step')}  dtype={d['dtype']}")
+        val = f"{d['value']:.2f} {d['unit']}  {d['ms_per_step']:.2f} ms/step" if d.get("value") else "(instrumented pass only: no timed region)"
+        print(f"{path}: {val}  B={d['config'].get('images_per_step')}  dtype={d['dtype']}")
         print(f"  roofline {r['kernel']}: frac {r['frac']:.4f} ({r['achieved']:.0f} TF/s), {r['avg_launch_us']:.1f} us/launch exact"
               f" ({r.get('avg_launch_us_event_pair', float('nan')):.1f} event pair -> {r.get('frac_event_pair', float('nan')):.4f}), {r['launches_per_image']:.1f} launches/image, traffic {r.get('traffic')}")
         for sh, v in r.get("by_shape", {}).items():
