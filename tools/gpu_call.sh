@@ -56,6 +56,9 @@ PY
       # "both", lagged all-gather of records + run lengths, per-rank rates, the same-process N = 1 reference and efficiency_vs_n1.  The
       # throughput of such a run means nothing; that every field is produced does
       APE_BENCH_SHARE_GPU=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --solo-steps 6 --no-cpu-baseline 2> $O/bench_n2_shared_gpu_gloo.err | tail -1 > $O/bench_n2_shared_gpu_gloo.json; cut -c1-200 $O/bench_n2_shared_gpu_gloo.json; tail -2 $O/bench_n2_shared_gpu_gloo.err | cut -c1-200 ;;
+    benches_wide)   # the widened model families: APE on ViT-e, EVA-01 MIM ViT-g (1024^2 / 1536^2), EVA-01-CLIP ViT-g
+      b E_D --size E_D --steps 20 --warmup 3 --no-second-flavour; b V_A --size V_A --steps 20 --warmup 3 --no-second-flavour
+      b V_A_1536 --size V_A_1536 --steps 10 --warmup 2 --no-second-flavour; b G_A --size G_A --steps 10 --warmup 2 --no-second-flavour ;;
     profile) ./tools/gpu_profile.sh $TAG ${APE_BENCH_ARGS} 2>&1 | tail -3 | cut -c1-160; mv gpurun_out/${TAG}_* $O/ 2>/dev/null; rm -f $O/*kernel_trace.csv.gz ;;
     pmc) ./tools/gpu_pmc.sh $TAG ${APE_PMC_GROUPS:-2} 2>&1 | tail -14 | cut -c1-220; cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_summary.txt 2>/dev/null ;;
     py:*) s=${recipe#py:}; timeout 900 python tools/$s ${APE_PY_ARGS} > $O/${s%.py}.log 2>&1; tail -40 $O/${s%.py}.log | cut -c1-220 ;;
