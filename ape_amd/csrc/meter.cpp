@@ -74,3 +74,20 @@ extern "C" int ape_hip_meter_read(int i, const char** name, float* ms) {
   }
   return 0;
 }
+
+// Zero-fill of a device buffer on a stream (hipMemsetAsync: a memset node when the stream is being captured).  The forward pass has two
+// operand buffers whose padding columns must be finite -- the transposed V of the ViT and of the decoder's self-attention -- and cleared
+// them with the tensor library's fill kernel; this entry makes that the library's own call (ape_amd.ops.zeros).
+extern "C" int ape_hip_zero(void* ptr, size_t nbytes, void* stream) {
+  if (nbytes == 0) return 0;
+  if (ptr == nullptr) {
+    ape_set_error("ape_hip_zero: null pointer");
+    return -1;
+  }
+  const hipError_t rc = hipMemsetAsync(ptr, 0, nbytes, (hipStream_t)stream);
+  if (rc != hipSuccess) {
+    ape_set_error("ape_hip_zero: %s", hipGetErrorString(rc));
+    return -2;
+  }
+  return 0;
+}

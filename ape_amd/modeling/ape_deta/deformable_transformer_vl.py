@@ -107,7 +107,7 @@ class DeformableDetrTransformerDecoderVL(nn.Module):
         value_all = ops.gemm(memory, P["wval"], P["bval"], rowmask=geo.mask_u8, mask_mode=ops.MASK_ZERO_OUTPUT,
                              **half_value_kwargs(dt, memory.shape[0]))
         Q = query.shape[0]
-        vt_buf = torch.zeros((E, round_up(Q, 64)), dtype=dt, device=query.device)
+        vt_buf = ops.zeros((E, round_up(Q, 64)), dt, query.device)
         vr4 = geo.vr4                                                   # [L, 4] = cat(valid_ratios, valid_ratios)
         out = query
         outp = query_sum if query_sum is not None else (query.float() + query_pos.float()).to(dt)

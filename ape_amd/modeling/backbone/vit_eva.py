@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...packing import attach_cache, f32, pack_matrix, round_up
+from ...packing import attach_cache, f32, pack_matrix, resize_pos_embed, round_up
 from ...stagetap import tap
 from .vit_eva_clip import Backbone, LastLevelMaxPool, PatchEmbed, SimpleFeaturePyramid, padded_head_dim, window_major_order  # noqa: F401
 
@@ -243,8 +243,7 @@ class ViT(Backbone):
                 pos = pos[:, 1:]
             size = int(math.sqrt(pos.shape[1]))
             if size != hw:
-                pos = F.interpolate(pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(hw, hw), mode="bicubic",
-                                    align_corners=False).permute(0, 2, 3, 1)
+                pos = resize_pos_embed(pos.reshape(size * size, -1), size, hw)       # the bicubic resize as one GEMM (packing.py)
             pos = pos.reshape(hw * hw, -1)[t2r.long()].contiguous()
             w = self.patch_embed.proj.weight
             j = torch.arange(ws * ws, device=dev)
@@ -276,7 +275,7 @@ class ViT(Backbone):
         x = tap(stages, "vit_embed", ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32))
         nwin = (hw // self.window_size) ** 2 * B
         Ep = self.blocks[0].attn.num_heads * padded_head_dim(self.embed_dim // self.blocks[0].attn.num_heads)
-        vt_buf = torch.zeros((Ep, round_up(B * n, 64)), dtype=dt, device=x.device)
+        vt_buf = ops.zeros((Ep, round_up(B * n, 64)), dt, x.device)
         for i, blk in enumerate(self.blocks):
             coords = P["coords_win"] if blk.window_size > 0 else P["coords_glb"]
             x = blk.forward_tokens(x, dt, coords, nwin, self.window_size ** 2, vt_buf, last=(i == len(self.blocks) - 1), images=B)

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...packing import attach_cache, f32, pack_matrix, round_up
+from ...packing import attach_cache, f32, pack_matrix, resize_pos_embed, round_up
 from ...stagetap import tap
 
 __all__ = ["ViT", "SimpleFeaturePyramid"]
@@ -345,8 +345,7 @@ class ViT(Backbone):
                 pos = pos[:, 1:]
             size = int(math.sqrt(pos.shape[1]))
             if size != hw:
-                pos = F.interpolate(pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(hw, hw), mode="bicubic",
-                                    align_corners=False).permute(0, 2, 3, 1)
+                pos = resize_pos_embed(pos.reshape(size * size, -1), size, hw)       # the bicubic resize as one GEMM (packing.py)
             pos = pos.reshape(hw * hw, -1)[t2r.long()].contiguous()
             w = self.patch_embed.proj.weight
             return dict(
@@ -382,7 +381,7 @@ class ViT(Backbone):
         x = tap(stages, "vit_embed", ops.gemm(patches, P["wpe"], P["bpe"], residual=pos, out_dtype=torch.float32))
         nwin = (hw // self.window_size) ** 2 * B
         Ep = self.blocks[0].packed(dt)["Ep"]
-        vt_buf = torch.zeros((Ep, round_up(B * n, 64)), dtype=dt, device=x.device)
+        vt_buf = ops.zeros((Ep, round_up(B * n, 64)), dt, x.device)
         if self.postnorm:
             # the fp32 stream is updated IN PLACE by the post-norm residual kernel: with taps, work on a private copy (a forced
             # tensor belongs to the teacher) and record copies

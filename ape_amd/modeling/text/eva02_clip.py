@@ -136,7 +136,7 @@ class TextTransformer(nn.Module):
         Lp = round_up(L, 8)
         x = ops.embed_tokens(tok, P["emb"], P["pos"], L, Lp)         # [B * Lp, W] fp32
         # V^T is read in 64-column tiles from each text's first column: (B - 1) * Lp + round_up(L, 64) <= round_up(B * Lp, 64) + 64
-        vt_buf = torch.zeros((self.width, round_up(B * Lp, 64) + 64), dtype=dt, device=x.device)
+        vt_buf = ops.zeros((self.width, round_up(B * Lp, 64) + 64), dt, x.device)
         for blk in self.transformer.resblocks:
             x = blk.forward_tokens(x, dt, B, L, Lp, vt_buf)
         rows = (torch.arange(B, device=x.device) * Lp + eot).to(torch.int32)

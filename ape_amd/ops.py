@@ -172,6 +172,15 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     return out
 
 
+def zeros(shape, dtype, device):
+    """a zero-filled device tensor WITHOUT a tensor-library launch: torch.empty (no kernel) + the library's stream-ordered zero-fill
+    (ape_hip_zero: hipMemsetAsync, a memset node under capture) -- the padded V^T operand buffers of the forward"""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    _dev(t)
+    _lib.check(_lib.load().ape_hip_zero(t.data_ptr(), t.numel() * t.element_size(), _stream()), "ape_hip_zero")
+    return t
+
+
 def gemm_norm_fusable(a, w, residual=None, out_dtype=None):
     """can `gemm(a, w, ..., residual=residual, norm=...)` run the LayerNorm in its epilogue?  (csrc/gemm.hip gemm_kres_ln_kernel)"""
     return (a.dtype in HALF16 and a.shape[1] == 256 and w.shape[0] == 256 and a.shape[0] >= 2048 and (out_dtype or a.dtype) == a.dtype

@@ -61,3 +61,43 @@ class PackCache:
 def attach_cache(module):
     module._pack = PackCache()
     module.register_load_state_dict_post_hook(lambda m, incompatible: m._pack.clear())
+
+
+def _cubic_axis_weights(n_in, n_out):
+    """[n_out, n_in] float64: one axis of torch's bicubic resampling (`F.interpolate(mode="bicubic", align_corners=False)`: cubic
+    convolution with A = -0.75 around src = (n_in / n_out) (dst + 0.5) - 0.5, the four taps' indices clamped to the border) written as a
+    matrix -- the resampling is linear in the input"""
+    import math
+
+    import numpy as np
+    A = -0.75
+
+    def near(x):          # |x| <= 1
+        return ((A + 2.0) * x - (A + 3.0)) * x * x + 1.0
+
+    def far(x):           # 1 < |x| < 2
+        return ((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A
+    W = np.zeros((n_out, n_in), dtype=np.float64)
+    scale = n_in / n_out
+    for o in range(n_out):
+        src = scale * (o + 0.5) - 0.5
+        i0 = math.floor(src)
+        t = src - i0
+        for k, wk in enumerate((far(t + 1.0), near(t), near(1.0 - t), far(2.0 - t))):
+            W[o, min(max(i0 - 1 + k, 0), n_in - 1)] += wk
+    return W
+
+
+def resize_pos_embed(pos, size, hw):
+    """get_abs_pos' resize (ape/modeling/backbone/utils_eva02.py:158-187: F.interpolate(bicubic, align_corners=False) of the pretraining
+    grid's position embedding to the token grid) as ONE GEMM of the library: bicubic resampling is a separable linear map, so
+    out[(y, x), :] = sum_ij Wy[y, i] Wx[x, j] pos[(i, j), :] = (Wy (x) Wx) . pos with the Kronecker matrix built on the host in float64
+    (4096 x 576 for APE-L_D: 9 MB).  pos [size * size, C] fp32 on the model's device -> [hw * hw, C] fp32.  A per-model constant,
+    computed once at weight-packing time; rounds 1-4 called torch's bicubic kernel here."""
+    import numpy as np
+
+    from . import ops
+    w1 = _cubic_axis_weights(size, hw)
+    kron = torch.from_numpy(np.kron(w1, w1).astype(np.float32)).to(pos.device)          # square grids: the same matrix on both axes
+    return ops.gemm(kron, pos.detach().float().t().contiguous(), None, out_dtype=torch.float32)
+

@@ -123,6 +123,9 @@ int ape_hip_meter_begin(void);
 int ape_hip_meter_count(void);
 int ape_hip_meter_end(void);
 int ape_hip_meter_read(int i, const char** name, float* ms);
+/* zero-fill of a device buffer on a stream (hipMemsetAsync; captured as a memset node): the padded V^T operand buffers of the forward --
+ * replaces the tensor library's fill kernel on the path (torch.zeros in rounds 1-4) -- csrc/meter.cpp */
+int ape_hip_zero(void* ptr, size_t nbytes, void* stream);
 
 /* per-row LayerNorm statistics of x [M, C] (row stride ldx): rowscale[m] = rsqrt(var_m + eps), rowshift[m] = -mean_m * rowscale[m]
  * (biased variance, two passes) -- the row terms of the folded LayerNorm above.  -- csrc/norm.hip */

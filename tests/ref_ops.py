@@ -670,3 +670,8 @@ def panoptic_merge(masks, scores, keep, classes, isthing, height, width, *, prob
                 info[n] = torch.tensor([cur, int(thing), c - stuff_offset + 1 if (not thing and stuff_offset >= 0) else c], dtype=torch.int32)
                 n += 1
     return panoptic_seg, info, torch.tensor([n], dtype=torch.int32, device=dev)
+
+
+def zeros(shape, dtype, device):
+    return torch.zeros(shape, dtype=dtype, device=device)
+
