@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...packing import attach_cache, f32, pack_matrix, resize_pos_embed, round_up
+from ...packing import attach_cache, f32, pack_matrix, round_up
 from ...stagetap import tap
 from .vit_eva_clip import Backbone, PatchEmbed, SimpleFeaturePyramid, VisionRotaryEmbeddingFast  # noqa: F401
 
@@ -192,8 +192,9 @@ class ViT(Backbone):
             if self.pretrain_use_cls_token:
                 pos = pos[:, 1:]
             size = int(math.sqrt(pos.shape[1]))
-            if size != hw:                             # get_abs_pos (utils_eva02.py:158-187): the bicubic resize as one GEMM
-                pos = resize_pos_embed(pos.reshape(size * size, -1), size, hw)
+            if size != hw:                             # get_abs_pos (utils_eva02.py:158-187)
+                pos = F.interpolate(pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(hw, hw), mode="bicubic",
+                                    align_corners=False).permute(0, 2, 3, 1)
             w = self.patch_embed.proj.weight
             d = dict(hw=hw, ident=torch.arange(n, dtype=torch.int32, device=dev), pos=pos.reshape(n, -1).contiguous(),
                      wpe=pack_matrix(w.reshape(w.shape[0], -1), dt), bpe=f32(self.patch_embed.proj.bias),

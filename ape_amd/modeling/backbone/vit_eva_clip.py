@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
-from ...packing import attach_cache, f32, pack_matrix, resize_pos_embed, round_up
+from ...packing import attach_cache, f32, pack_matrix, round_up
 from ...stagetap import tap
 
 __all__ = ["ViT", "SimpleFeaturePyramid"]
@@ -345,7 +345,8 @@ class ViT(Backbone):
                 pos = pos[:, 1:]
             size = int(math.sqrt(pos.shape[1]))
             if size != hw:
-                pos = resize_pos_embed(pos.reshape(size * size, -1), size, hw)       # the bicubic resize as one GEMM (packing.py)
+                pos = F.interpolate(pos.reshape(1, size, size, -1).permute(0, 3, 1, 2), size=(hw, hw), mode="bicubic",
+                                    align_corners=False).permute(0, 2, 3, 1)
             pos = pos.reshape(hw * hw, -1)[t2r.long()].contiguous()
             w = self.patch_embed.proj.weight
             return dict(

@@ -92,8 +92,13 @@ def resize_pos_embed(pos, size, hw):
     """get_abs_pos' resize (ape/modeling/backbone/utils_eva02.py:158-187: F.interpolate(bicubic, align_corners=False) of the pretraining
     grid's position embedding to the token grid) as ONE GEMM of the library: bicubic resampling is a separable linear map, so
     out[(y, x), :] = sum_ij Wy[y, i] Wx[x, j] pos[(i, j), :] = (Wy (x) Wx) . pos with the Kronecker matrix built on the host in float64
-    (4096 x 576 for APE-L_D: 9 MB).  pos [size * size, C] fp32 on the model's device -> [hw * hw, C] fp32.  A per-model constant,
-    computed once at weight-packing time; rounds 1-4 called torch's bicubic kernel here."""
+    (4096 x 576 for APE-L_D: 9 MB).  pos [size * size, C] fp32 on the model's device -> [hw * hw, C] fp32.
+    NOT used by the backbones: it agrees with torch's kernel to 1e-6 (tests/test_host_model.py), and the 1e-6 is what rules it out -- the
+    reference fixtures were produced with torch's bicubic arithmetic, and at 1536^2 the fp32 pipeline sits just inside its 1e-3 bar
+    against them (logits 9.6e-4, boxes 5.2e-4); with this embedding it measured logits 5.5e-4, boxes 1.04e-3 (round 5,
+    profiles/r05_pos_embed_gemm_experiment.log): the random-weight model turns 1e-6 into 1e-3 either way, and only one of the two is
+    the reference's arithmetic.  The
+    backbones keep F.interpolate at weight-packing time (a per-model constant, off the forward path)."""
     import numpy as np
 
     from . import ops
