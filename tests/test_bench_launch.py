@@ -83,3 +83,36 @@ def test_mask_format_default_is_the_same_contract_for_every_rank_count():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '("both" if world > 1 else "bitmask")' in src
     assert '"rle" if world > 1' not in src
+
+
+def test_roofline_traffic_is_refused_unless_the_pmc_summary_was_measured_on_this_build(tmp_path, monkeypatch):
+    """bench.pmc_traffic_bytes: the newest profiles/*_pmc_summary.txt counts only when its `# library_digest` header equals the digest
+    of the sources bench.py runs on (ape_amd.build._digest()); a summary of another build -> (None, why).  The family's instantiations
+    (dense, persistent, convolution) are launch-weighted."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from ape_amd import build
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    rows = ("kernel | launches | FETCH_SIZE | WRITE_SIZE | HBM MB/launch\n"
+            "gemm_bf16_p8_kernel<256, true, unsigned short, 0, false, tru |   100 | 1 | 1 | 200.0\n"
+            "gemm_bf16_p8_kernel<256, true, unsigned short, 0, false, fal |   300 | 1 | 1 | 100.0\n"
+            "gemm_bf16_p8_kernel<128, true, unsigned short, 0, false, fal |   500 | 1 | 1 | 50.0\n")
+    (prof / "r09_pmc_summary.txt").write_text("# library_digest deadbeef\n" + rows)
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, why = bench.pmc_traffic_bytes("gemm_bf16_p8_kernel<256, true>")
+    assert t is None and "refused" in why and "deadbeef" in why
+    (prof / "r09_pmc_summary.txt").write_text(f"# library_digest {build._digest()}\n" + rows)
+    t, why = bench.pmc_traffic_bytes("gemm_bf16_p8_kernel<256, true>")
+    assert abs(t - 125.0 * 1024 * 1024) < 1.0 and "400 launches" in why          # (100 x 200 + 300 x 100) / 400 MB
+    t, _ = bench.pmc_traffic_bytes("gemm_bf16_p8_kernel<128, true>")
+    assert abs(t - 50.0 * 1024 * 1024) < 1.0
+
+
+def test_kernel_family_folds_the_tile_kernels_instantiations():
+    sys.path.insert(0, ROOT)
+    import bench
+    fam = bench.GemmMeter.family
+    assert fam("gemm_bf16_p8_kernel<256, true, conv3x3>") == fam("gemm_bf16_p8_kernel<256, true, persistent>") == "gemm_bf16_p8_kernel<256, true>"
+    assert fam("gemm_bf16_p8_kernel<256, true>") == "gemm_bf16_p8_kernel<256, true>" and fam("gemm_f16_p8_kernel<128, true, conv3x3>") == "gemm_f16_p8_kernel<128, true>"
+    assert fam("gemm_bf16_kres_kernel<0, false, true>") == "gemm_bf16_kres_kernel<0, false, true>"
