@@ -55,20 +55,40 @@ def build(force=False, verbose=True):
     procs = []
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
+    # per-object stamps: an object is rebuilt only when its own source, a header of csrc/ (or include/ape_hip.h) or its flags changed --
+    # iterating on one kernel then costs one hipcc run, not eighteen
+    hh = hashlib.sha256()
+    for f in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(HERE, "..", "include", "ape_hip.h")]:
+        with open(f, "rb") as fh:
+            hh.update(fh.read())
+    headers_digest = hh.hexdigest()
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [HIPCC] + FILE_FLAGS.get(os.path.basename(src), FLAGS) + ["-c", src, "-o", obj]
         if src.endswith(".cpp"):
             cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        with open(src, "rb") as fh:
+            odig = hashlib.sha256(fh.read() + headers_digest.encode() + " ".join(cmd).encode()).hexdigest()
+        ostamp = obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
         if verbose:
             print("[ape_amd.build]", " ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, pr in procs:
+        procs.append((src, ostamp, odig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = None
+    for src, ostamp, odig, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             sys.stderr.write(out.decode())
-            raise RuntimeError(f"hipcc failed on {src}")
+            failed = failed or src
+            continue
+        with open(ostamp, "w") as fh:
+            fh.write(odig)
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print("[ape_amd.build]", " ".join(cmd), flush=True)

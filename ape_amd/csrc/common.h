@@ -150,10 +150,10 @@ void ape_set_error(const char* fmt, ...);
 // elapsed time is the dispatch's begin-to-end duration (what rocprofv3's kernel trace reports).  KERNEL is stringified as the launch's
 // name in the meter's records: the template expression as written at the launch site.
 #include <hip/hip_ext.h>
-hipEvent_t* ape_meter_pair(const char* kernel);
+hipEvent_t* ape_meter_pair(const char* kernel, hipStream_t stream);
 #define APE_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...)                                                                  \
   do {                                                                                                                     \
-    hipEvent_t* ev__ = ape_meter_pair(#KERNEL);                                                                            \
+    hipEvent_t* ev__ = ape_meter_pair(#KERNEL, STREAM);                                                                           \
     if (ev__ != nullptr) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, ev__[0], ev__[1], 0, __VA_ARGS__);        \
     else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                                                \
   } while (0)
@@ -175,6 +175,28 @@ hipEvent_t* ape_meter_pair(const char* kernel);
   } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+// ---- per-DEVICE launcher state: function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) and the CU count belong to
+// the device that is current at the launch, not to the first one a process happened to use
+constexpr int APE_MAX_DEVICES = 64;
+static inline int ape_current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= APE_MAX_DEVICES) d = 0;
+  return d;
+}
+struct ApeOncePerDevice {          // `static ApeOncePerDevice f; if (f.first()) { ...set attributes... }`
+  bool done[APE_MAX_DEVICES] = {};
+  bool first() { const int d = ape_current_device(); const bool f = !done[d]; done[d] = true; return f; }
+};
+static inline int ape_cu_count() {   // compute units of the current device, rounded down to a multiple of 8 (XCD-aware tile orders); 256 if unknown
+  static int n[APE_MAX_DEVICES] = {};
+  const int d = ape_current_device();
+  if (n[d] == 0) {
+    int c = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || c < 8) c = 256;
+    n[d] = c & ~7;
+  }
+  return n[d];
+}
 static inline bool ape_is16(int dt) { return dt == APE_DT_BF16 || dt == APE_DT_F16; }
 // the 16-bit storage kind of one call: 0 = none of the dtypes is 16-bit, APE_DT_BF16 / APE_DT_F16, -1 = mixed or unknown
 static inline int ape_h16_kind(const int* dts, int n) {

@@ -336,10 +336,9 @@ extern "C" int ape_hip_ffn_fused(const void* X, int ldx, const void* W1, int ldw
   const int rt = rt_env != nullptr ? atoi(rt_env) : (ceil_div(M, 192) >= 256 ? 3 : 2);
 #define FF_LAUNCH(W2P_, RT_, H_)                                                                                              \
   do {                                                                                                                        \
-    static bool attr__ = false;                                                                                               \
-    if (!attr__) {                                                                                                            \
+    static ApeOncePerDevice attr__;                                                                                               \
+    if (attr__.first()) {                                                                                                            \
       (void)hipFuncSetAttribute((const void*)ffn_fused_kernel<W2P_, RT_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr__ = true;                                                                                                          \
     }                                                                                                                         \
     APE_LAUNCH((ffn_fused_kernel<W2P_, RT_, H_>), dim3(ceil_div(M, 64 * RT_)), dim3(256), lds, (hipStream_t)stream, p); \
   } while (0)

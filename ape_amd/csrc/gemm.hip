@@ -1119,15 +1119,14 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
   constexpr bool HF = h16<H>::dt == APE_DT_F16;
   APE_CHECK_ARG(HF || v2_ok || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output needs 16-byte aligned output rows");
   if (v2_ok) {
-    static bool attr_done = false;
-    if (!attr_done) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
+    static ApeOncePerDevice attr_done;
+    if (attr_done.first()) {  // > 64 KiB of dynamic LDS needs the opt-in attribute
       (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_v2_kernel<false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<true, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_ring_kernel<false, 4, 4, H>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_V2_LDS);
-      attr_done = true;
     }
     if (p.ln_w != nullptr) {
       // LayerNorm in the epilogue: the K = N = 256 register-resident kernel only (the callers check the same conditions and
@@ -1137,8 +1136,8 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
                         p.ldc % 8 == 0 && ((uintptr_t)p.C) % 16 == 0 && p.K % GB_K == 0 && ((uintptr_t)p.ln_w) % 16 == 0 && ((uintptr_t)p.ln_b) % 16 == 0 &&
                         (p.residual == nullptr || (p.res_dt == h16<H>::dt && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0)),
                     "ape_hip_gemm: an epilogue LayerNorm (ln_w) needs K == N == 256, M >= 2048, 16-bit operands / residual / output of one type, a plain epilogue");
-      static bool lattr = false;
-      if (!lattr) { (void)hipFuncSetAttribute((const void*)gemm_kres_ln_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS); lattr = true; }
+      static ApeOncePerDevice lattr;
+      if (lattr.first()) { (void)hipFuncSetAttribute((const void*)gemm_kres_ln_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS); }
       LAUNCH_GEMM("gemm_kres_ln_kernel", (gemm_kres_ln_kernel<H>), dim3(ceil_div(p.M, KR_BM)), KR_LDS);
       return 0;
     }
@@ -1149,14 +1148,13 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
                       (p.residual == nullptr || (p.res_dt == h16<H>::dt && p.ldr % 8 == 0 && ((uintptr_t)p.residual) % 16 == 0));
     APE_CHECK_ARG(HF || kres || p.out_dt != APE_DT_F16, "ape_hip_gemm: f16 output is only produced by the K == 256 kernel (disabled by the environment?)");
     if (kres) {
-      static bool kattr = false;
-      if (!kattr) {
+      static ApeOncePerDevice kattr;
+      if (kattr.first()) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, false, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<1, true, false, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kres_kernel<0, false, true, H>, hipFuncAttributeMaxDynamicSharedMemorySize, KR_LDS);
-        kattr = true;
       }
       const int mblk = ceil_div(p.M, KR_BM);
       const int nch = ceil_div(p.N, KR_CH);
@@ -1168,7 +1166,7 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
       p.reserved0 = 0;
       {
         const char* te = getenv("APE_KRES_TAILSPLIT");
-        constexpr int slots = 512;                                  // 2 workgroups per CU x 256 CUs
+        const int slots = 2 * ape_cu_count();                       // 2 workgroups per CU (512 on the 256 CUs of an MI355X)
         const int nfull = (mblk / slots) * slots, tail = mblk - nfull;
         // from 8 column chunks on (measured, profiles/r05_kres_probe.log: 1536 columns 120 -> 109 us, 2048: 154 -> 142; with 2 - 4 chunks the
         // extra copies of the A rows cost more than the shorter last round gains: 480 columns 52.7 -> 56.1 us, 256: 31.8 -> 32.9)
@@ -1221,6 +1219,9 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
 extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(a != nullptr, "ape_hip_gemm: null args");
   ApeGemmArgs p = *a;
+  // internal hint field of the library's OWN copy (bit 30: p8 residual prefetch off; bits 0-15 | 16-29: kres tail split `nfull | parts << 16`);
+  // whatever a caller left there is dropped here, once, for every kernel behind this entry
+  p.reserved0 = 0;
   APE_CHECK_ARG(p.A && p.W && p.C, "ape_hip_gemm: null pointer");
   APE_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "ape_hip_gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
   APE_CHECK_ARG(p.in_dt == APE_DT_F32 || ape_is16(p.in_dt), "ape_hip_gemm: bad in_dt %d", p.in_dt);

@@ -343,7 +343,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   f32x4_t rpre[RESPF ? 8 : 1][RESPF ? 2 : 1];
   bool respf = false;
   if (RESPF) {
-    respf = fast && p.residual != nullptr && p.res_dt == APE_DT_F32 && p.rope_cos == nullptr && p.act != APE_ACT_SWIGLU && !(p.reserved0 & (1 << 30));
+    // nk >= 2: with ONE K tile the main loop executes no counted wait at all (both `t + 2 < nk` and `t + 1 < nk` are false), so nothing
+    // would retire these loads in front of the epilogue's reads (K = 64 reaches this kernel through the C ABI only)
+    respf = fast && nk >= 2 && p.residual != nullptr && p.res_dt == APE_DT_F32 && p.rope_cos == nullptr && p.act != APE_ACT_SWIGLU && !(p.reserved0 & (1 << 30));
     if (respf) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -631,11 +633,7 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   // PERSISTENT grid: a launch with more tiles than CUs gets one workgroup per CU (rounded down to a multiple of 8: the tile order is
   // XCD-aware), each walking the tiles the plain launch would have sent to that CU one workgroup after another -- and staging tile
   // i + 1's first K tiles under tile i's epilogue (see the kernel's tile loop).  APE_P8_PERSIST=0 restores one workgroup per tile.
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-    return n & ~7;
-  }();
+  const int ncu = ape_cu_count();
   const char* pe = getenv("APE_P8_PERSIST");
   // ... for the launches the persistent flavour is compiled for: 256 x 256 tiles, staggered schedule, SwiGLU into a 16-bit output,
   // bias by column or none, nothing else in the epilogue (the kernel's PERSIST contract)
@@ -644,11 +642,10 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
                        p.alpha == 1.f && !(p.clamp > 0.f) && (p.bias == nullptr || ((uintptr_t)p.bias) % 16 == 0);
   constexpr int P8_BIAS_LDS = 8 * 1024;            // persistent launches: 1 KB per wave behind the two stages (the next tile's bias)
   if (persist) {
-    static bool pattr = false;
-    if (!pattr) {
+    static ApeOncePerDevice pattr;
+    if (pattr.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + P8_BIAS_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072 + P8_BIAS_LDS);
-      pattr = true;
     }
     if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<256, true, f16_t, 0, false, true>), dim3(ncu), dim3(512), 131072 + P8_BIAS_LDS, s, p);
     else APE_LAUNCH((gemm_bf16_p8_kernel<256, true, bf16_t, 0, false, true>), dim3(ncu), dim3(512), 131072 + P8_BIAS_LDS, s, p);
@@ -658,10 +655,9 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
   const int grid = tiles;
 #define P8_LAUNCH(BN_, ST_, H_, LDS_, NAME_)                                                                            \
   do {                                                                                                                  \
-    static bool attr__ = false;                                                                                         \
-    if (!attr__) {                                                                                                      \
+    static ApeOncePerDevice attr__;                                                                                         \
+    if (attr__.first()) {                                                                                                      \
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<BN_, ST_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_); \
-      attr__ = true;                                                                                                    \
     }                                                                                                                   \
     APE_LAUNCH((gemm_bf16_p8_kernel<BN_, ST_, H_>), dim3(grid), dim3(512), LDS_, s, p);                                  \
     name = NAME_;                                                                                                       \
@@ -685,13 +681,12 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     if ((bn != 256 && bn != 128) || p.K != 9 * 256 || p.lda < 256 || p.M != p.conv_h * p.conv_w || p.conv_zero == nullptr || ((uintptr_t)p.conv_zero) % 16 != 0)
       return nullptr;
     constexpr int CONV_LDS = 131072 + 9 * P8_BM * 4, CONV_LDS128 = 98304 + 9 * P8_BM * 4;
-    static bool cattr = false;
-    if (!cattr) {
+    static ApeOncePerDevice cattr;
+    if (cattr.first()) {
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, bf16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<256, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, bf16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS128);
       (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, f16_t, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS128);
-      cattr = true;
     }
     if (bn == 128) {
       if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<128, true, f16_t, 0, true>), dim3(tiles), dim3(512), CONV_LDS128, s, p);

@@ -31,13 +31,23 @@ hipEvent_t take_event() {
 }  // namespace
 
 // called by APE_LAUNCH (common.h): the event pair of the launch about to be issued, or nullptr when metering is off
-hipEvent_t* ape_meter_pair(const char* kernel) {
+hipEvent_t* ape_meter_pair(const char* kernel, hipStream_t stream) {
   if (!g_on) return nullptr;
+  // a stream under capture records no timestamps, and hipExtLaunchKernelGGL with events would fail or invalidate the capture: such a
+  // launch goes out plain and simply is not metered
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (cs != hipStreamCaptureStatusNone) return nullptr;
   Rec r;
   r.name = kernel;
+  const size_t used = g_pool_used;
   r.ev[0] = take_event();
   r.ev[1] = take_event();
-  if (r.ev[0] == nullptr || r.ev[1] == nullptr) return nullptr;
+  if (r.ev[0] == nullptr || r.ev[1] == nullptr) {
+    g_pool_used = used;             // roll back: the slot taken for the first event is not lost when the second cannot be created
+    (void)hipGetLastError();
+    return nullptr;
+  }
   g_recs.push_back(r);
   return g_recs.back().ev;          // valid until the next push_back: APE_LAUNCH uses it at once
 }

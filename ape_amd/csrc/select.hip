@@ -190,10 +190,9 @@ extern "C" int ape_hip_nms_scan_segments(const uint64_t* mask, int n, const int*
   const size_t sub_rows = (size_t)(ceil_div(max_segment, 64) + 1) * 64, sub_words = (size_t)ceil_div(max_segment, 64) + 1;
   const size_t lds = sub_rows * sub_words * 8;
   if (lds <= 160 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static ApeOncePerDevice attr_done;
+    if (attr_done.first()) {
       (void)hipFuncSetAttribute((const void*)nms_scan_segments_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_done = true;
     }
     APE_LAUNCH(nms_scan_segments_kernel<true>, dim3(num_segments), dim3(256), lds, (hipStream_t)stream,
                        (const unsigned long long*)mask, ceil_div(n, 64), n, seg_offsets, valid, keep);
@@ -211,10 +210,9 @@ extern "C" int ape_hip_nms_scan_classes(const uint64_t* mask, int n, const int* 
   const size_t lds = (size_t)n * nw * 8;
   APE_CHECK_ARG(mask && order && keep && n > 0 && num_classes > 0 && lds <= 160 * 1024,
                 "ape_hip_nms_scan_classes: bad args (the n x n/64 bit matrix must fit the 160 KiB LDS: n <= 1280)");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static ApeOncePerDevice attr_done;
+  if (attr_done.first()) {
     (void)hipFuncSetAttribute((const void*)nms_scan_classes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
   }
   APE_LAUNCH(nms_scan_classes_kernel, dim3(ceil_div(num_classes, 4)), dim3(256), lds, (hipStream_t)stream,
                      (const unsigned long long*)mask, nw, n, order, valid, keep, num_classes);

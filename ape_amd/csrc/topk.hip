@@ -638,12 +638,11 @@ static int topk_per(const int* seg_n, const int* seg_k, int nseg) {
 }
 
 static void set_stage2_attr() {
-  static bool done = false;
-  if (!done) {
+  static ApeOncePerDevice done;
+  if (done.first()) {
     (void)hipFuncSetAttribute((const void*)proposal_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     (void)hipFuncSetAttribute((const void*)det_topk2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
     (void)hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-    done = true;
   }
 }
 
@@ -700,10 +699,9 @@ extern "C" int ape_hip_proposal_order(const int32_t* cand, int n, const float* l
   if (fill_levels(lv, level_start, level_n, L)) return -1;
   APE_CHECK_ARG(cand && logit && xyxy && boxes_b && groups_b && seg && cand_a && lv_a && pos_b && n > 0 && n <= PO_PAD,
                 "ape_hip_proposal_order: 1 <= n <= 8192 candidates");
-  static bool attr_done = false;
-  if (!attr_done) {   // 64 KiB of dynamic LDS next to the kernel's static arrays needs the opt-in attribute
+  static ApeOncePerDevice attr_done;
+  if (attr_done.first()) {   // 64 KiB of dynamic LDS next to the kernel's static arrays needs the opt-in attribute
     (void)hipFuncSetAttribute((const void*)proposal_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PO_PAD * sizeof(u64));
-    attr_done = true;
   }
   APE_LAUNCH(proposal_order_kernel, dim3(1), dim3(TK_THREADS), (size_t)2 * ((n + 1023) / 1024) * 1024 * sizeof(u64), (hipStream_t)stream, cand, n, logit, xyxy, lv,
                      boxes_b, groups_b, seg, cand_a, lv_a, pos_b);

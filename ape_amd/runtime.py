@@ -117,12 +117,18 @@ class GraphedForward:
         self.panoptic = panoptic
         # pipelined steps: start the ViT branch behind the tails' encoders (see _run_entry); APE_PIPE_LATE_VIT=0|1 overrides
         self.late_vit = os.environ.get("APE_PIPE_LATE_VIT", "0") == "1"
+        # pipelined steps: the first step of a stream / the flush behind its last step run as ViT-only / tails-only graphs (see
+        # _build); APE_PIPE_PARTIAL=0 replays the full step there, as rounds 2-5 did
+        self.partial_graphs = os.environ.get("APE_PIPE_PARTIAL", "1") != "0"
         self._graphs = {}
         self._copy_stream = None
 
     def _retire(self, entry, strict=True):
         if getattr(entry, "graph", None) is None:
             return
+        for name in ("graph_vit", "graph_tails"):         # the partial graphs of a pipelined entry share its fate (and its byte count)
+            if getattr(entry, name, None) is not None:
+                _RETIRED.append((getattr(entry, name), 0))
         nbytes = int(getattr(entry, "pool_bytes", 0))
         n, held = retired_graphs()
         if strict and held + nbytes > RETIRE_LIMIT_BYTES:
@@ -193,15 +199,17 @@ class GraphedForward:
         return self._device_part(e.images[b], e.text, height, width, e.frame[b], e.prompt, vit_feat,
                                  e.sgeo[b] if self.any_size else None, encoder_done)
 
-    def _run_entry(self, e):
-        """the device work of one step of entry `e` on its static buffers: (ViT of the images) + B tails"""
+    def _run_entry(self, e, part="full"):
+        """the device work of one step of entry `e` on its static buffers: (ViT of the images) + B tails.  Pipelined mode, `part`:
+        "full" = ViT of the new images || tails of the previous step's; "vit" = the ViT branch only (the FIRST step of a stream: no
+        previous images whose tails could run); "tails" = the tails only (the FLUSH behind the last step: no new images)."""
         from . import ops
         mv = self.mv
         if e.prompt == "expression" and mv.test_topk_per_image != 1:      # (:183-194) forward() applies the same rule
             saved = mv.test_topk_per_image
             mv.test_topk_per_image = 1
             try:
-                return self._run_entry(e)
+                return self._run_entry(e, part)
             finally:
                 mv.test_topk_per_image = saved
         B = len(e.images)
@@ -212,6 +220,12 @@ class GraphedForward:
             # (nested fork/join inside image branches made hipStreamEndCapture crash on this ROCm).
             with ops.inline_forks():
                 feats = [e.feat[b * n_tok:(b + 1) * n_tok] for b in range(B)]
+                if part == "vit":
+                    e.feat.copy_(net.forward_tokens(e.images if B > 1 else e.images[0], mv._mean, mv._std))
+                    return None
+                if part == "tails":
+                    jobs = [ops.fork(lambda b=b: self._tail(e, b, feats[b]), force=True) for b in range(1, B)]
+                    return [self._tail(e, 0, feats[0])] + [j.join() for j in jobs]
                 if self.late_vit:
                     # ViT of the new images ordered BEHIND the encoders of the tails: the tails' GEMM-bound first half (FPN,
                     # encoder) then has the chip to itself, and the GEMM-bound ViT overlaps their latency-bound second half
@@ -347,9 +361,21 @@ class GraphedForward:
             e.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(e.graph):
                 e.outs = self._run_entry(e)
-            e.pool_bytes = max(0, torch.cuda.memory_reserved() - reserved)      # the capture's private pool (what eviction parks)
+            # pipelined: the two ends of a stream as their own graphs -- the first step has no previous images (ViT branch only), the
+            # flush behind the last step has no new ones (tails only).  Replaying the FULL step there ran one ViT pass and B tails
+            # nobody consumed per stream: K steps cost K + 1 full replays (5 % of a 20-step run).  Same launches, same static
+            # buffers, the part's own output tensors.
+            e.graph_vit = e.graph_tails = None
+            if self.pipeline and self.partial_graphs:
+                e.graph_vit = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(e.graph_vit):
+                    self._run_entry(e, "vit")
+                e.graph_tails = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(e.graph_tails):
+                    e.outs_tails = self._run_entry(e, "tails")
+            e.pool_bytes = max(0, torch.cuda.memory_reserved() - reserved)      # the captures' private pools (what eviction parks)
         else:
-            e.graph = None
+            e.graph = e.graph_vit = e.graph_tails = None
         if bank is not None:
             mv.features_phrase_bank.copy_(bank)
         k = 1 if prompt == "expression" else mv.test_topk_per_image       # (:183-194) one box per referring expression
@@ -461,11 +487,17 @@ class GraphedForward:
                     raise ValueError(f"GraphedForward(any_size): image {h}x{w} does not fit the {S}x{S} pad")
                 e.images[b].copy_(e.mean_canvas, non_blocking=True)
                 self._write_input(e.images[b][:, :h, :w], im)
+        part = "full"
+        if self.pipeline and self.partial_graphs:
+            part = "tails" if images is None else ("vit" if completes is None else "full")
         if e.graph is not None:
-            e.graph.replay()
-            outs = e.outs
+            g = {"full": e.graph, "vit": e.graph_vit, "tails": e.graph_tails}[part]
+            if g is None:
+                g, part = e.graph, "full"
+            g.replay()
+            outs = e.outs_tails if part == "tails" else e.outs
         else:
-            outs = self._run_entry(e)
+            outs = self._run_entry(e, part)
         if completes is not None:
             cur.wait_event(s.copied)                      # the slot's previous transfer has left the staging buffers
             has_masks = s.d_masks is not None and outs[0][1] is not None
@@ -526,8 +558,7 @@ class GraphedForward:
             e.frame.copy_(torch.tensor(vals, dtype=torch.float32))          # pageable source: staged before the call returns
 
     def flush(self, entry=None):
-        """pipelined mode: run the tails of the ticket whose ViT features are waiting (one more replay; its ViT branch recomputes
-        the features of the images already in the static buffers, which nobody consumes)"""
+        """pipelined mode: run the tails of the ticket whose ViT features are waiting (one replay of the tails-only graph)"""
         for e in ([entry] if entry is not None else list(self._graphs.values())):
             if self.pipeline and e.pending is not None:
                 t, e.pending = e.pending(), None

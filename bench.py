@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--no-second-flavour", action="store_true",
                     help="skip the second timed region of the default bf16 run: the SAME step in IEEE half (--dtype f16's pipeline, the "
                          "reference's own evaluation dtype), --f16-steps steps, reported as value_f16 / ms_per_step_f16 (N = 1 only)")
-    ap.add_argument("--f16-steps", type=int, default=20)
+    ap.add_argument("--f16-steps", type=int, default=0, help="0 = the same number of steps (and the same warm-up) as the bf16 region")
     ap.add_argument("--dry-images", type=int, default=1000, help="--dry: length of the sharded synthetic stream")
     ap.add_argument("--instrumented-only", action="store_true",
                     help="skip the timed region: run only the instrumented pass that produces `roofline` (what tools/gpu_profile.sh puts "
@@ -603,11 +603,12 @@ def main():
     # copy stream meanwhile); 2 with the software pipeline, where a ticket's detections are produced by the next step's replay
     depth = 1 if args.no_pipeline else 2
 
-    def timed_region(runner, warmup, steps, collective=True):
+    def timed_region(runner, warmup, steps, collective=True, trace=None):
         """`warmup` untimed steps, then EXACTLY `steps` steps (the last one flushed inside the region) between barrier +
         synchronize on both sides; returns this rank's seconds.  runner: the DataParallelRunner (records / runs exchanged), or the
         GraphedForward itself (the same step with no exchange: the same-process N = 1 reference of an N-rank run)."""
         queue = []
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(warmup + steps + 2)] if trace is not None else None
 
         def step(i):
             if raw_images is not None:
@@ -626,24 +627,41 @@ def main():
             if hasattr(runner, "drain"):
                 runner.drain()
 
+        # `trace` (a dict): stream-side milliseconds of every step, warm-up included -- an event recorded on the compute stream behind each
+        # submit (no host wait: the region is timed exactly as without it); what the driver's short command pays per step, in order
+        if marks is not None:
+            marks[0].record()
         for i in range(warmup):
             step(i)
+            if marks is not None:
+                marks[1 + i].record()
         flush()
         torch.cuda.synchronize()
         if dist is not None and collective:
             dist.barrier()
         t0 = time.perf_counter()
+        if marks is not None:
+            marks[warmup + 1].record()
         for i in range(steps):
             step(warmup + i)
+            if marks is not None:
+                marks[warmup + 2 + i].record()
         flush()
         torch.cuda.synchronize()
         if dist is not None and collective:
             dist.barrier()
-        return max(time.perf_counter() - t0, 1e-9)
+        sec = max(time.perf_counter() - t0, 1e-9)
+        if marks is not None:
+            trace["warmup_ms"] = [round(marks[i].elapsed_time(marks[i + 1]), 3) for i in range(warmup)]
+            trace["timed_ms"] = [round(marks[warmup + 1 + i].elapsed_time(marks[warmup + 2 + i]), 3) for i in range(steps)]
+            trace["note"] = ("stream-side ms between the events recorded behind consecutive submits (the first timed entry includes the ViT-only "
+                             "first step, the flush of the last step's tails comes after the last entry): sum(timed_ms) + flush = the timed region")
+        return sec
 
     if args.instrumented_only:
         args.warmup = args.steps = 0
-    elapsed_rank = elapsed = timed_region(dp, args.warmup, args.steps)
+    step_trace = {} if (args.steps and args.steps + args.warmup <= 400) else None
+    elapsed_rank = elapsed = timed_region(dp, args.warmup, args.steps, trace=step_trace)
     per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -675,8 +693,14 @@ def main():
         g16 = GraphedForward(mv, use_graph=not args.no_graph, images_per_step=B, batch_vit=not args.no_batch_vit,
                              pipeline=not args.no_pipeline, any_size=args.stream == "coco", semantic=sem_meta, mask_format=mask_format,
                              input_resize=(S, S), input_format="RGB")
-        sec = timed_region(g16, 3, args.f16_steps, collective=False)
-        f16 = {"value_f16": args.f16_steps * B / sec, "ms_per_step_f16": 1e3 * sec / args.f16_steps, "steps_f16": args.f16_steps}
+        # the SAME protocol as the bf16 region (round 5 timed 20 steps behind 3 warm-up steps next to 100 behind 10: with one extra
+        # replay per region for the flush, that alone read 4 % low): same warm-up, same number of steps, its own step trace
+        n16 = args.f16_steps or args.steps
+        trace16 = {} if step_trace is not None else None
+        sec = timed_region(g16, args.warmup, n16, collective=False, trace=trace16)
+        f16 = {"value_f16": n16 * B / sec, "ms_per_step_f16": 1e3 * sec / n16, "steps_f16": n16, "warmup_f16": args.warmup}
+        if trace16:
+            f16["step_trace_f16"] = trace16
         del g16
         mv.set_compute_dtype(DTYPES[args.dtype])
 
@@ -772,6 +796,8 @@ def main():
             result["efficiency_vs_n1"] = result["value"] / (world * n1["value"])
         if f16 is not None:
             result.update(f16)
+        if step_trace:
+            result["step_trace"] = step_trace
         if world == 1 and not args.no_cpu_baseline:
             try:
                 timed = [im.contiguous() for im in images[:max(1, args.cpu_images)]]

@@ -958,7 +958,9 @@ def test_gemm_p8_residual_prefetch(ops, monkeypatch, bf):
     launches (a register read before its load has landed would differ from run to run)"""
     if SELF:
         pytest.skip("kernel-internal data path: HIP library only")
-    for (M, N, K) in [(8192, 1024, 1024), (8192, 1024, 2752 // 64 * 64), (4096 + 100, 1024, 512), (8192, 896 + 64, 256), (300, 384, 64)]:
+    # (1024, 256, 64), (2048, 1024, 64): ONE K tile on full tiles -- the main loop then has no counted wait that could retire the prefetch
+    # (ADVICE round 5: the launcher must not prefetch there)
+    for (M, N, K) in [(8192, 1024, 1024), (8192, 1024, 2752 // 64 * 64), (4096 + 100, 1024, 512), (8192, 896 + 64, 256), (300, 384, 64), (1024, 256, 64), (2048, 1024, 64)]:
         a, w = rnd(M, K, dtype=bf, seed=41), rnd(N, K, dtype=bf, scale=K ** -0.5, seed=42)
         bias, res = rnd(N, seed=43), rnd(M, N, seed=44)
         rs, sh, cv = rnd(M, seed=45).abs() + 0.5, rnd(M, seed=46), rnd(N, seed=47)
@@ -972,6 +974,25 @@ def test_gemm_p8_residual_prefetch(ops, monkeypatch, bf):
         e = relerr(ops.gemm(a, w, bias, residual=res, tile64=4, out_dtype=torch.float32), ref_ops.gemm(a, w, bias, residual=res, out_dtype=torch.float32))
         print(f"gemm p8<128> residual prefetch M{M} N{N} K{K}: identical; vs the definition {e:.3e}")
         assert e < 3e-4
+
+
+def test_gemm_half_outputs_saturate(ops):
+    """every IEEE-half store of the GEMM kernels SATURATES at +-65504 instead of producing inf: the deformable attention's value projection
+    relies on it (layers/multi_scale_deform_attn.py: no clamp= on the half value / offset projections since round 5; the reference's fp16
+    evaluation overflows to inf there, multi_scale_deform_attn.py:262-264).  Pinned per kernel path: the K = 256 register-resident kernel
+    (bf16 operands -> half output, and half operands), its LayerNorm-free residual flavour, and the 256 x 128 / 256 x 256 tile kernels"""
+    if SELF:
+        pytest.skip("kernel store path: HIP library only")
+    big = 300.0
+    for dt_in, (M, N, K), tile in [(torch.bfloat16, (4096, 256, 256), None), (torch.float16, (4096, 256, 256), None), (torch.float16, (4096, 512, 256), None),
+                                   (torch.float16, (2048, 1024, 512), 4), (torch.float16, (2048, 1024, 512), 3)]:
+        a = torch.full((M, K), big, device=DEV).to(dt_in)
+        sign = torch.where(torch.arange(N, device=DEV) % 2 == 0, 1.0, -1.0)
+        w = (sign[:, None] * torch.ones((N, K), device=DEV)).to(dt_in)          # every output = +-300 * K = +-76 800 (K = 256) > 65504
+        got = ops.gemm(a, w, None, out_dtype=torch.float16, **({"tile64": tile} if tile is not None else {}))
+        assert got.dtype == torch.float16 and bool(torch.isfinite(got).all()), (dt_in, M, N, K, tile)
+        assert torch.equal(got.float(), (sign * 65504.0).expand(M, N)), (dt_in, M, N, K, tile)
+    print("half outputs saturate at +-65504 on the kres and p8 paths")
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16])

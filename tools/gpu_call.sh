@@ -13,6 +13,9 @@
 #   benches        the other configurations / flavours (no CPU baseline)
 #   profile        tools/gpu_profile.sh (rocprofv3 kernel stats: instrumented pass alone + pipelined graph run)
 #   pmc            tools/gpu_pmc.sh (separate FETCH_SIZE / WRITE_SIZE / SQ passes) + summary
+#   env            environment variables of the box that steer the HIP / HSA runtimes, clocks
+#   d2h            tools/gpu_d2h_probe.py per environment variant under rocprofv3 (is the mask transfer a blit kernel or SDMA?)
+#   drivercmd      the driver's exact command (--gpus 1 --steps 20 --warmup 5) with the per-step trace printed
 #   py:<script>    python tools/<script> (a probe), output -> <script>.log
 TAG=$1; shift
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -61,6 +64,30 @@ PY
       b V_A_1536 --size V_A_1536 --steps 10 --warmup 2 --no-second-flavour; b G_A --size G_A --steps 10 --warmup 2 --no-second-flavour ;;
     profile) ./tools/gpu_profile.sh $TAG ${APE_BENCH_ARGS} 2>&1 | tail -3 | cut -c1-160; mv gpurun_out/${TAG}_* $O/ 2>/dev/null; rm -f $O/*kernel_trace.csv.gz ;;
     pmc) ./tools/gpu_pmc.sh $TAG ${APE_PMC_GROUPS:-2} 2>&1 | tail -14 | cut -c1-220; cp gpurun_out/pmc_$TAG/summary.txt $O/pmc_summary.txt 2>/dev/null ;;
+    env) env | grep -E "^(HSA|HIP|ROC|GPU|AMD|NCCL|RCCL|PYTORCH)" | sort | tee $O/env.txt; rocm-smi --showclocks --showpower 2>/dev/null | head -30 | tee -a $O/env.txt ;;
+    d2h)   # the mask transfer: blit kernel or SDMA?  one probe run per environment variant, each under rocprofv3 --kernel-trace --stats
+      i=0
+      for v in "X=0" "HSA_ENABLE_SDMA=1" "GPU_FORCE_BLIT_COPY_SIZE=0" "HSA_ENABLE_SDMA=0" "HSA_ENABLE_SDMA_COPY_SIZE_OVERRIDE=0"; do
+        i=$((i + 1))
+        (cd /tmp && rm -rf /tmp/prof_d$i && env $v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d$i -o p -- python $GRAFT_REPO_ROOT/tools/gpu_d2h_probe.py > $GRAFT_REPO_ROOT/$O/d2h_$i.log 2>&1)
+        echo "--- variant $v" | tee -a $O/d2h_summary.txt
+        grep -E "^env|copy alone" $O/d2h_$i.log | tee -a $O/d2h_summary.txt
+        f=$(find /tmp/prof_d$i -name "*kernel_stats.csv" | head -1)
+        (grep -i -E "copyBuffer|blit|fill" "$f" | cut -d, -f1-4 || echo "no copy kernel in the trace") | tee -a $O/d2h_summary.txt
+      done ;;
+    drivercmd)   # EXACTLY the driver's command, ${APE_REPEAT:-2} times back to back on this box, with the per-step trace on the line
+      for r in $(seq 1 ${APE_REPEAT:-2}); do
+        timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 ${APE_BENCH_ARGS} 2> $O/drivercmd_$r.err | tail -1 > $O/drivercmd_$r.json
+        python - <<PY | tee -a $O/drivercmd_trace.txt
+import json
+d = json.loads(open("$O/drivercmd_$r.json").read())
+print("run $r: value", round(d["value"], 2), "ms/step", round(d["ms_per_step"], 3), "f16", round(d.get("value_f16") or 0, 2), "frac", round(d["roofline"]["frac"], 4), "avg_us", round(d["roofline"]["avg_launch_us"], 2))
+t = d.get("step_trace") or {}
+print("  warmup_ms", t.get("warmup_ms")); print("  timed_ms ", t.get("timed_ms"))
+t = d.get("step_trace_f16") or {}
+print("  f16 warmup_ms", t.get("warmup_ms")); print("  f16 timed_ms ", t.get("timed_ms"))
+PY
+      done ;;
     py:*) s=${recipe#py:}; timeout 900 python tools/$s ${APE_PY_ARGS} > $O/${s%.py}.log 2>&1; tail -40 $O/${s%.py}.log | cut -c1-220 ;;
     *) echo "unknown recipe $recipe" ;;
   esac

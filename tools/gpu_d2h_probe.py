@@ -1,0 +1,65 @@
+"""How does the 105 MB mask transfer (device -> pinned host) travel: as a shader blit (__amd_rocclr_copyBuffer occupies CUs) or on an SDMA
+engine?    Runs the copy through torch's copy_ and through hipMemcpyAsync / hipMemcpyDtoHAsync directly, alone
+and next to a CU-saturating GEMM loop; run it under `rocprofv3 --kernel-trace --stats` per environment variant (tools/gpu_call.sh d2h)
+to see whether a copy kernel shows up.  Prints one line per variant."""
+import ctypes
+import os
+import time
+
+import torch
+
+hip = ctypes.CDLL("libamdhip64.so")
+N = 100 * 1024 * 1024
+x = torch.zeros(N, dtype=torch.uint8, device="cuda")
+h = torch.empty(N, dtype=torch.uint8, pin_memory=True)
+y = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+cs = torch.cuda.Stream()
+torch.cuda.synchronize()
+
+
+def copy_torch():
+    with torch.cuda.stream(cs):
+        h.copy_(x, non_blocking=True)
+
+
+def copy_hip():
+    rc = hip.hipMemcpyAsync(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_size_t(N), ctypes.c_int(2), ctypes.c_void_p(cs.cuda_stream))
+    assert rc == 0, rc
+
+
+def copy_dtoh():
+    rc = hip.hipMemcpyDtoHAsync(ctypes.c_void_p(h.data_ptr()), ctypes.c_void_p(x.data_ptr()), ctypes.c_size_t(N), ctypes.c_void_p(cs.cuda_stream))
+    assert rc == 0, rc
+
+
+def t_copy(fn, n=5):
+    fn(); cs.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    cs.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / n
+
+
+def t_mm(n=40, fn=None):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if fn is not None:
+        fn()
+    for _ in range(n):
+        (y @ y)
+    torch.cuda.current_stream().synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    torch.cuda.synchronize()
+    return dt
+
+
+envs = {k: os.environ.get(k) for k in ("HSA_ENABLE_SDMA", "GPU_FORCE_BLIT_COPY_SIZE", "HSA_FORCE_SDMA_SIZE", "HSA_ENABLE_SDMA_COPY_SIZE_OVERRIDE")}
+print("env", envs)
+t_mm(5)
+base = min(t_mm() for _ in range(3))
+for name, fn in (("torch.copy_", copy_torch), ("hipMemcpyAsync", copy_hip), ("hipMemcpyDtoHAsync", copy_dtoh)):
+    alone = t_copy(fn)
+    both = min(t_mm(fn=lambda: [fn(), fn(), fn()]) for _ in range(3))
+    print(f"{name:20s} copy alone {alone:6.2f} ms ({N / alone / 1e6:5.1f} GB/s)   40 GEMMs alone {base:7.2f} ms, with 3 copies in flight {both:7.2f} ms "
+          f"(+{100 * (both / base - 1):.1f} %)")
