@@ -65,6 +65,8 @@ SIGNATURES = {
     "ape_hip_meter_end": (c_int, []),
     "ape_hip_meter_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_float)]),
     "ape_hip_zero": (c_int, [c_void_p, ctypes.c_size_t, c_void_p]),
+    "ape_hip_sdma_usable": (c_int, [c_void_p, c_void_p]),
+    "ape_hip_sdma_d2h": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),

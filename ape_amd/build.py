@@ -89,7 +89,7 @@ def build(force=False, verbose=True):
             fh.write(odig)
     if failed:
         raise RuntimeError(f"hipcc failed on {failed}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lhsa-runtime64"]
     if verbose:
         print("[ape_amd.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,66 @@
+// Device -> pinned-host transfer on an SDMA engine (round 6).
+// On this stack (ROCm 7.2, MI355X) hipMemcpyAsync of a device buffer into hipHostMalloc'ed memory runs as a SHADER BLIT
+// (`__amd_rocclr_copyBuffer`, profiles/r06_d2h_blit_vs_sdma_probe.txt: every environment switch of the HIP / HSA runtimes tried leaves it a
+// kernel): 105 MB of instance masks per image = a 1.9 ms kernel at PCIe rate whose few workgroups sit on CUs the whole time.  A GEMM launch with
+// one 512-thread workgroup per CU (all of the tile kernels' launches) cannot place the workgroups of the occupied CUs until another CU
+// drains -- a second round: measured +18 % on a GEMM loop with copies in flight, i.e. the copy's whole duration is ADDED to the GEMMs'.
+// The HSA runtime underneath does own DMA engines; this entry asks it directly: hsa_amd_memory_async_copy between the agents that own the
+// two allocations.  Blocking (returns when the bytes are in host memory) and NOT stream-ordered: the caller makes sure the source is
+// complete (event / stream synchronize) and calls from a helper thread (ctypes releases the GIL); ape_amd/runtime.py does exactly that.
+#include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <cstdint>
+
+void ape_set_error(const char* fmt, ...);
+
+namespace {
+bool owner_of(const void* p, hsa_agent_t* agent, bool* is_host) {
+  hsa_amd_pointer_info_t info{};
+  info.size = sizeof(info);
+  if (hsa_amd_pointer_info(p, &info, nullptr, nullptr, nullptr) != HSA_STATUS_SUCCESS) return false;
+  if (info.type != HSA_EXT_POINTER_TYPE_HSA && info.type != HSA_EXT_POINTER_TYPE_LOCKED) return false;
+  hsa_device_type_t t = HSA_DEVICE_TYPE_CPU;
+  if (hsa_agent_get_info(info.agentOwner, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return false;
+  *agent = info.agentOwner;
+  *is_host = t == HSA_DEVICE_TYPE_CPU;
+  return true;
+}
+thread_local hsa_signal_t g_sig = {0};
+}  // namespace
+
+// 1 when both pointers belong to allocations the HSA runtime knows (device memory / pinned host memory) -- the precondition of the copy
+extern "C" int ape_hip_sdma_usable(const void* host_dst, const void* dev_src) {
+  hsa_agent_t a{}, b{};
+  bool ha = false, hb = false;
+  return (owner_of(host_dst, &a, &ha) && owner_of(dev_src, &b, &hb) && ha && !hb) ? 1 : 0;
+}
+
+// copy nbytes from device memory to pinned host memory on a DMA engine; returns when the bytes have landed (0 = ok)
+extern "C" int ape_hip_sdma_d2h(void* host_dst, const void* dev_src, size_t nbytes) {
+  if (nbytes == 0) return 0;
+  hsa_agent_t dst_agent{}, src_agent{};
+  bool dst_host = false, src_host = false;
+  if (!owner_of(host_dst, &dst_agent, &dst_host) || !owner_of(dev_src, &src_agent, &src_host) || !dst_host || src_host) {
+    ape_set_error("ape_hip_sdma_d2h: destination must be pinned host memory (hipHostMalloc) and source device memory of this process");
+    return -1;
+  }
+  if (g_sig.handle == 0 && hsa_signal_create(1, 0, nullptr, &g_sig) != HSA_STATUS_SUCCESS) {
+    g_sig.handle = 0;
+    ape_set_error("ape_hip_sdma_d2h: hsa_signal_create failed");
+    return -2;
+  }
+  hsa_signal_store_relaxed(g_sig, 1);
+  const hsa_status_t rc = hsa_amd_memory_async_copy(host_dst, dst_agent, dev_src, src_agent, nbytes, 0, nullptr, g_sig);
+  if (rc != HSA_STATUS_SUCCESS) {
+    ape_set_error("ape_hip_sdma_d2h: hsa_amd_memory_async_copy failed (status 0x%x)", (unsigned)rc);
+    return -2;
+  }
+  const hsa_signal_value_t v = hsa_signal_wait_scacquire(g_sig, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED);
+  if (v < 0) {
+    ape_set_error("ape_hip_sdma_d2h: the copy engine reported an error (signal %lld)", (long long)v);
+    return -2;
+  }
+  return 0;
+}

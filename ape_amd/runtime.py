@@ -32,6 +32,8 @@ vector.  One graph then serves every size -- including different sizes inside on
 per-size path (tests/test_model_gpu.py::test_any_size_runtime).
 """
 import os
+import queue
+import threading
 import weakref
 from types import SimpleNamespace
 
@@ -55,6 +57,49 @@ RETIRE_LIMIT_BYTES = int(float(os.environ.get("APE_GRAPH_RETIRE_LIMIT_GB", "64")
 def retired_graphs():
     """(number of parked graphs, bytes of HBM their private pools hold) -- process wide"""
     return len(_RETIRED), sum(b for _, b in _RETIRED)
+
+
+class _DmaTransfer:
+    """Helper thread that moves finished result slots to pinned host memory on a DMA ENGINE (csrc/hostcopy.cpp ape_hip_sdma_d2h).
+
+    hipMemcpyAsync (what `tensor.copy_(..., non_blocking=True)` issues) runs a device -> pinned-host copy as a shader blit on this stack:
+    a PCIe-bound kernel of ~1.9 ms per 105 MB image that keeps a few CUs occupied, so every GEMM launch with one workgroup per CU
+    pays a second round while it runs (profiles/r06_d2h_blit_vs_sdma_probe.txt: +16-18 % on a GEMM loop with copies in flight, +0.2-1.1 %
+    with the same bytes on the DMA engine).  The HSA copy is not stream-ordered, so this thread waits for the slot's `computed` event on
+    the host, issues the blocking copies (ctypes releases the GIL), and sets `done`; `GraphedForward.result()` waits for it."""
+
+    def __init__(self, device):
+        self.device = device
+        self.q = queue.SimpleQueue()
+        self.thread = threading.Thread(target=self._run, name="ape-dma-transfer", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        from . import _lib
+        lib = _lib.load()
+        torch.cuda.set_device(self.device)
+        while True:
+            job = self.q.get()
+            if job is None:
+                return
+            ev, copies, done, err = job
+            try:
+                ev.synchronize()                              # the paste kernels of this slot have finished (host-side wait)
+                for dst, src, n in copies:
+                    if lib.ape_hip_sdma_d2h(dst, src, n) != 0:
+                        raise RuntimeError("ape_amd.runtime: " + (lib.ape_hip_last_error() or b"ape_hip_sdma_d2h failed").decode())
+            except BaseException as exc:                      # surfaced by result()
+                err.append(exc)
+            finally:
+                done.set()
+
+    def submit(self, event, copies):
+        done, err = threading.Event(), []
+        self.q.put((event, copies, done, err))
+        return done, err
+
+    def close(self):
+        self.q.put(None)
 
 
 class _Ticket:
@@ -122,6 +167,12 @@ class GraphedForward:
         self.partial_graphs = os.environ.get("APE_PIPE_PARTIAL", "1") != "0"
         self._graphs = {}
         self._copy_stream = None
+        # mask transfer: "sdma" = the library's DMA-engine copy on a helper thread (default), "blit" = hipMemcpyAsync on the copy stream
+        # (a shader blit on this stack; rounds 1-5) -- APE_D2H=blit|sdma
+        self.d2h = os.environ.get("APE_D2H", "sdma")
+        if self.d2h not in ("sdma", "blit"):
+            raise ValueError("APE_D2H is 'sdma' or 'blit'")
+        self._dma = None
 
     def _retire(self, entry, strict=True):
         if getattr(entry, "graph", None) is None:
@@ -147,6 +198,8 @@ class GraphedForward:
 
     def __del__(self):
         try:
+            if self._dma is not None:
+                self._dma.close()
             for e in self._graphs.values():
                 self._retire(e, strict=False)     # a destructor parks unconditionally
         except Exception:       # interpreter shutdown
@@ -533,11 +586,20 @@ class GraphedForward:
                 if has_masks and s.d_runs is not None:
                     s.h_runs.copy_(s.d_runs, non_blocking=True)
                     s.h_nruns.copy_(s.d_nruns, non_blocking=True)
-                if has_masks and s.h_masks is not None:
+                if has_masks and s.h_masks is not None and self.d2h == "blit":
                     for b in range(len(outs)):
                         fh, fw = completes.frames[b]
                         s.h_masks[b, : k * fh * fw].copy_(s.d_masks[b, : k * fh * fw], non_blocking=True)
                 s.copied.record(self._copy_stream)
+            s.masks_done = s.masks_err = None
+            if has_masks and s.h_masks is not None and self.d2h == "sdma":
+                # the [k, H, W] masks (105 MB per 1024^2 image) leave on a DMA engine: the helper thread waits for `computed` on the host.
+                # The slot is not reused before result() has waited for this transfer (s.busy), so no stream-side ordering is needed.
+                if self._dma is None:
+                    self._dma = _DmaTransfer(s.d_masks.device)
+                copies = [(s.h_masks[b].data_ptr(), s.d_masks[b].data_ptr(), k * completes.frames[b][0] * completes.frames[b][1])
+                          for b in range(len(outs))]
+                s.masks_done, s.masks_err = self._dma.submit(s.computed, copies)
             s.busy = True
             s.has_masks = has_masks
             completes.slot, completes.ready = s, True
@@ -573,6 +635,10 @@ class GraphedForward:
             self.flush(e)
         s = ticket.slot
         s.copied.synchronize()
+        if s.masks_done is not None:                        # the DMA-engine transfer of the masks (helper thread)
+            s.masks_done.wait()
+            if s.masks_err:
+                raise s.masks_err[0]
         s.busy = False
         insts = []
         k = e.k

@@ -126,6 +126,14 @@ int ape_hip_meter_read(int i, const char** name, float* ms);
 /* zero-fill of a device buffer on a stream (hipMemsetAsync; captured as a memset node): the padded V^T operand buffers of the forward --
  * replaces the tensor library's fill kernel on the path (torch.zeros in rounds 1-4) -- csrc/meter.cpp */
 int ape_hip_zero(void* ptr, size_t nbytes, void* stream);
+/* Result transfer on a DMA ENGINE (round 6; csrc/hostcopy.cpp).  `DefaultPredictor` / `inference_on_dataset` hand `Instances` to the host
+ * (ape/modeling/ape_deta/deformable_detr_segm_vl.py:599-613: `.to("cpu")` of [k, H, W] masks = 105 MB per 1024^2 image).  hipMemcpyAsync runs
+ * that copy as a shader blit which holds CUs for its whole PCIe-bound duration; this entry hands it to the HSA runtime's copy engines
+ * instead (hsa_amd_memory_async_copy between the agents owning the two allocations).  BLOCKING and NOT stream-ordered: call it from a
+ * helper thread once the source is complete.  host_dst: pinned host memory (hipHostMalloc); dev_src: device memory.
+ * ape_hip_sdma_usable: 1 when the pointer pair qualifies. */
+int ape_hip_sdma_usable(const void* host_dst, const void* dev_src);
+int ape_hip_sdma_d2h(void* host_dst, const void* dev_src, size_t nbytes);
 
 /* per-row LayerNorm statistics of x [M, C] (row stride ldx): rowscale[m] = rsqrt(var_m + eps), rowshift[m] = -mean_m * rowscale[m]
  * (biased variance, two passes) -- the row terms of the folded LayerNorm above.  -- csrc/norm.hip */

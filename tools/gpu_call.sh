@@ -67,11 +67,11 @@ PY
     env) env | grep -E "^(HSA|HIP|ROC|GPU|AMD|NCCL|RCCL|PYTORCH)" | sort | tee $O/env.txt; rocm-smi --showclocks --showpower 2>/dev/null | head -30 | tee -a $O/env.txt ;;
     d2h)   # the mask transfer: blit kernel or SDMA?  one probe run per environment variant, each under rocprofv3 --kernel-trace --stats
       i=0
-      for v in "X=0" "HSA_ENABLE_SDMA=1" "GPU_FORCE_BLIT_COPY_SIZE=0" "HSA_ENABLE_SDMA=0" "HSA_ENABLE_SDMA_COPY_SIZE_OVERRIDE=0"; do
+      for v in ${APE_D2H_VARIANTS:-X=0 HSA_ENABLE_SDMA=1 GPU_FORCE_BLIT_COPY_SIZE=0 HSA_ENABLE_SDMA=0 HSA_ENABLE_SDMA_COPY_SIZE_OVERRIDE=0}; do
         i=$((i + 1))
         (cd /tmp && rm -rf /tmp/prof_d$i && env $v timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_d$i -o p -- python $GRAFT_REPO_ROOT/tools/gpu_d2h_probe.py > $GRAFT_REPO_ROOT/$O/d2h_$i.log 2>&1)
         echo "--- variant $v" | tee -a $O/d2h_summary.txt
-        grep -E "^env|copy alone" $O/d2h_$i.log | tee -a $O/d2h_summary.txt
+        grep -E "^env|copy alone|sdma copy correct|Error|error" $O/d2h_$i.log | tee -a $O/d2h_summary.txt
         f=$(find /tmp/prof_d$i -name "*kernel_stats.csv" | head -1)
         (grep -i -E "copyBuffer|blit|fill" "$f" | cut -d, -f1-4 || echo "no copy kernel in the trace") | tee -a $O/d2h_summary.txt
       done ;;
