@@ -342,6 +342,38 @@ def box_ap_vs_fp32(mv, images, text, flavours=("bf16", "f16")):
     return r
 
 
+def same_rounding_parity(model, size, image, text, flavour):
+    """T2 of BASELINE.md section 3 for the timed flavour on ONE timed image: the oracle evaluated at the pipeline's own 16-bit rounding
+    points (oracle/rounded.py, ~1 min of host time at 1024^2) is the teacher of a teacher-forced run of the HIP pipeline; every stage's
+    output against the rounded oracle's -- what remains is accumulation order and the rounding flips it causes (tests/test_same_rounding.py
+    asserts <= 2e-3 per stage at the BASELINE configurations)."""
+    from ape_amd.stagetap import StageTap
+    from oracle import rounded
+    from oracle.configs import CONFIGS
+
+    mv = model.model_vision
+    dt = DTYPES[flavour]
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    orc = rounded.RoundedApeOracle(dict(CONFIGS[size]), sd, dtype=dt)
+    t0 = time.perf_counter()
+    orc.forward(image.cpu(), text.cpu())
+    sec = time.perf_counter() - t0
+    net = mv.backbone.net
+    teacher = rounded.teacher_stages(orc, net.token_order(net.img_size // net.patch_size)[0])
+    mv.set_compute_dtype(dt)
+    forced = StageTap(teacher=teacher)
+    mv.forward_single(image, text, forced_topk=orc.hip["topk_proposals"].to(image.device), stages=forced)
+    dist = rounded.stage_distances(forced, teacher)
+    worst = sorted(dist, key=lambda k: -dist[k][0])
+    return {"flavour": flavour, "stages": len(dist), "max_stage_rel_rms": dist[worst[0]][0] if worst else None,
+            "worst_stages": {k: round(dist[k][0], 6) for k in worst[:6]},
+            "pred_logits_rel_rms": dist.get("pred_logits", (None,))[0], "pred_boxes_rel_rms": dist.get("pred_boxes", (None,))[0],
+            "stages_over_2e-3": sorted(k for k in dist if dist[k][0] > 2e-3), "oracle_seconds": round(sec, 1),
+            "method": "every stage of the 16-bit HIP pipeline teacher-forced with the input of the oracle evaluated at the SAME rounding "
+                      "points (storage dtype of every tensor, 16-bit GEMM operands, half offsets / values, the flash loop's per-tile "
+                      "probability rounding); relative rms of the stage outputs"}
+
+
 def parity_object(mv, images, text, stages_per_image, ap_images, timed="bf16"):
     """both 16-bit flavours of the HIP pipeline (bf16 and f16; `timed` names the one the line's `value` was measured on) against the
     oracle's fp32 forwards of the same images (same weights): head tensors with the oracle's proposal order injected (max-abs
@@ -803,6 +835,11 @@ def main():
                 timed = [im.contiguous() for im in images[:max(1, args.cpu_images)]]
                 result["cpu_baseline"], O = cpu_baseline(model, args.size, timed, text, n_images=args.cpu_images)
                 result["parity"] = parity_object(mv, timed, text, O, args.ap_images, timed=args.dtype)
+                try:
+                    result["parity"]["vs_same_rounding_oracle"] = same_rounding_parity(model, args.size, timed[0], text, args.dtype)
+                except NotImplementedError as exc:        # the rounded oracle covers the APE-L_D path (BASELINE's configurations)
+                    result["parity"]["vs_same_rounding_oracle"] = {"skipped": str(exc)}
+                mv.set_compute_dtype(DTYPES[args.dtype])
             except Exception as exc:  # the baseline must never take the GPU number down with it
                 import traceback
                 result.setdefault("cpu_baseline", {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",

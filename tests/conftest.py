@@ -30,7 +30,9 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         nid = it.nodeid
         full_size_f16 = nid.endswith("-f16]") and ("test_L_D_bf16_pipeline" in nid or "test_L_D_bf16_teacher_forced" in nid)
-        if any(k in nid for k in _SLOW_KEYS) or full_size_f16:
+        # the same-rounding (T2) cases whose oracle forward takes minutes of host time: 1536^2, and the f16 repetitions
+        t2_long = "test_hip_pipeline_vs_same_rounding_oracle" in nid and ("L_D_1536" in nid or nid.endswith("-f16]"))
+        if any(k in nid for k in _SLOW_KEYS) or full_size_f16 or t2_long:
             it.add_marker(pytest.mark.slow_gpu)
             slow.append(it)
         else:

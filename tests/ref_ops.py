@@ -229,7 +229,25 @@ def attention(q, k, vt, *, batch, n, heads, head_dim, scale, out=None, stride=No
     att = (qf @ kf.transpose(-1, -2)) * scale
     if causal:
         att = att + torch.full((n, n), float("-inf"), device=att.device).triu_(1)
-    o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                       # [batch, n, heads, hdv]
+    if q.dtype in (torch.bfloat16, torch.float16) and not causal:
+        # the kernel's rounding points (csrc/attention.hip): a flash loop over key tiles of 64 -- the tile's probabilities 2^(s c - m) are
+        # rounded to the operands' 16-bit type relative to the running maximum m, the row sum runs over the ROUNDED probabilities (an MFMA
+        # of the packed tile with ones), earlier sums are rescaled in fp32
+        c = scale * 1.4426950408889634
+        m = torch.full(qf.shape[:-1] + (1,), float("-inf"), device=qf.device)
+        l = torch.zeros_like(m)
+        acc = torch.zeros(qf.shape[:-1] + (hdv,), device=qf.device)
+        for t0 in range(0, n, 64):
+            st = qf @ kf[:, :, t0:t0 + 64].transpose(-1, -2)
+            m_new = torch.maximum(m, st.amax(dim=-1, keepdim=True) * c)
+            alpha = torch.exp2(m - m_new)
+            pt = torch.exp2(st * c - m_new).to(q.dtype).float()
+            l = l * alpha + pt.sum(dim=-1, keepdim=True)
+            acc = acc * alpha + pt @ vf[:, :, t0:t0 + 64]
+            m = m_new
+        o = (acc / l).permute(0, 2, 1, 3)                                # [batch, n, heads, hdv]
+    else:
+        o = (att.softmax(-1) @ vf).permute(0, 2, 1, 3)                   # [batch, n, heads, hdv]
     full = o.new_zeros((batch, stride, heads, hdv))
     full[:, :n] = o
     full = full.reshape(rows, heads * hdv)
