@@ -30,6 +30,10 @@ struct MsdaParams {
   void* out; int ldout;
   int S, Q;             // per batch element
   int H[8], W[8], start[8];
+  // fused quad kernel: 1 / W, 1 / H when EVERY level's extent is a power of two (then o * (1 / W) == o / W bit for bit and the location
+  // arithmetic needs no IEEE division sequence: 10 of them per lane, ~110 VALU instructions); pow2 = 0 keeps the division
+  float invW[8], invH[8];
+  int pow2;
 };
 
 template <typename TV>
@@ -177,16 +181,21 @@ struct CornerGroup {
   float w[4];
 };
 
+// Round 6: a corner travels as a 32-bit BYTE OFFSET of its value row (computed once by the lane that owns the sample: row * row bytes,
+// one full-rate v_mul_u32_u24), the receiving lane adds its own (head, channel group) byte offset -- the DPP broadcast and that add are
+// ONE v_add_u32_dpp -- and the load takes the wave-uniform base pointer from SGPRs (global_load_dwordx4 v, v_off, s[base:base+1]).
+// Before: v_mov_b32_dpp + v_mad_i64_i32 (quarter rate) + v_lshl_add_u64 per corner, 80 corners per lane -- the 64-bit address arithmetic
+// was ~30 % of the kernel's VALU cycles, and the kernel is VALU bound.
 template <typename TV, int L>
-__device__ __forceinline__ void group_load(const TV* __restrict__ vb, int ldv, const float (&cw)[L][4], const int (&ci)[L][4], int s,
-                                           CornerGroup<TV>& g) {
+__device__ __forceinline__ void group_load(const unsigned char* __restrict__ vbase, uint32_t lane_off, const float (&cw)[L][4],
+                                           const int (&ci)[L][4], int s, CornerGroup<TV>& g) {
   const int l = s >> 2, P = s & 3;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     g.w[c] = quad_pick_f(P, cw[l][c]);
-    int idx = quad_pick_i(P, ci[l][c]);
-    asm volatile("" : "+v"(idx));            // the load may not be hoisted above this point (IR passes ignore sched_barrier)
-    g.raw[c] = *reinterpret_cast<const uint4*>(vb + (size_t)idx * ldv);
+    uint32_t off = (uint32_t)quad_pick_i(P, ci[l][c]) + lane_off;
+    asm volatile("" : "+v"(off));            // the load may not be hoisted above this point (IR passes ignore sched_barrier)
+    g.raw[c] = *reinterpret_cast<const uint4*>(vbase + (size_t)off);
   }
 }
 
@@ -251,6 +260,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   const int h = g & 7;
   const size_t qg = (size_t)batch * p.Q + qi;
   const TV* vb = reinterpret_cast<const TV*>(p.value) + (size_t)batch * p.S * p.ldv + h * MS_D + sub * 8;
+  // the same rows as (wave-uniform base, 32-bit byte offset): the launcher checks S * ldv * sizeof(TV) < 2^32 and row bytes < 2^24
+  const unsigned char* vbase = reinterpret_cast<const unsigned char*>(reinterpret_cast<const TV*>(p.value) + (size_t)batch * p.S * p.ldv);
+  const uint32_t lane_off = (uint32_t)((h * MS_D + sub * 8) * sizeof(TV));
+  const uint32_t rowb = (uint32_t)(p.ldv * (int)sizeof(TV));
   constexpr int LP = L * MS_P;
 
   // ---- phase 1: this lane's samples (point `sub` of every level)
@@ -285,7 +298,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const float rx = rf[l * p.refdim], ry = rf[l * p.refdim + 1];
     float lx, ly;
     if (p.refdim == 2) {                       // loc = ref + off / (W, H)            (multi_scale_deform_attn.py:298-303)
-      lx = rx + o.x / (float)W; ly = ry + o.y / (float)H;
+      if (p.pow2) { lx = rx + o.x * p.invW[l]; ly = ry + o.y * p.invH[l]; }       // exact for power-of-two extents (uniform branch)
+      else { lx = rx + o.x / (float)W; ly = ry + o.y / (float)H; }
     } else {                                   // loc = ref_xy + off / P * ref_wh / 2 (multi_scale_deform_attn.py:304-311)
       const float rw = rf[l * p.refdim + 2], rh = rf[l * p.refdim + 3];
       lx = rx + o.x / (float)MS_P * rw * 0.5f; ly = ry + o.y / (float)MS_P * rh * 0.5f;
@@ -305,6 +319,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     cw[l][1] = (t_ok && r_ok) ? aw * hh * lw : 0.f; ci[l][1] = (t_ok && r_ok) ? base + h_low * W + w_high : 0;
     cw[l][2] = (b_ok && l_ok) ? aw * lh * hw : 0.f; ci[l][2] = (b_ok && l_ok) ? base + h_high * W + w_low : 0;
     cw[l][3] = (b_ok && r_ok) ? aw * lh * lw : 0.f; ci[l][3] = (b_ok && r_ok) ? base + h_high * W + w_high : 0;
+    if (sizeof(TV) == 2) {                     // the 16-bit gather loops take BYTE offsets of the rows (group_load)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ci[l][c] = (int)__umul24((unsigned)ci[l][c], rowb);
+    }
   }
   // ---- phase 2: gather; (index, weight) of each corner broadcast from the lane that owns the sample's point.
   // Software pipeline over the L*4 samples: the 4 loads of sample s+1 are issued before the FMAs of sample s; the
@@ -314,14 +332,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
     for (int c = 0; c < 8; ++c) acc[c] = 0.f;
     CornerGroup<TV> g0, g1;
-    group_load<TV, L>(vb, p.ldv, cw, ci, 0, g0);
+    group_load<TV, L>(vbase, lane_off, cw, ci, 0, g0);
 #pragma unroll
     for (int s = 0; s < L * 4; s += 2) {
-      group_load<TV, L>(vb, p.ldv, cw, ci, s + 1, g1);
+      group_load<TV, L>(vbase, lane_off, cw, ci, s + 1, g1);
       __builtin_amdgcn_sched_barrier(0);
       group_fma_half<TV>(g0, acc);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < L * 4) group_load<TV, L>(vb, p.ldv, cw, ci, s + 2, g0);
+      if (s + 2 < L * 4) group_load<TV, L>(vbase, lane_off, cw, ci, s + 2, g0);
       __builtin_amdgcn_sched_barrier(0);
       group_fma_half<TV>(g1, acc);
       __builtin_amdgcn_sched_barrier(0);
@@ -331,14 +349,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 #pragma unroll
     for (int e = 0; e < 4; ++e) a2[e] = (f32x2_t){0.f, 0.f};
     CornerGroup<TV> g0, g1;
-    group_load<TV, L>(vb, p.ldv, cw, ci, 0, g0);
+    group_load<TV, L>(vbase, lane_off, cw, ci, 0, g0);
 #pragma unroll
     for (int s = 0; s < L * 4; s += 2) {
-      group_load<TV, L>(vb, p.ldv, cw, ci, s + 1, g1);
+      group_load<TV, L>(vbase, lane_off, cw, ci, s + 1, g1);
       __builtin_amdgcn_sched_barrier(0);
       group_fma<TV>(g0, a2);
       __builtin_amdgcn_sched_barrier(0);
-      if (s + 2 < L * 4) group_load<TV, L>(vb, p.ldv, cw, ci, s + 2, g0);
+      if (s + 2 < L * 4) group_load<TV, L>(vbase, lane_off, cw, ci, s + 2, g0);
       __builtin_amdgcn_sched_barrier(0);
       group_fma<TV>(g1, a2);
       __builtin_amdgcn_sched_barrier(0);
@@ -451,6 +469,14 @@ static int msda_fused_launch(const void* value, int ldv, int v_dt, const int64_t
   p.value = value; p.ldv = ldv; p.offw = offw; p.ldoffw = ldoffw; p.offw_f16 = offw_f16; p.ref = ref; p.refdim = refdim;
   p.out = out; p.ldout = ldout; p.S = S; p.Q = Q;
   if (fill_levels(p, spatial_shapes, level_start_index, L, S)) return -1;
+  // 16-bit gather loops address a corner as (uniform base of the batch element) + 32-bit byte offset, the row offset a 24 x 24-bit product
+  APE_CHECK_ARG(v_dt == APE_DT_F32 || ((uint64_t)S * (uint64_t)ldv * 2 < (1ull << 32) && S < (1 << 24) && ldv * 2 < (1 << 24)),
+                "msda_fused: a batch element's value tensor must stay below 4 GiB (S = %d rows of %d elements)", S, ldv);
+  p.pow2 = 1;
+  for (int l = 0; l < L; ++l) {
+    p.pow2 &= ((p.W[l] & (p.W[l] - 1)) == 0 && (p.H[l] & (p.H[l] - 1)) == 0) ? 1 : 0;
+    p.invW[l] = 1.f / (float)p.W[l]; p.invH[l] = 1.f / (float)p.H[l];
+  }
   int rc;
   hipStream_t s = (hipStream_t)stream;
   if (v_dt == APE_DT_BF16 && out_dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, true>(p, B, L, s);
