@@ -383,6 +383,175 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-STAGED sampler for the encoder's level-0 queries (round 6; BASELINE.json north_star: "LDS-staged 4-level feature sampling with
+// coalesced HBM reads"; replaces ape/layers/csrc/MsdaDeformAttn/ms_deform_im2col_cuda.cuh:237-299 for those queries).
+//
+// The quad kernel above gathers every bilinear corner as one 64-byte head row through the texture-address path: 80 scattered row
+// reads per (query, head), 3.6 GB per encoder layer through 64 B / clk / CU with a working set (~670 KB per 16 x 16-query tile) that
+// the 32 KB L1 cannot hold -- 189 us per layer, unchanged by a 25 % cut of its VALU instructions (it waits on L1 misses).
+// An encoder query samples around ITS OWN position (multi_scale_deform_attn.py:298-303: loc = reference + offset / (W, H), offsets a
+// few pixels), so the 256 queries of a 16 x 16 tile of the finest level read, in level l, a window of (16 / 2^l + 2 HALO + 2)^2 rows
+// of ONE head: <= 900 rows x 64 B.  One workgroup = (tile, head): per level it STAGES that window with coalesced 16-byte loads
+// (each row read once instead of ~9 times), then every thread samples its query's 4 points of the level out of LDS
+// (ds_read_b128, chunk slots XOR-swizzled by the window column so that the lanes of one read spread over the banks) and keeps all
+// 32 channels of its (query, head) in registers.  Two workgroups per CU (57.6 KB each): one stages while the other samples.
+// A corner outside the staged window (an offset beyond HALO pixels, or reference points that are not the queries' own positions)
+// is gathered from global memory like before -- the result never depends on the locality assumption, only the speed does.
+// Queries of the coarser levels (25 %) go through the quad kernel (their windows on the finest level would not fit).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int ML_T = 16;                              // tile edge: 16 x 16 queries of level 0
+constexpr int ML_HALO = 6;                            // staged margin around the tile's own positions, in pixels of each level
+constexpr int ML_RMAX = ML_T + 2 * ML_HALO + 2;       // 30: widest window (level 0)
+constexpr int ML_ROWS = ML_RMAX * ML_RMAX;            // 900 rows x 64 B = 57 600 B of LDS
+
+template <typename TO, typename TW, int L>
+__global__ __launch_bounds__(256) void msda_lds_kernel(const MsdaParams p) {
+  __shared__ uint4 sV[ML_ROWS * 4];
+  const int t = threadIdx.x;
+  const int h = blockIdx.x & 7;                       // head = XCD (blockIdx round-robins over the 8 XCDs): an XCD's L2 holds one head's slices
+  const int tile = blockIdx.x >> 3;
+  const int batch = blockIdx.y;
+  const int W0 = p.W[0];
+  const int tiles_x = W0 / ML_T;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  const int qi = p.start[0] + (ty * ML_T + (t >> 4)) * W0 + tx * ML_T + (t & 15);
+  const size_t qg = (size_t)batch * p.Q + qi;
+  const size_t q_first = (size_t)batch * p.Q + p.start[0] + (size_t)(ty * ML_T) * W0 + tx * ML_T;
+  const size_t q_last = q_first + (size_t)(ML_T - 1) * W0 + (ML_T - 1);
+  const uint32_t rowb = (uint32_t)p.ldv * 2u;
+  const unsigned char* vhead = reinterpret_cast<const unsigned char*>(p.value) + (size_t)batch * p.S * rowb + h * (MS_D * 2);
+  constexpr int LP = L * MS_P;
+
+  // ---- softmax over the L * 4 logits of this (query, head)
+  float e[LP];
+  {
+    const TW* lg = reinterpret_cast<const TW*>(p.offw) + qg * p.ldoffw + MS_HEADS * LP * 2 + h * LP;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = ldf<TW>(lg + i); mx = fmaxf(mx, e[i]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { e[i] = expf(e[i] - mx); sum += e[i]; }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) e[i] *= inv;
+  }
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  const TW* of = reinterpret_cast<const TW*>(p.offw) + qg * p.ldoffw + h * LP * 2;
+  const float* rf = p.ref + qg * L * 2;
+  const float* rfa = p.ref + q_first * L * 2;
+  const float* rfb = p.ref + q_last * L * 2;
+
+#pragma unroll 1
+  for (int l = 0; l < L; ++l) {
+    const int H = p.H[l], W = p.W[l];
+    // ---- the window of this level: the tile's own positions +- HALO (uniform: from the tile's first and last query)
+    const float ax = rfa[l * 2] * (float)W - 0.5f, ay = rfa[l * 2 + 1] * (float)H - 0.5f;
+    const float bx = rfb[l * 2] * (float)W - 0.5f, by = rfb[l * 2 + 1] * (float)H - 0.5f;
+    int x_lo = max(0, (int)floorf(fminf(ax, bx)) - ML_HALO), x_hi = min(W - 1, (int)floorf(fmaxf(ax, bx)) + ML_HALO + 1);
+    int y_lo = max(0, (int)floorf(fminf(ay, by)) - ML_HALO), y_hi = min(H - 1, (int)floorf(fmaxf(ay, by)) + ML_HALO + 1);
+    x_lo = __builtin_amdgcn_readfirstlane(x_lo); x_hi = __builtin_amdgcn_readfirstlane(x_hi);
+    y_lo = __builtin_amdgcn_readfirstlane(y_lo); y_hi = __builtin_amdgcn_readfirstlane(y_hi);
+    const int rw = max(0, min(ML_RMAX, x_hi - x_lo + 1)), rh = max(0, min(ML_RMAX, y_hi - y_lo + 1));
+    const unsigned char* vl = vhead + (size_t)p.start[l] * rowb;
+    if (l > 0) __syncthreads();                        // every thread is done with the previous level's window
+    // ---- stage: item i = (row r = i >> 2, chunk slot s = i & 3); slot s of window row (ry, rx) holds the row's chunk s ^ (rx & 3)
+    {
+      const int n = rw * rh * 4;
+      if (n == 0 && t < 4) sV[t] = make_uint4(0u, 0u, 0u, 0u);     // empty window: corners read row 0 with weight 0 -- it must hold finite values
+      const float inv_rw = 1.f / (float)max(rw, 1);
+      for (int i0 = 0; i0 < n; i0 += 1024) {
+        uint4 v[4];
+        int ii[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * 256 + t;
+          ii[u] = i;
+          if (i < n) {
+            const int r = i >> 2, sl = i & 3;
+            const int ry = (int)(((float)r + 0.5f) * inv_rw);
+            const int rx = r - ry * rw;
+            v[u] = *reinterpret_cast<const uint4*>(vl + (size_t)((y_lo + ry) * W + x_lo + rx) * rowb + ((sl ^ (rx & 3)) << 4));
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ii[u] < n) sV[ii[u]] = v[u];
+      }
+    }
+    __syncthreads();
+    // ---- this query's 4 points of the level
+    float off[8];
+    if (sizeof(TW) == 4) {
+      const float4 o0 = *reinterpret_cast<const float4*>(of + l * 8), o1 = *reinterpret_cast<const float4*>(of + l * 8 + 4);
+      off[0] = o0.x; off[1] = o0.y; off[2] = o0.z; off[3] = o0.w; off[4] = o1.x; off[5] = o1.y; off[6] = o1.z; off[7] = o1.w;
+    } else {
+      typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
+      const h8_t tq = *reinterpret_cast<const h8_t*>(of + l * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) off[u] = (float)tq[u];
+    }
+    const float rx0 = rf[l * 2], ry0 = rf[l * 2 + 1];
+    // this level's 4 attention weights: static indices only (a runtime index would move e[] out of the register file)
+    float ew[MS_P];
+#pragma unroll
+    for (int pt = 0; pt < MS_P; ++pt) {
+      ew[pt] = e[pt];
+#pragma unroll
+      for (int ll = 1; ll < L; ++ll) ew[pt] = (l == ll) ? e[ll * MS_P + pt] : ew[pt];
+    }
+#pragma unroll
+    for (int pt = 0; pt < MS_P; ++pt) {
+      float lx, ly;
+      if (p.pow2) { lx = rx0 + off[2 * pt] * p.invW[l]; ly = ry0 + off[2 * pt + 1] * p.invH[l]; }
+      else { lx = rx0 + off[2 * pt] / (float)W; ly = ry0 + off[2 * pt + 1] / (float)H; }
+      const float aw = ew[pt];
+      const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
+      const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+      const float hf = floorf(h_im), wf = floorf(w_im);
+      const int h_low = (int)hf, w_low = (int)wf;
+      const float lh = h_im - hf, lw = w_im - wf;
+      const float hh = 1.f - lh, hw = 1.f - lw;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int cy = h_low + (c >> 1), cx = w_low + (c & 1);
+        const bool ok = inside && cy >= 0 && cy <= H - 1 && cx >= 0 && cx <= W - 1;
+        const float wgt = ok ? aw * ((c >> 1) ? lh : hh) * ((c & 1) ? lw : hw) : 0.f;
+        const int ry = cy - y_lo, rx = cx - x_lo;
+        const bool staged = ok && ry >= 0 && ry < rh && rx >= 0 && rx < rw;
+        const int row = staged ? ry * rw + rx : 0;
+        const float wl = staged ? wgt : 0.f;
+        const int sw = rx & 3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                      // logical chunk k (channels 8 k .. 8 k + 7) sits in slot k ^ (rx & 3)
+          const uint4 d = sV[row * 4 + (k ^ sw)];
+          fma_mix_lo(acc[8 * k + 0], d.x, wl); fma_mix_hi(acc[8 * k + 1], d.x, wl);
+          fma_mix_lo(acc[8 * k + 2], d.y, wl); fma_mix_hi(acc[8 * k + 3], d.y, wl);
+          fma_mix_lo(acc[8 * k + 4], d.z, wl); fma_mix_hi(acc[8 * k + 5], d.z, wl);
+          fma_mix_lo(acc[8 * k + 6], d.w, wl); fma_mix_hi(acc[8 * k + 7], d.w, wl);
+        }
+        if (ok && !staged) {                               // outside the window: the row comes from global memory (rare)
+          const unsigned char* g = vl + (size_t)(cy * W + cx) * rowb;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint4 d = *reinterpret_cast<const uint4*>(g + (k << 4));
+            fma_mix_lo(acc[8 * k + 0], d.x, wgt); fma_mix_hi(acc[8 * k + 1], d.x, wgt);
+            fma_mix_lo(acc[8 * k + 2], d.y, wgt); fma_mix_hi(acc[8 * k + 3], d.y, wgt);
+            fma_mix_lo(acc[8 * k + 4], d.z, wgt); fma_mix_hi(acc[8 * k + 5], d.z, wgt);
+            fma_mix_lo(acc[8 * k + 6], d.w, wgt); fma_mix_hi(acc[8 * k + 7], d.w, wgt);
+          }
+        }
+      }
+    }
+  }
+  TO* o = reinterpret_cast<TO*>(p.out) + qg * p.ldout + h * MS_D;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) st8<TO>(o + 8 * k, acc + 8 * k);
+}
+
 template <typename TV, typename TO, bool FUSED>
 static int launch_msda(const MsdaParams& p, int B, int L, hipStream_t s) {
   const dim3 grid(ceil_div(p.Q, 8), B), block(256);
@@ -479,6 +648,41 @@ static int msda_fused_launch(const void* value, int ldv, int v_dt, const int64_t
   }
   int rc;
   hipStream_t s = (hipStream_t)stream;
+  // ---- encoder calls (the queries ARE the tokens, 2-d reference points), OPT-IN (APE_MSDA_LDS=1): level-0 queries through the LDS-staged
+  // kernel, the coarser levels' queries through the quad kernel on the remaining query range.  Measured on MI355X at 1024^2
+  // (profiles/r06_msda_lds_staged.txt): 191 us for the level-0 queries + 58 us for the rest = 249 us against 189 us for the quad kernel
+  // alone -- correct in every case of tests/test_ops_gpu.py::test_msda_lds_staged_encoder_path, but SLOWER: with one thread per (query,
+  // head) the location / corner arithmetic of all 20 samples is no longer shared by a quad (8.1 k VALU instructions per (query, head)
+  // against 4.4 k), and 57.6 KB of LDS per workgroup leaves 2 waves per SIMD to hide LDS latency with.  So the default stays the quad
+  // kernel; the staged kernel is kept as the measured answer to "why not LDS".
+  {
+    const char* le = getenv("APE_MSDA_LDS");
+    const int n0 = p.H[0] * p.W[0];
+    if ((le != nullptr && atoi(le) == 1) && L == 5 && refdim == 2 && Q == S && v_dt == APE_DT_F16 && p.start[0] == 0 && p.W[0] % ML_T == 0 &&
+        p.H[0] % ML_T == 0 && n0 < Q && (out_dt == APE_DT_BF16 || out_dt == APE_DT_F16)) {
+      const dim3 grid((p.H[0] / ML_T) * (p.W[0] / ML_T) * 8, B), block(256);
+      if (out_dt == APE_DT_BF16) {
+        if (offw_f16) APE_LAUNCH((msda_lds_kernel<bf16_t, f16_t, 5>), grid, block, 0, s, p);
+        else APE_LAUNCH((msda_lds_kernel<bf16_t, float, 5>), grid, block, 0, s, p);
+      } else {
+        if (offw_f16) APE_LAUNCH((msda_lds_kernel<f16_t, f16_t, 5>), grid, block, 0, s, p);
+        else APE_LAUNCH((msda_lds_kernel<f16_t, float, 5>), grid, block, 0, s, p);
+      }
+      APE_CHECK_LAUNCH("ape_hip_msda_fused (LDS-staged level-0 queries)");
+      // the rest of the queries: [n0, Q) of every batch element -- the quad kernel indexes queries from its pointers' origin
+      APE_CHECK_ARG(B == 1, "msda_fused: the LDS-staged encoder path takes one batch element per call");
+      MsdaParams r = p;
+      r.Q = Q - n0;
+      r.offw = reinterpret_cast<const unsigned char*>(offw) + (size_t)n0 * ldoffw * (offw_f16 ? 2 : 4);
+      r.ref = ref + (size_t)n0 * L * refdim;
+      r.out = reinterpret_cast<unsigned char*>(out) + (size_t)n0 * ldout * 2;
+      if (out_dt == APE_DT_BF16) rc = launch_msda<f16_t, bf16_t, true>(r, B, L, s);
+      else rc = launch_msda<f16_t, f16_t, true>(r, B, L, s);
+      if (rc) return rc;
+      APE_CHECK_LAUNCH("ape_hip_msda_fused");
+      return 0;
+    }
+  }
   if (v_dt == APE_DT_BF16 && out_dt == APE_DT_BF16) rc = launch_msda<bf16_t, bf16_t, true>(p, B, L, s);
   else if (v_dt == APE_DT_BF16 && out_dt == APE_DT_F32) rc = launch_msda<bf16_t, float, true>(p, B, L, s);
   else if (v_dt == APE_DT_F16 && out_dt == APE_DT_BF16) rc = launch_msda<f16_t, bf16_t, true>(p, B, L, s);    // half values (production)

@@ -368,6 +368,52 @@ def test_msda_half_offsets_path(ops):
     assert e < 1e-4 and relerr(want, full) < 1.2e-2      # harsh synthetic weights (logit std ~5, offsets of several pixels on a 4x4 level); below the bf16 rounding of the output
 
 
+@pytest.mark.parametrize("shapes", [[(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], [(256, 256), (128, 128), (64, 64), (32, 32), (16, 16)],
+                                    [(96, 96), (48, 48), (24, 24), (12, 12), (6, 6)]], ids=["64", "256", "96"])
+@pytest.mark.parametrize("out_dt", [torch.bfloat16, torch.float16])
+def test_msda_lds_staged_encoder_path(ops, monkeypatch, shapes, out_dt):
+    """the LDS-staged sampler of the encoder's level-0 queries (csrc/msda.hip msda_lds_kernel; multi_scale_deform_attn.py:298-303 with the
+    queries' own positions as reference points): vs the definition and vs the quad kernel (APE_MSDA_LDS=0) on the SAME inputs -- local
+    offsets (every corner inside the staged windows), offsets far beyond the halo (global-memory fall-back), a padded image (valid
+    ratios < 1: windows shifted against the tile), random reference points (the locality assumption violated on purpose), fp32 and
+    half offsets | logits; 96 x 96: extents that are not powers of two (division path)"""
+    if SELF:
+        pytest.skip("kernel-internal data path: HIP library only")
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(5)
+    value = (torch.randn(S, 256, generator=g) * 2.0).to(torch.float16).to(DEV)
+    starts = [0]
+    for h, w in shapes[:-1]:
+        starts.append(starts[-1] + h * w)
+
+    def own_refs(vr):                # get_reference_points (deformable_transformer_vl.py:371-400) for valid ratios vr = (vx, vy)
+        pts = []
+        for (H, W) in shapes:
+            ys, xs = torch.meshgrid(torch.linspace(0.5, H - 0.5, H), torch.linspace(0.5, W - 0.5, W), indexing="ij")
+            pts.append(torch.stack((xs.reshape(-1) / (vr[0] * W), ys.reshape(-1) / (vr[1] * H)), -1))
+        ref = torch.cat(pts, 0)[:, None, :] * torch.tensor(vr)[None, None, :]
+        return ref.repeat(1, 5, 1).contiguous().to(DEV)
+
+    cases = [("local +-3 px", own_refs((1.0, 1.0)), 1.5), ("beyond the halo +-20 px", own_refs((1.0, 1.0)), 10.0),
+             ("padded 0.67 x 0.81", own_refs((0.67, 0.81)), 2.0), ("random references", torch.rand(S, 5, 2, generator=g).to(DEV), 2.0)]
+    for name, ref, sigma in cases:
+        off = torch.randn(S, 8 * 5 * 4 * 2, generator=g) * sigma
+        logit = torch.randn(S, 8 * 20, generator=g) * 2.0
+        offw32 = torch.cat([off, logit], 1).contiguous().to(DEV)
+        for offw in (offw32, offw32.to(torch.float16)):
+            monkeypatch.setenv("APE_MSDA_LDS", "1")
+            got = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=out_dt)
+            monkeypatch.setenv("APE_MSDA_LDS", "0")
+            quad = ops.msda_fused(value, shapes, starts, offw, ref, out_dtype=out_dt)
+            want = ref_ops.msda_fused(value, shapes, starts, offw.float(), ref, out_dtype=torch.float32)
+            e, eq = relerr(got, want), relerr(got, quad)
+            n0 = shapes[0][0] * shapes[0][1]
+            assert torch.equal(got[n0:], quad[n0:])                          # the coarser levels' queries take the quad kernel either way
+            print(f"msda LDS-staged {shapes[0]} {out_dt} {name} offsets {offw.dtype}: vs definition {e:.3e}, vs quad kernel {eq:.3e}")
+            assert e < TOL[out_dt] and eq < TOL[out_dt], (name, e, eq)
+    monkeypatch.delenv("APE_MSDA_LDS", raising=False)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32, torch.float16])
 def test_ms_deform_attn_forward_operator(ops, dtype):
     """the reference operator signature (ape/layers/csrc/vision.cpp:76-79) incl. batch > 1"""
