@@ -749,6 +749,19 @@ def test_semantic_kernels(ops, dt):
     e3 = relerr(ops.bilinear_resize(x[:, :33, :40], 20, 17), ref_ops.bilinear_resize(x[:, :33, :40], 20, 17))   # strided view, downscale
     print("semantic kernels", dt, e, e2, e3)
     assert e < T16(dt, 5e-3, 1e-5) and e2 < 1e-5 and e3 < 1e-5
+    if not SELF:
+        # the vector kernel (8 queries per thread, 16-byte stores; n % 8 == 0) against the scalar kernel: the same arithmetic per element,
+        # bit-identical outputs -- incl. more than 512 queries (a lane's second trip) and a crop that is not a multiple of the pixel quad
+        import os
+        for (h1, w1, S1, n1, ch, cw) in [(24, 24, 96, 24, 70, 93), (16, 20, 64, 1032, 33, 61), (96, 96, 384, 504, 40, 384)]:
+            lt1 = rnd(h1 * w1, n1, seed=7) * 3.0
+            os.environ["APE_MASK_UP8"] = "0"
+            try:
+                scalar = ops.mask_upsample_sigmoid(lt1, h1, w1, S1, ch, cw, dt)
+            finally:
+                os.environ.pop("APE_MASK_UP8")
+            vec = ops.mask_upsample_sigmoid(lt1, h1, w1, S1, ch, cw, dt)
+            assert torch.equal(vec, scalar), (h1, w1, n1, ch, cw)
 
 
 def test_box_refine(ops):
