@@ -65,6 +65,11 @@ SIGNATURES = {
     "ape_hip_meter_end": (c_int, []),
     "ape_hip_meter_read": (c_int, [c_int, POINTER(c_char_p), POINTER(c_float)]),
     "ape_hip_zero": (c_int, [c_void_p, ctypes.c_size_t, c_void_p]),
+    "ape_hip_stuff_collapse": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ape_hip_sem_class_weights": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p]),
+    "ape_hip_pan_class_scores": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_float, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]),
+    "ape_hip_argmax_labels": (c_int, [c_void_p, ctypes.c_size_t, c_int, ctypes.c_size_t, c_float, c_void_p, c_void_p]),
     "ape_hip_sdma_usable": (c_int, [c_void_p, c_void_p]),
     "ape_hip_sdma_d2h": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

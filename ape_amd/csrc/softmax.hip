@@ -132,3 +132,136 @@ extern "C" int ape_hip_transpose(const void* S, int lds, int in_dt, int T, int C
   APE_CHECK_LAUNCH("ape_hip_transpose");
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-query class scores of the semantic / panoptic branches (round 6: these were ~15 tensor-library launches per image inside the captured
+// step -- sigmoid, division, softmax, max, comparisons, cat / min, zero-filled transposes).
+//   stuff_collapse    : get_stuff_score (deformable_detr_segm_vl.py:1251-1271) with a leading "things" stuff class: the nt thing columns
+//                       collapse into ONE column (their minimum), the stuff columns follow:  [Q, K] -> [Q, K - nt + 1]
+//   sem_class_weights : _postprocess_semantic (:891-894) for the kept queries: w = softmax_c(sigmoid(logits[qidx[r], c]) / temp) * valid[r] (valid = the kept detection's score >= 0; NULL: all),
+//                       written TRANSPOSED as the A operand of the class x query product: A[c, r] (16-bit or fp32), zero columns r >= k
+//   pan_class_scores  : _postprocess_panoptic (:944-949) for the panoptic queries: (score, label) = max_c sigmoid(logits) -- or, with
+//                       transform_eval, of softmax_c(sigmoid / temp) --, keep = valid & (max_c sigmoid > object_mask_threshold)
+// One wave per query row; the class rows are L2 resident (K <= a few thousand); fp32 math, the same operation order as the tensor-level
+// definitions (tests/ref_ops.py).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stuff_collapse_kernel(const float* __restrict__ x, int ldx, int Q, int K, int nt, float* __restrict__ out,
+                                                             int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const float* r = x + (size_t)q * ldx;
+  float m = INFINITY;
+  for (int c = lane; c < nt; c += 64) m = fminf(m, r[c]);
+  m = -wave_max(-m);
+  float* o = out + (size_t)q * ldo;
+  if (lane == 0) o[0] = m;
+  for (int c = nt + lane; c < K; c += 64) o[c - nt + 1] = r[c];
+}
+
+extern "C" int ape_hip_stuff_collapse(const float* logits, int ldl, int Q, int K, int nt, float* out, int ldo, void* stream) {
+  APE_CHECK_ARG(logits && out && Q > 0 && nt >= 1 && nt <= K && ldo >= K - nt + 1, "ape_hip_stuff_collapse: bad args");
+  APE_LAUNCH(stuff_collapse_kernel, dim3(ceil_div(Q, 4)), dim3(256), 0, (hipStream_t)stream, logits, ldl, Q, K, nt, out, ldo);
+  APE_CHECK_LAUNCH("ape_hip_stuff_collapse");
+  return 0;
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+template <typename TO>
+__global__ __launch_bounds__(256) void sem_class_weights_kernel(const float* __restrict__ x, int ldx, const int64_t* __restrict__ qidx,
+                                                                const float* __restrict__ valid, int k, int kp, int K, float temp,
+                                                                TO* __restrict__ A, int lda) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= kp) return;
+  if (r >= k) {                                                  // padding columns of the operand
+    for (int c = lane; c < K; c += 64) stf<TO>(A + (size_t)c * lda + r, 0.f);
+    return;
+  }
+  const float* row = x + (size_t)qidx[r] * ldx;
+  float m = -INFINITY;
+  for (int c = lane; c < K; c += 64) m = fmaxf(m, sigmoidf_(row[c]) / temp);
+  m = wave_max(m);
+  float sum = 0.f;
+  for (int c = lane; c < K; c += 64) sum += expf(sigmoidf_(row[c]) / temp - m);
+  sum = wave_sum(sum);
+  const float sc = (valid == nullptr || valid[r] >= 0.f) ? 1.f / sum : 0.f;
+  for (int c = lane; c < K; c += 64) stf<TO>(A + (size_t)c * lda + r, expf(sigmoidf_(row[c]) / temp - m) * sc);
+}
+
+extern "C" int ape_hip_sem_class_weights(const float* logits, int ldl, const int64_t* qidx, const float* valid, int k, int kp, int K,
+                                         float temp, void* A, int lda, int out_dt, void* stream) {
+  APE_CHECK_ARG(logits && qidx && A && k > 0 && kp >= k && K > 0 && lda >= kp, "ape_hip_sem_class_weights: bad args");
+  const dim3 grid(ceil_div(kp, 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_dt == APE_DT_F16) APE_LAUNCH(sem_class_weights_kernel<f16_t>, grid, block, 0, s, logits, ldl, qidx, valid, k, kp, K, temp, (f16_t*)A, lda);
+  else if (out_dt == APE_DT_BF16) APE_LAUNCH(sem_class_weights_kernel<bf16_t>, grid, block, 0, s, logits, ldl, qidx, valid, k, kp, K, temp, (bf16_t*)A, lda);
+  else if (out_dt == APE_DT_F32) APE_LAUNCH(sem_class_weights_kernel<float>, grid, block, 0, s, logits, ldl, qidx, valid, k, kp, K, temp, (float*)A, lda);
+  else APE_CHECK_ARG(false, "ape_hip_sem_class_weights: bad out_dt %d", out_dt);
+  APE_CHECK_LAUNCH("ape_hip_sem_class_weights");
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void pan_class_scores_kernel(const float* __restrict__ x, int ldx, const int64_t* __restrict__ qidx,
+                                                               const float* __restrict__ valid, int k, int K, float thresh, int transform,
+                                                               float temp, float* __restrict__ score, int64_t* __restrict__ label,
+                                                               int32_t* __restrict__ label32, uint8_t* __restrict__ keep) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= k) return;
+  const float* row = x + (size_t)(qidx != nullptr ? qidx[r] : r) * ldx;
+  // max of sigmoid, first index on ties (torch.max)
+  float m = -INFINITY;
+  int mi = 0x7fffffff;
+  for (int c = lane; c < K; c += 64) {
+    const float v = sigmoidf_(row[c]);
+    if (v > m) { m = v; mi = c; }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(m, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+  }
+  const bool kp = (valid == nullptr || valid[r] >= 0.f) && (m > thresh);
+  float sc = m;
+  if (transform) {                                               // softmax(sigmoid / temp).max(-1): the same argmax, the score renormalised
+    float sum = 0.f;
+    for (int c = lane; c < K; c += 64) sum += expf(sigmoidf_(row[c]) / temp - m / temp);
+    sum = wave_sum(sum);
+    sc = 1.f / sum;
+  }
+  if (lane == 0) { score[r] = sc; label[r] = mi; if (label32 != nullptr) label32[r] = mi; keep[r] = kp ? 1 : 0; }
+}
+
+extern "C" int ape_hip_pan_class_scores(const float* logits, int ldl, const int64_t* qidx, const float* valid, int k, int K, float thresh,
+                                        int transform, float temp, float* score, int64_t* label, int32_t* label32, uint8_t* keep, void* stream) {
+  APE_CHECK_ARG(logits && score && label && keep && k > 0 && K > 0, "ape_hip_pan_class_scores: bad args");
+  APE_LAUNCH(pan_class_scores_kernel, dim3(ceil_div(k, 4)), dim3(256), 0, (hipStream_t)stream, logits, ldl, qidx, valid, k, K, thresh, transform,
+             temp, score, label, label32, keep);
+  APE_CHECK_LAUNCH("ape_hip_pan_class_scores");
+  return 0;
+}
+
+// argmax over the class axis of a [C, H * W] fp32 score volume -> int16 labels (the label map every semantic evaluator reduces the scores to;
+// first index on ties like torch.argmax); `class0` (NaN = off) REPLACES the scores of class 0 (deformable_detr_segm_vl.py:654-663: the constant
+// "things" logit of stuff-only evaluation).
+__global__ __launch_bounds__(256) void argmax_labels_kernel(const float* __restrict__ x, size_t ldc, int C, size_t n, float class0,
+                                                            int16_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float m = (class0 == class0) ? class0 : x[i];
+  int mi = 0;
+  for (int c = 1; c < C; ++c) {
+    const float v = x[(size_t)c * ldc + i];
+    if (v > m) { m = v; mi = c; }
+  }
+  out[i] = (int16_t)mi;
+}
+
+extern "C" int ape_hip_argmax_labels(const float* x, size_t ld_class, int C, size_t n, float class0, int16_t* out, void* stream) {
+  APE_CHECK_ARG(x && out && C > 0 && C < 32768 && n > 0 && ld_class >= n, "ape_hip_argmax_labels: bad args");
+  APE_LAUNCH(argmax_labels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ld_class, C, n, class0, out);
+  APE_CHECK_LAUNCH("ape_hip_argmax_labels");
+  return 0;
+}

@@ -463,16 +463,15 @@ class DeformableDETRSegmVL(nn.Module):
             # are upsampled to the padded input size (:569-572) and cropped to the image (sem_seg_postprocess, :942)
             if self.panoptic_post_nms:
                 pdet = self.inference_single(logits, boxes, (h, w), geo.box_scale)
-                pq, pvalid = pdet["det_query"], pdet["det_scores"] >= 0
+                pq, pvscore = pdet["det_query"], pdet["det_scores"]            # empty slots carry score -1
             else:
-                pq = torch.arange(logits.shape[0], device=logits.device)
-                pvalid = torch.ones_like(pq, dtype=torch.bool)
+                pq, pvscore = ops.arange_i64(logits.shape[0], logits.device), None
             H0, W0 = geo.shapes[0]
             S = self.backbone.padding_constraints.get("square_size", 0)
             pkept = ops.gather_rows(membed, pq)
             plog = ops.gemm(pkept, mask_feat, None, out_dtype=torch.float32)                          # [k, H0*W0]
             up = ops.bilinear_resize(plog.view(-1, H0, W0), S, S)
-            out.update(pan_masks=up[:, :h, :w], pan_cls=logits[pq], pan_valid=pvalid, pan_query=pq)
+            out.update(pan_masks=up[:, :h, :w], pan_cls=ops.gather_rows(logits, pq), pan_valid_score=pvscore, pan_query=pq)
         if want_masks:
             H0, W0 = geo.shapes[0]
             # only the kept queries are decoded / upsampled: the einsum (:510) and F.interpolate (:569-572) act per query
@@ -492,12 +491,11 @@ class DeformableDETRSegmVL(nn.Module):
     @staticmethod
     def stuff_score(logits, meta):
         """get_stuff_score (deformable_detr_segm_vl.py:1251-1271): with a leading "things" stuff class, the thing columns
-        collapse into one (their minimum)."""
+        collapse into one (their minimum) -- one library launch (csrc/softmax.hip stuff_collapse)."""
         thing, stuff, entity = meta.get("thing_classes") or [], meta.get("stuff_classes") or [], meta["entity"]
         overlap = len(thing) > 0 and len(stuff) > 0 and (set(thing) <= set(stuff) or set(stuff) <= set(thing))
         if entity == "thing+stuff" and stuff[0] == "things" and not overlap:
-            nt = len(thing)
-            return torch.cat([logits[:, :nt].min(dim=1, keepdim=True)[0], logits[:, nt:]], dim=1).contiguous()
+            return ops.stuff_collapse(logits, len(thing))
         return logits
 
     def semantic_single(self, logits, boxes, membed, mask_feat, geo, image_size, meta, dt, stages=None, pano_temp=0.06):
@@ -509,24 +507,23 @@ class DeformableDETRSegmVL(nn.Module):
         sem_logits = self.stuff_score(logits, meta)
         if self.semantic_post_nms:
             sdet = self.inference_single(sem_logits, boxes, image_size, geo.box_scale)
-            qidx, valid = sdet["det_query"], sdet["det_scores"] >= 0
+            qidx, vscore = sdet["det_query"], sdet["det_scores"]                 # empty slots of the fixed-shape list carry score -1
         else:
-            qidx = torch.arange(logits.shape[0], device=logits.device)
-            valid = torch.ones_like(qidx, dtype=torch.bool)
+            qidx, vscore = ops.arange_i64(logits.shape[0], logits.device), None
         k = qidx.numel()
         kp = (k + 7) // 8 * 8
-        cls = torch.softmax(sem_logits[qidx].sigmoid() / pano_temp, dim=-1) * valid[:, None]           # [k, K']  (:891-894)
-        A = torch.zeros((cls.shape[1], kp), dtype=dt, device=cls.device)
-        A[:, :k] = cls.t()
-        kept = torch.zeros((kp, membed.shape[1]), dtype=dt, device=cls.device)
-        kept[:k] = ops.gather_rows(membed, qidx.to(torch.int32))
+        # class weights of the kept queries, softmax(sigmoid / T) (:891-894), as the [K', kp] A operand; the kept queries' mask embeddings
+        # as a zero-padded [kp, 256] operand -- library launches only (round 5: sigmoid / softmax / mask / zeros / transposed copy in torch)
+        A = ops.sem_class_weights(sem_logits, qidx, vscore, pano_temp, kp, dt)
+        kept = ops.zeros((kp, membed.shape[1]), dt, membed.device)
+        ops.gather_rows(membed, qidx, out=kept[:k])
         H0, W0 = geo.shapes[0]
         S = self.backbone.padding_constraints.get("square_size", 0)
         mlog_t = ops.gemm(mask_feat, kept, None, out_dtype=torch.float32)                               # [H0*W0, kp] pixel-major
         prob = ops.mask_upsample_sigmoid(mlog_t, H0, W0, S, h, w, dt)                                   # [h*w, kp]   (:569-572, 895)
         sem = ops.gemm(A, prob, None, out_dtype=torch.float32)                                          # [K', h*w]   (:899)
         if stages is not None:
-            stages.update(sem_box_cls=sem_logits, sem_query=qidx, sem_valid=valid)
+            stages.update(sem_box_cls=sem_logits, sem_query=qidx, sem_valid=(vscore >= 0) if vscore is not None else torch.ones_like(qidx, dtype=torch.bool))
         return sem.view(-1, h, w)
 
     def inference_single(self, logits, boxes, image_size, scale=None):
@@ -599,12 +596,10 @@ class DeformableDETRSegmVL(nn.Module):
         (k x K' values); the pixel work and the sequential walk over the queries are csrc/masks.hip `panoptic_*` (3 launches).
         -> (panoptic_seg int32 [H, W], info int32 [k, 3] = (id, isthing, category_id) per segment, count int32 [1]), all on the device"""
         cfg = self.panoptic_configs
-        mask_cls = out["pan_cls"].float()
-        sig = mask_cls.sigmoid()
-        scores, labels = sig.max(-1)
-        keep = out["pan_valid"] & (scores > cfg["object_mask_threshold"])                    # (:947)
-        if cfg["transform_eval"]:
-            scores, labels = torch.softmax(sig / cfg["pano_temp"], dim=-1).max(-1)            # (:948-949)
+        mask_cls = out["pan_cls"]
+        # (:944-949) max of the sigmoid scores, the mask threshold, the optional softmax(sigmoid / T) rescoring: one library launch
+        scores, _, keep, labels = ops.pan_class_scores(mask_cls, None, out.get("pan_valid_score"), cfg["object_mask_threshold"],
+                                                       bool(cfg["transform_eval"]), cfg["pano_temp"])
         ids = tuple(sorted(i for i in (meta.get("thing_dataset_id_to_contiguous_id") or {}).values() if 0 <= i < mask_cls.shape[1]))
         key = (ids, mask_cls.shape[1], mask_cls.device)
         cache = self.__dict__.setdefault("_pan_thing_cache", {})          # per (thing ids, vocabulary width, device): built outside captures
@@ -613,7 +608,7 @@ class DeformableDETRSegmVL(nn.Module):
             thing[list(ids)] = True
             cache[key] = thing.to(mask_cls.device)
         things_first = (meta.get("stuff_classes") or [""])[0] == "things"
-        return ops.panoptic_merge(out["pan_masks"], scores.contiguous(), keep, labels, cache[key], height, width, prob=cfg["prob"],
+        return ops.panoptic_merge(out["pan_masks"], scores, keep, labels, cache[key], height, width, prob=cfg["prob"],
                                   overlap_threshold=cfg["overlap_threshold"],
                                   stuff_offset=len(meta["thing_classes"]) if things_first else -1)
 

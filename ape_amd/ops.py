@@ -757,6 +757,77 @@ def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):
     return out
 
 
+_ARANGE = {}
+
+
+def arange_i64(n, device):
+    """the constant [0, 1, ..., n - 1] int64 on `device`, created once per (n, device) -- the first call happens in the un-captured warm-up
+    runs of a step, so a captured step only READS it (no tensor-library launch inside the graph)"""
+    key = (int(n), str(device))
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(int(n), dtype=torch.int64, device=device)
+    return _ARANGE[key]
+
+
+def stuff_collapse(logits, nt):
+    """get_stuff_score (deformable_detr_segm_vl.py:1251-1271) with a leading "things" stuff class: [Q, K] fp32 -> [Q, K - nt + 1] (column 0 =
+    the minimum over the nt thing columns, then the stuff columns)"""
+    _dev(logits)
+    _rowmajor(logits, "logits")
+    Q, K = logits.shape
+    out = torch.empty((Q, K - nt + 1), dtype=torch.float32, device=logits.device)
+    _lib.check(_lib.load().ape_hip_stuff_collapse(_p(logits), _ld(logits), Q, K, int(nt), _p(out), _ld(out), _stream()), "ape_hip_stuff_collapse")
+    return out
+
+
+def sem_class_weights(logits, qidx, valid, temp, kp, out_dtype):
+    """softmax_c(sigmoid(logits[qidx]) / temp) * valid (:891-894), TRANSPOSED and zero-padded to kp query columns: the [K, kp] A operand of
+    the semantic branch's class x query product.  logits [Q, K] fp32, qidx int64 [k], valid: fp32 [k] detection scores (a row counts iff its
+    score >= 0: the fixed-shape detection lists mark empty slots with -1) or None"""
+    _dev(logits, qidx, valid)
+    _rowmajor(logits, "logits")
+    if qidx.dtype != torch.int64 or not qidx.is_contiguous():
+        raise TypeError("ape_amd.ops.sem_class_weights: qidx must be contiguous int64")
+    k, K = qidx.numel(), logits.shape[1]
+    A = torch.empty((K, kp), dtype=out_dtype, device=logits.device)
+    v = _f32vec(valid, "valid")
+    rc = _lib.load().ape_hip_sem_class_weights(_p(logits), _ld(logits), _p(qidx), _p(v), k, int(kp), K, float(temp), _p(A), _ld(A), _dt(A), _stream())
+    _lib.check(rc, "ape_hip_sem_class_weights")
+    return A
+
+
+def pan_class_scores(logits, qidx, valid, thresh, transform, temp):
+    """_postprocess_panoptic's per-query scores (:944-949): -> (score fp32 [k], label int64 [k], keep bool [k], label int32 [k]); logits [Q, K] fp32, qidx int64 [k]
+    (None: the rows themselves), valid: fp32 [k] detection scores (valid iff >= 0) or None"""
+    _dev(logits, qidx, valid)
+    _rowmajor(logits, "logits")
+    k = qidx.numel() if qidx is not None else logits.shape[0]
+    dev = logits.device
+    score = torch.empty((k,), dtype=torch.float32, device=dev)
+    label = torch.empty((k,), dtype=torch.int64, device=dev)          # the kernel writes int64 (torch.max's index type)
+    keep = torch.empty((k,), dtype=torch.bool, device=dev)
+    label32 = torch.empty((k,), dtype=torch.int32, device=dev)
+    v = _f32vec(valid, "valid")
+    rc = _lib.load().ape_hip_pan_class_scores(_p(logits), _ld(logits), _p(qidx), _p(v), k, logits.shape[1], float(thresh), 1 if transform else 0,
+                                              float(temp), _p(score), _p(label), _p(label32), _p(keep), _stream())
+    _lib.check(rc, "ape_hip_pan_class_scores")
+    return score, label, keep, label32
+
+
+def argmax_labels(x, class0=None, out=None):
+    """int16 argmax over the class axis of fp32 scores [C, H, W] (contiguous) -> [H, W]; class0: constant that replaces class 0's scores
+    (deformable_detr_segm_vl.py:654-663)"""
+    _dev(x, out)
+    if x.dtype != torch.float32 or x.dim() != 3 or not x.is_contiguous():
+        raise ValueError("ape_amd.ops.argmax_labels: x must be contiguous float32 [C, H, W]")
+    C, H, W = x.shape
+    if out is None:
+        out = torch.empty((H, W), dtype=torch.int16, device=x.device)
+    rc = _lib.load().ape_hip_argmax_labels(_p(x), H * W, C, H * W, float("nan") if class0 is None else float(class0), _p(out), _stream())
+    _lib.check(rc, "ape_hip_argmax_labels")
+    return out
+
+
 def bilinear_resize(x, height, width):
     """F.interpolate(x[None], (height, width), mode="bilinear", align_corners=False)[0] for fp32 x [C, h, w]
     (rows contiguous; channel / row strides free)."""
@@ -781,9 +852,11 @@ def panoptic_merge(masks, scores, keep, classes, isthing, height, width, *, prob
     k, h, w = masks.shape
     dev = masks.device
     scores = scores.contiguous()
-    keep8 = keep.to(torch.uint8).contiguous()
-    cls32 = classes.to(torch.int32).contiguous()
-    thing8 = isthing.to(torch.uint8).contiguous()
+    # bool -> uint8 views are free; the class ids arrive as int64 from pan_class_scores: their LOW words are the int32 ids (little endian,
+    # ids >= 0), read through a stride-2 view by a one-launch gather only when they are not int32 already
+    keep8 = keep.view(torch.uint8) if keep.dtype == torch.bool and keep.is_contiguous() else keep.to(torch.uint8).contiguous()
+    cls32 = classes if classes.dtype == torch.int32 and classes.is_contiguous() else classes.to(torch.int32).contiguous()
+    thing8 = isthing.view(torch.uint8) if isthing.dtype == torch.bool and isthing.is_contiguous() else isthing.to(torch.uint8).contiguous()
     owner = torch.empty((height, width), dtype=torch.int16, device=dev)
     conf = torch.empty((height, width), dtype=torch.uint8, device=dev)
     areas = torch.empty((k, 3), dtype=torch.int32, device=dev)

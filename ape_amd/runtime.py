@@ -222,7 +222,7 @@ class GraphedForward:
         pan = None
         if self.panoptic is not None:
             # any_size: (height, width) = the pad; the pieces stay fixed-shape here and are merged in _replay (ticket sizes)
-            pan = ({k: out[k] for k in ("pan_masks", "pan_cls", "pan_valid")} if self.any_size
+            pan = ({k: out.get(k) for k in ("pan_masks", "pan_cls", "pan_valid_score")} if self.any_size
                    else mv.panoptic_device(out, height, width, self.panoptic))
         # boxes in the output frame, keep flags, records with the kept detections first (stable) -- the host then takes PREFIX
         # views of the pinned buffers instead of gathering ~1 MB per mask with a boolean index; dropped rows (empty slots, empty
@@ -240,12 +240,13 @@ class GraphedForward:
         import math
         from . import ops
         mv = self.mv
-        r = ops.bilinear_resize(sem, height, width)                                          # (:916)
+        r = ops.bilinear_resize(sem, height, width)                             # (:916)
         meta = self.semantic
+        class0 = None
         if (mv.eval_dataset_id >= 0 and meta.get("entity") == "stuff" and (meta.get("stuff_classes") or [""])[0] == "things"
                 and mv.stuff_prob_thing > 0):                                                # (:654-663)
-            r[0] = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
-        return r.argmax(0).to(torch.int16).contiguous()
+            class0 = math.log(mv.stuff_prob_thing / (1 - mv.stuff_prob_thing))
+        return ops.argmax_labels(r, class0)                                                  # library launch (round 5: torch argmax + cast)
 
     def _tail(self, e, b, vit_feat, encoder_done=None):
         height, width = e.size

@@ -324,6 +324,21 @@ int ape_hip_colstats(const float* S, int lds, int T, int C, const float* gmax, f
                      void* stream);
 int ape_hip_transpose(const void* S, int lds, int in_dt, int T, int C, const float* gmax, const float* colmax,
                       const float* colsum, void* out, int ldo, int out_dt, void* stream);
+/* Per-query class scores of the semantic / panoptic branches (round 6; csrc/softmax.hip) -- replace the tensor-library glue of
+ * ape/modeling/ape_deta/deformable_detr_segm_vl.py:1251-1271 (get_stuff_score), :891-894 (semantic class weights), :944-949 (panoptic scores)
+ * and the final argmax of the label map.
+ *   stuff_collapse   : [Q, K] -> [Q, K - nt + 1]: column 0 = min over the nt thing columns, then the stuff columns
+ *   sem_class_weights: A[c, r] = softmax_c(sigmoid(logits[qidx[r], c]) / temp) * valid[r] for r < k, 0 for k <= r < kp (lda >= kp)
+ *   pan_class_scores : score / label = max_c sigmoid (transform: of softmax_c(sigmoid / temp)); keep = valid & (max sigmoid > thresh)
+ *   (valid_score: fp32 [k] detection scores, a row is valid iff its score >= 0 -- the fixed-shape detection lists mark empty slots with -1; NULL = all)
+ *   argmax_labels    : int16 argmax over the class axis of [C, n] scores (class stride ld_class); class0 != NaN replaces class 0's scores */
+int ape_hip_stuff_collapse(const float* logits, int ldl, int Q, int K, int nt, float* out, int ldo, void* stream);
+int ape_hip_sem_class_weights(const float* logits, int ldl, const int64_t* qidx, const float* valid_score, int k, int kp, int K, float temp,
+                              void* A, int lda, int out_dt, void* stream);
+int ape_hip_pan_class_scores(const float* logits, int ldl, const int64_t* qidx, const float* valid_score, int k, int K, float thresh, int transform,
+                             float temp, float* score, int64_t* label, int32_t* label32 /* may be NULL */, uint8_t* keep, void* stream);
+int ape_hip_argmax_labels(const float* x, size_t ld_class, int C, size_t n, float class0, int16_t* out, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Instance-mask post-processing of the kept detections -- csrc/masks.hip

@@ -459,6 +459,46 @@ def mask_upsample_sigmoid(logits_t, h0, w0, size, crop_h, crop_w, out_dtype):
     return up[:, :crop_h, :crop_w].sigmoid().reshape(n, -1).t().contiguous().to(out_dtype)
 
 
+def arange_i64(n, device):
+    return torch.arange(int(n), dtype=torch.int64, device=device)
+
+
+def stuff_collapse(logits, nt):
+    return torch.cat([logits[:, :nt].min(dim=1, keepdim=True)[0], logits[:, nt:]], dim=1).contiguous()
+
+
+def sem_class_weights(logits, qidx, valid, temp, kp, out_dtype):
+    cls = torch.softmax(logits.float()[qidx].sigmoid() / temp, dim=-1)
+    if valid is not None:
+        cls = cls * (valid.float() >= 0)[:, None]
+    A = torch.zeros((cls.shape[1], kp), dtype=out_dtype, device=logits.device)
+    A[:, : cls.shape[0]] = cls.t().to(out_dtype)
+    return A
+
+
+def pan_class_scores(logits, qidx, valid, thresh, transform, temp):
+    x = logits.float() if qidx is None else logits.float()[qidx]
+    sig = x.sigmoid()
+    scores, labels = sig.max(-1)
+    keep = scores > thresh
+    if valid is not None:
+        keep = keep & (valid.float() >= 0)
+    if transform:
+        scores, labels = torch.softmax(sig / temp, dim=-1).max(-1)
+    return scores.contiguous(), labels, keep, labels.to(torch.int32)
+
+
+def argmax_labels(x, class0=None, out=None):
+    if class0 is not None:
+        x = x.clone()
+        x[0] = class0
+    r = x.argmax(0).to(torch.int16)
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r
+
+
 def bilinear_resize(x, height, width):
     return F.interpolate(x.float()[None], size=(height, width), mode="bilinear", align_corners=False)[0]
 

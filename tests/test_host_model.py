@@ -588,6 +588,29 @@ def test_forward_path_issues_no_tensor_library_glue(monkeypatch):
     # round 5: ZERO -- the two zero-fills of the padded V^T operand buffers (ViT, decoder self-attention) go through the library's own
     # stream-ordered fill (ops.zeros -> ape_hip_zero) like every other launch of the forward
     assert sum(g.kinds.values()) == 0, dict(g.kinds)
+    # round 6: the SEMANTIC and PANOPTIC branches of a captured step as well (torch.softmax / sigmoid / cat / min /
+    # zero-filled transposes / argmax inside GraphedForward(semantic=..., panoptic=...)) -- the device work of one image exactly as
+    # runtime.GraphedForward._device_part issues it, on the semantic fixture's metadata
+    from ape_amd.runtime import GraphedForward
+    model, image, text, gold = M.build_model("tiny_semantic", "cpu", torch.float32)
+    mv = model.model_vision
+    mv.set_compute_dtype(torch.bfloat16)
+    meta = gold["semantic_meta"]
+    thing_ids = {i + 1: i for i in range(len(meta["thing_classes"]))}
+    mv.semantic_on = mv.panoptic_on = True
+    mv.set_metadata(0, name="coco_2017_val", thing_classes=meta["thing_classes"], stuff_classes=meta["stuff_classes"],
+                    thing_dataset_id_to_contiguous_id=thing_ids)
+    mv.panoptic_configs = dict(gold.get("panoptic_cfg") or {"prob": 0.1, "pano_temp": 0.06, "transform_eval": True, "object_mask_threshold": 0.01,
+                                                            "overlap_threshold": 0.4})
+    sem_meta = dict(mv.metadata_list[-1], entity=mv.dataset_entities[-1])
+    run = GraphedForward.__new__(GraphedForward)
+    run.mv, run.with_masks, run.semantic, run.panoptic, run.any_size = mv, True, sem_meta, mv.metadata_list[-1], False
+    h, w = image.shape[-2:]
+    frame = torch.tensor([1.0, 1.0, 1.0, 1.0, w, h, w, h])
+    run._device_part(image, text, h, w, frame)          # caches
+    with Glue() as g:
+        run._device_part(image, text, h, w, frame)
+    assert sum(g.kinds.values()) == 0, dict(g.kinds)
 
 
 def test_graph_retirement_is_bounded(monkeypatch):

@@ -764,6 +764,37 @@ def test_semantic_kernels(ops, dt):
             assert torch.equal(vec, scalar), (h1, w1, n1, ch, cw)
 
 
+@pytest.mark.parametrize("K,nt", [(134, 80), (20, 3), (1203, 1), (65, 65)])
+def test_class_score_kernels(ops, K, nt):
+    """stuff_collapse / sem_class_weights / pan_class_scores / argmax_labels (csrc/softmax.hip) vs their tensor-level definitions
+    (deformable_detr_segm_vl.py:1251-1271, :891-894, :944-949): values to fp32 rounding, labels / keep flags / argmax IDENTICAL"""
+    Q, k = 900, 300
+    g = torch.Generator().manual_seed(K)
+    logits = (torch.randn(Q, K, generator=g) * 3.0 - 2.0).to(DEV)
+    logits[5, :] = logits[5, 0]                                       # a row of ties: first index wins
+    qidx = torch.randperm(Q, generator=g)[:k].to(DEV)
+    vscore = torch.where(torch.rand(k, generator=g) < 0.1, torch.tensor(-1.0), torch.rand(k, generator=g)).to(DEV)
+    got, want = ops.stuff_collapse(logits, nt), ref_ops.stuff_collapse(logits, nt)
+    assert torch.equal(got, want)
+    kp = (k + 7) // 8 * 8
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        for v in (vscore, None):
+            A, B = ops.sem_class_weights(got, qidx, v, 0.06, kp, dt), ref_ops.sem_class_weights(want, qidx, v, 0.06, kp, dt)
+            assert A.shape == B.shape == (K - nt + 1, kp) and A.dtype == dt
+            assert relerr(A, B) < T16(dt, 5e-3, 2e-6), (dt, relerr(A, B))
+            assert float(A[:, k:].abs().max()) == 0.0
+    for transform in (False, True):
+        for q, v in ((qidx, vscore), (None, None)):
+            s1, l1, k1, l32 = ops.pan_class_scores(logits, q, v, 0.3, transform, 0.06)
+            s2, l2, k2, _ = ref_ops.pan_class_scores(logits, q, v, 0.3, transform, 0.06)
+            assert torch.equal(l1, l2) and torch.equal(k1, k2) and torch.equal(l32.long(), l2) and relerr(s1, s2) < 2e-6
+    x = rnd(K, 37, 53, seed=3)
+    x[:, 4, 4] = 1.0                                                  # ties -> class 0
+    assert torch.equal(ops.argmax_labels(x), ref_ops.argmax_labels(x))
+    assert torch.equal(ops.argmax_labels(x, class0=0.25), ref_ops.argmax_labels(x, class0=0.25))
+    print(f"class score kernels K={K} nt={nt}: ok")
+
+
 def test_box_refine(ops):
     Q, L = 900, 5
     g = torch.Generator().manual_seed(5)
