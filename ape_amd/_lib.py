@@ -32,6 +32,7 @@ class GemmArgs(Structure):
         ("rowscale", c_void_p), ("rowshift", c_void_p), ("colvec", c_void_p), ("rope_cs", c_void_p),
         ("ln_w", c_void_p), ("ln_b", c_void_p), ("ln_eps", c_float), ("reserved0", c_int32),
         ("conv_perm", c_void_p), ("conv_zero", c_void_p), ("conv_h", c_int32), ("conv_w", c_int32),
+        ("rowstat_cols", c_int32), ("rowstat_eps", c_float),
     ]
 
 

@@ -120,6 +120,27 @@ template <> struct h16<f16_t> {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
   }
 };
+// fp32 dot product of two packed 16-bit pairs on top of c (v_dot2c_f32_bf16 / v_dot2c_f32_f16): a.lo * b.lo + a.hi * b.hi + c
+template <typename H> __device__ __forceinline__ float dot2acc(uint32_t a, uint32_t b, float c);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <> __device__ __forceinline__ float dot2acc<bf16_t>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2acc<f16_t>(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b), c, false);
+}
+// the same instruction as a volatile asm statement (acc += a . b): stays where it is written -- the builtin is pure arithmetic that
+// hipcc sinks to its first use, e.g. out of a pipelined main loop's phase and behind the barriers that delimit it
+template <typename H> __device__ __forceinline__ void dot2acc_pinned(float& acc, uint32_t a, uint32_t b);
+template <> __device__ __forceinline__ void dot2acc_pinned<bf16_t>(float& acc, uint32_t a, uint32_t b) {
+  asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <> __device__ __forceinline__ void dot2acc_pinned<f16_t>(float& acc, uint32_t a, uint32_t b) {
+  asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <typename H> struct ones2;                       // (1, 1) as a packed pair
+template <> struct ones2<bf16_t> { static constexpr uint32_t v = 0x3f803f80u; };
+template <> struct ones2<f16_t> { static constexpr uint32_t v = 0x3c003c00u; };
 // two packed 16-bit values -> two floats
 template <typename H> __device__ __forceinline__ void unpack2(uint32_t u, float& a, float& b);
 template <> __device__ __forceinline__ void unpack2<bf16_t>(uint32_t u, float& a, float& b) {

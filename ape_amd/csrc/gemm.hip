@@ -1022,50 +1022,57 @@ __global__ __launch_bounds__(256, 2) void gemm_kres_ln_kernel(const GemmParams p
     compute(t, t >> 2, t & 3);
   }
   // ---- epilogue: + bias + residual, LayerNorm over the row's 256 channels, 16-byte stores (64 contiguous bytes per row and instruction)
+  // ONE wave-uniform branch on the residual (round 6).  Tested per load, each of the 16 residual pieces of a wave sat in a basic block
+  // of its own, and the register allocator carried three finished accumulators through that chain in scratch: the 56-76 B per lane
+  // this kernel had since round 4 (a dispatch with any scratch is throttled on this chip).  Same arithmetic, 250 / 235 registers, 0 B.
+  auto epilogue = [&](auto res_t) __attribute__((always_inline)) {
+    constexpr bool RES = decltype(res_t)::value;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int m = mrow[mi] < p.M ? mrow[mi] : p.M - 1;                   // clamped: the lane swaps need every lane
-    float v[64];
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-      for (int jp = 0; jp < 4; ++jp) {
-        const int col = cc * KR_CH + jp * 32 + fq * 8;
-        float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (p.residual != nullptr) ld8<H>(reinterpret_cast<const H*>(p.residual) + (size_t)m * p.ldr + col, rv);
-        const float4 b0 = *reinterpret_cast<const float4*>(sbias + col), b1 = *reinterpret_cast<const float4*>(sbias + col + 4);
-        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[cc * 32 + jp * 8 + h * 4 + r] = acc[cc][mi][jp * 2 + h][r] + bb[h * 4 + r] + rv[h * 4 + r];
-      }
-    float sum = 0.f;
-#pragma unroll
-    for (int e = 0; e < 64; ++e) sum += v[e];
-    const float mean = kr_rows_sum(sum) * (1.f / 256.f);
-    float d2 = 0.f;
-#pragma unroll
-    for (int e = 0; e < 64; ++e) { v[e] -= mean; d2 = fmaf(v[e], v[e], d2); }
-    const float rstd = rsqrtf(kr_rows_sum(d2) * (1.f / 256.f) + p.ln_eps);
-    if (mrow[mi] < p.M) {
-      H* yp = reinterpret_cast<H*>(p.C) + (size_t)m * p.ldc;
+    for (int mi = 0; mi < 2; ++mi) {
+      const int m = mrow[mi] < p.M ? mrow[mi] : p.M - 1;                   // clamped: the lane swaps need every lane
+      float v[64];
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
         for (int jp = 0; jp < 4; ++jp) {
           const int col = cc * KR_CH + jp * 32 + fq * 8;
-          const float4 g0 = *reinterpret_cast<const float4*>(sgam + col), g1 = *reinterpret_cast<const float4*>(sgam + col + 4);
-          const float4 e0 = *reinterpret_cast<const float4*>(sbet + col), e1 = *reinterpret_cast<const float4*>(sbet + col + 4);
-          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-          float o[8];
+          float rv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (RES) ld8<H>(reinterpret_cast<const H*>(p.residual) + (size_t)m * p.ldr + col, rv);
+          const float4 b0 = *reinterpret_cast<const float4*>(sbias + col), b1 = *reinterpret_cast<const float4*>(sbias + col + 4);
+          const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-          for (int q = 0; q < 8; ++q) o[q] = fmaf(v[cc * 32 + jp * 8 + q] * rstd, gg[q], ee[q]);
-          st8<H>(yp + col, o);
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[cc * 32 + jp * 8 + h * 4 + r] = acc[cc][mi][jp * 2 + h][r] + bb[h * 4 + r] + rv[h * 4 + r];
         }
+      float sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 64; ++e) sum += v[e];
+      const float mean = kr_rows_sum(sum) * (1.f / 256.f);
+      float d2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 64; ++e) { v[e] -= mean; d2 = fmaf(v[e], v[e], d2); }
+      const float rstd = rsqrtf(kr_rows_sum(d2) * (1.f / 256.f) + p.ln_eps);
+      if (mrow[mi] < p.M) {
+        H* yp = reinterpret_cast<H*>(p.C) + (size_t)m * p.ldc;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int jp = 0; jp < 4; ++jp) {
+            const int col = cc * KR_CH + jp * 32 + fq * 8;
+            const float4 g0 = *reinterpret_cast<const float4*>(sgam + col), g1 = *reinterpret_cast<const float4*>(sgam + col + 4);
+            const float4 e0 = *reinterpret_cast<const float4*>(sbet + col), e1 = *reinterpret_cast<const float4*>(sbet + col + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = fmaf(v[cc * 32 + jp * 8 + q] * rstd, gg[q], ee[q]);
+            st8<H>(yp + col, o);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one row tile at a time (both interleaved do not fit the register file)
     }
-    __builtin_amdgcn_sched_barrier(0);      // one row tile at a time (both interleaved do not fit the register file)
-  }
+  };
+  if (p.residual != nullptr) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1114,6 +1121,8 @@ static int gemm_launch_h16(ApeGemmArgs& p, hipStream_t s) {
       g_last_gemm_kernel = name;
       return 0;
     }
+    APE_CHECK_ARG(p.rowstat_cols == 0, "ape_hip_gemm: rowstat_cols needs the 256 x 128 tile kernel's plain epilogue (K %% 64 == 0, N %% 128 == 0, alpha 1, "
+                                       "no mask / clamp / activation / RoPE, 16-byte aligned bias / colvec / residual rows)");
     p.tile64 = 0;
   }
   constexpr bool HF = h16<H>::dt == APE_DT_F16;
@@ -1245,9 +1254,12 @@ extern "C" int ape_hip_gemm(const ApeGemmArgs* a, void* stream) {
   APE_CHECK_ARG(p.splitk <= 1 || ape_is16(p.in_dt), "ape_hip_gemm: split-K is implemented for the 16-bit kernels only");
   APE_CHECK_ARG(p.rope_cos == nullptr || (p.rope_sin != nullptr && p.rope_rows > 0 && p.rope_hd > 0 && p.rope_hd % 4 == 0),
                 "ape_hip_gemm: bad rope args");
-  APE_CHECK_ARG((p.rowscale == nullptr) == (p.rowshift == nullptr) && (p.rowscale == nullptr) == (p.colvec == nullptr),
-                "ape_hip_gemm: rowscale / rowshift / colvec go together");
+  APE_CHECK_ARG((p.rowscale == nullptr) == (p.rowshift == nullptr) && ((p.rowscale == nullptr) == (p.colvec == nullptr) || (p.rowstat_cols > 0 && p.rowscale == nullptr)),
+                "ape_hip_gemm: rowscale / rowshift / colvec go together (colvec alone with rowstat_cols > 0)");
   APE_CHECK_ARG(p.rowscale == nullptr || (!p.trans_out && p.act != APE_ACT_SWIGLU), "ape_hip_gemm: folded LayerNorm needs a plain (non-transposed, non-SwiGLU) epilogue");
+  APE_CHECK_ARG(p.rowstat_cols >= 0 && (p.rowstat_cols == 0 || (p.rowscale == nullptr && p.colvec != nullptr && ape_is16(p.in_dt) && p.tile64 == 4 && !p.trans_out &&
+                                                                  p.splitk <= 1 && p.ln_w == nullptr && p.conv_h <= 0)),
+                "ape_hip_gemm: rowstat_cols (in-launch row statistics) needs colvec without rowscale / rowshift, 16-bit operands and tile64 == 4");
   const int esz_out = p.out_dt == APE_DT_F32 ? 4 : 2;
   const int esz_res = p.res_dt == APE_DT_F32 ? 4 : 2;
   int vec = (p.ldc % 4 == 0) && (((uintptr_t)p.C) % 16 == 0);

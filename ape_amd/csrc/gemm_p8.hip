@@ -48,6 +48,15 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+__device__ __forceinline__ float p8_quad_sum(float v) {      // sum over the lanes l, l ^ 16, l ^ 32, l ^ 48 (all four receive it)
+  const unsigned u = __float_as_uint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned w = __float_as_uint(m);
+  const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // ABL (builds with -DAPE_P8_ABLATION only; tools/gpu_p8_ablate.py): 0 = the kernel; 1 = epilogue without its bias / table / residual
 // loads; 2 = full epilogue, no stores; 3 = no epilogue; 4 = one K tile only (prologue + epilogue)
 // CONV: implicit-GEMM 3 x 3 convolution (stride 1, zero padding 1) over a token-major [H * W, C = 256] map: A is the conv INPUT, K = 9 * C
@@ -59,9 +68,18 @@ template <int N> __device__ __forceinline__ void p8_wait_vmcnt() {
 // the ViT's SwiGLU, the one launch of the forward with more 256 x 256 tiles than CUs).  A separate instantiation with ONLY that
 // epilogue: the tile loop costs registers, and a kernel that spills even outside its main loop runs at half speed on this chip
 // (any scratch use at all: measured, profiles/r05_p8_persistent_probe.log) -- the one-tile kernels stay exactly as they were.
-template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0, bool CONV = false, bool PERSIST = false>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
+// RSTAT (round 6): the folded LayerNorm's row statistics computed by the launch itself (ApeGemmArgs.rowstat_cols).  Wave (wr, wc) owns
+// the 2 x 16 rows  wr * 128 + h * 64 + wc * 16 + frow  (h = 0, 1): next to each A half-tile's fragment reads it fetches the two
+// fragments of ITS row tile once more (a dynamic LDS address instead of a dynamic register index into af[][]), and adds 8 + 8
+// v_dot2c_f32 per half-tile (x . 1 and x . x of the lane's 16 values) in the shadow of the phase's MFMAs.  Behind the main loop the
+// four k-quarter lanes of a row are summed with two lane swaps and (sum, sum of squares) goes to LDS; the epilogue reads its eight
+// rows' pairs and forms rstd / -mean rstd itself.  What this removes per ViT block: the row_stats launch over the [rows, 2730]
+// SwiGLU output (13.7 us at 8192 rows, a second pass over 45 MB) and -- with the attention's inner LayerNorm folded the same way --
+// the LayerNorm launch between attention and output projection (12.9 us).  A separate instantiation: the other kernels' code is unchanged.
+template <int BN, bool STAGGER, typename H = bf16_t, int ABL = 0, bool CONV = false, bool PERSIST = false, bool RSTAT = false>   // H: bf16_t | f16_t operands (v_mfma_f32_16x16x32_bf16 / _f16), same schedule
 __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p) {
   static_assert(!PERSIST || (BN == 256 && ABL == 0 && !CONV), "the persistent flavour is the dense 256 x 256 kernel");
+  static_assert(!RSTAT || (BN == 128 && ABL == 0 && !CONV && !PERSIST), "in-launch row statistics: the 256 x 128 tile kernel");
   constexpr int WN = BN / 4;              // columns per wave: 64 | 32
   constexpr int TN = WN / 16;             // n tiles per wave: 4 | 2
   constexpr int TNH = TN / 2;             // n tiles per half: 2 | 1
@@ -190,6 +208,14 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       af[h][i][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + i * 2048 + rd1));
     }
   };
+  // RSTAT: this wave's statistics fragments (row tile wc of the half-tile, both k steps) and its running sums per half
+  bf16x8_t sfr[2];
+  float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+  auto read_S = [&](int stage, int h) __attribute__((always_inline)) {
+    const unsigned char* base = smem + stage * STG + (h ? OFF_A1 : OFF_A0) + wr * (64 * 128) + wc * 2048;
+    sfr[0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd0));
+    sfr[1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd1));
+  };
   auto read_B = [&](int stage, int h) __attribute__((always_inline)) {
     const unsigned char* base = smem + stage * STG + (h ? OFF_B1 : OFF_B0) + wc * ((WN / 2) * 128);
 #pragma unroll
@@ -226,7 +252,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = bq[j];
-    } else if (fast && p.bias != nullptr && p.rowscale == nullptr) {
+    } else if (!RSTAT && fast && p.bias != nullptr && p.rowscale == nullptr) {
       if (p.vec_ok & P8_BIAS_BY_ROW) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -260,6 +286,30 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
         for (int j = 0; j < TNH; ++j)
           acc[ha * 4 + i][hb * TNH + j] =
               h16<H>::mfma(wf[hb][j][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH + j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  // RSTAT: the phase's 8 MFMAs with the half-tile's 16 statistics instructions BETWEEN them (two per MFMA, pinned by the schedule groups:
+  // issued behind the MFMAs they were 2 x 128 cycles on top of every K tile -- measured +9 us on the 43 K tiles of the down projection)
+  auto mma_stat = [&](int ha, int hb, int h) __attribute__((always_inline)) {
+    static_assert(!RSTAT || TNH == 1, "one MFMA per statistics dword");
+    __builtin_amdgcn_s_setprio(1);
+    const uint4 u0 = __builtin_bit_cast(uint4, sfr[0]), u1 = __builtin_bit_cast(uint4, sfr[1]);
+    const uint32_t w8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+    uint32_t ones = ones2<H>::v;
+    asm volatile("" : "+v"(ones));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[ha * 4 + i][hb * TNH] = h16<H>::mfma(wf[hb][0][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH]);
+        dot2acc_pinned<H>(st1[h], w8[ks * 4 + i], ones);
+        dot2acc_pinned<H>(st2[h], w8[ks * 4 + i], w8[ks * 4 + i]);
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU (v_dot2c_f32) in its shadow
+    }
     __builtin_amdgcn_s_setprio(0);
   };
   auto barrier = [&]() __attribute__((always_inline)) {
@@ -369,6 +419,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   for (int t = 0; t < nk; ++t) {
     const int s = t & 1;
     // ---- phase 1
+    if (RSTAT) read_S(s, 0);                 // in front of the B0 reads: the counted lgkm wait below retires it with them
     read_B(s, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_A(s, 0);
@@ -377,7 +428,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads (issued first) are complete: B0 may be re-staged next phase
     barrier();
     lgkm0();
-    mma(0, 0);
+    if (RSTAT) mma_stat(0, 0, 0); else mma(0, 0);
     barrier();
     // ---- phase 2
     read_B(s, 1);
@@ -389,12 +440,13 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     mma(0, 1);
     barrier();
     // ---- phase 3
+    if (RSTAT) read_S(s, 1);
     read_A(s, 1);
     if (t + 2 < nk) { if (CONV) { conv_issue(t + 2, 0, ia0); conv_read(t + 2, 1, ia1); } else issue_A(t + 2, 0); }   // ia1: next iteration's phase 1
     if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(4); issue_rope(5); issue_rope(6); issue_rope(7); }
     barrier();
     lgkm0();
-    mma(1, 1);
+    if (RSTAT) mma_stat(1, 1, 1); else mma(1, 1);
     barrier();
     // ---- phase 4: every load of K tile t+1 must have landed before the next phase reads it
     if (t + 2 < nk) {
@@ -413,6 +465,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     // or it puts a vmcnt(0) in front of every row's table read -- which, stores counting on vmcnt, waits for the previous row's
     // output stores (one store round trip per accumulator row)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    barrier();
+  }
+
+  if (RSTAT) {
+    // every wave is past its last fragment read (the re-synchronising barrier above): stage 0 is free.  (sum, sum of squares) of row
+    // r at byte 8 r; the four lanes frow + 16 fq of a row hold the four k quarters of every K tile
+    float2* srow = reinterpret_cast<float2*>(smem);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float a = p8_quad_sum(st1[h]), b = p8_quad_sum(st2[h]);
+      if (fq == 0) srow[wr * 128 + (h * 4 + wc) * 16 + frow] = make_float2(a, b);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS writes are done before the barrier releases the readers
     barrier();
   }
 
@@ -470,6 +535,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     const unsigned char* tbl = smem + (nk & 1) * STG;
     const int c0 = (enb & 63) >> 2;                              // first 16-byte chunk (2 pairs) of this lane's columns in a table row
     uint32_t pk[DEFER ? 8 : 1][DEFER ? W / 4 : 1];
+    // RSTAT: (sum, sum of squares) of this lane's eight rows from LDS -- inline asm for the reason given at the table reads below
+    f32x2_t rst[RSTAT ? 8 : 1];
+    if (RSTAT) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t a = (uint32_t)(uintptr_t)(lds_void_t*)(smem + (ewr * 128 + i * 16 + efrow) * 8);
+        asm volatile("ds_read_b64 %0, %1" : "=v"(rst[RSTAT ? i : 0]) : "v"(a));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(rst[RSTAT ? i : 0]));     // consumed only behind the wait
+    }
 #pragma clang loop unroll(full)
     for (int i = 0; i < 8; ++i) {
       const int m = em0 + ewr * 128 + i * 16 + efrow;
@@ -512,7 +590,18 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
             for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], c, sn);
           }
         } else {
-          epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, enb, o, cols, cs, RESPF && respf);
+          if (RSTAT) {
+            // the folded LayerNorm's row terms from this launch's own statistics, then + bias (epi_row_fast's order), then the rest
+            const float inv_n = 1.f / (float)p.rowstat_cols;
+            const float mean = rst[RSTAT ? i : 0][0] * inv_n;
+            const float var = fmaxf(fmaf(-mean, mean, rst[RSTAT ? i : 0][1] * inv_n), 0.f);
+            const float rs = rsqrtf(var + p.rowstat_eps), sh = -mean * rs;
+#pragma unroll
+            for (int e = 0; e < W; ++e) o[e] = fmaf(o[e], rs, sh * cols.colvec[e]) + cols.bias[e];
+            epi_row_fast<W, false, false, ACT, H, false>(p, m, enb, o, cols, cs, RESPF && respf);
+          } else {
+            epi_row_fast<W, ROPE, NORM, ACT, H, RLDS>(p, m, enb, o, cols, cs, RESPF && respf);
+          }
           if (RESPF && respf) {                // the residual fetched ahead of the main loop: landed long ago (in-order vmcnt, main-loop waits)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -570,6 +659,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     } else {
       run(F{}, F{}, std::integral_constant<int, EPI_ACT_SWIGLU>{}, F{}, F{});
     }
+  } else if (RSTAT) {
+    run(F{}, T{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{}, F{});
   } else if (p.rope_cos != nullptr) {
     if (BN == 256 && rope_lds) run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, T{}, F{});
     else run(T{}, F{}, std::integral_constant<int, EPI_ACT_NONE>{}, F{}, F{});
@@ -653,6 +744,24 @@ const char* ape_gemm_p8_launch(ApeGemmArgs p, int bn, int stagger, hipStream_t s
     return f16 ? "gemm_f16_p8_kernel<256, true, persistent>" : "gemm_bf16_p8_kernel<256, true, persistent>";
   }
   const int grid = tiles;
+  if (p.rowstat_cols > 0) {
+    // in-launch row statistics: the 256 x 128 staggered tile kernel with its fast epilogue in EVERY wave (the generic epilogue knows
+    // nothing of the statistics in LDS) -- the conditions of epi_fast_ok, checked on the host
+    const int esz = p.out_dt == APE_DT_F32 ? 4 : 2;
+    const bool ok = bn == 128 && stagger && p.conv_h == 0 && p.rowscale == nullptr && p.colvec != nullptr && (p.vec_ok & 8) && p.N % 128 == 0 &&
+                    p.alpha == 1.f && p.rowmask == nullptr && !(p.clamp > 0.f) && p.act == APE_ACT_NONE && p.rope_cos == nullptr &&
+                    (p.bias == nullptr || (p.vec_ok & 2)) && !(p.vec_ok & P8_BIAS_BY_ROW) &&
+                    (p.residual == nullptr || ((p.vec_ok & 1) && p.ldr % 8 == 0)) && ((size_t)p.ldc * esz) % 16 == 0 && p.rowstat_cols <= p.K;
+    if (!ok) return nullptr;
+    static ApeOncePerDevice sattr;
+    if (sattr.first()) {
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, bf16_t, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+      (void)hipFuncSetAttribute((const void*)gemm_bf16_p8_kernel<128, true, f16_t, 0, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+    }
+    if (f16) APE_LAUNCH((gemm_bf16_p8_kernel<128, true, f16_t, 0, false, false, true>), dim3(grid), dim3(512), 98304, s, p);
+    else APE_LAUNCH((gemm_bf16_p8_kernel<128, true, bf16_t, 0, false, false, true>), dim3(grid), dim3(512), 98304, s, p);
+    return f16 ? "gemm_f16_p8_kernel<128, true, rowstat>" : "gemm_bf16_p8_kernel<128, true, rowstat>";
+  }
 #define P8_LAUNCH(BN_, ST_, H_, LDS_, NAME_)                                                                            \
   do {                                                                                                                  \
     static ApeOncePerDevice attr__;                                                                                         \

@@ -158,6 +158,7 @@ class Block(nn.Module):
             if self.subln:
                 P["nin"] = (f32(a.inner_attn_ln.weight), f32(a.inner_attn_ln.bias), a.inner_attn_ln.eps)
                 P["nffn"] = (f32(m.ffn_ln.weight), f32(m.ffn_ln.bias), m.ffn_ln.eps)
+                P.update(self._folded_inner_ln(a, dt, hd == hdp))
             if self.naiveswiglu:
                 hid = m.w1.weight.shape[0]
                 hid_pad = round_up(hid, 64)
@@ -195,6 +196,20 @@ class Block(nn.Module):
         return dict(w3f=w3f, c1=w3f.float().sum(dim=1).contiguous(),                 # row sums of the ROUNDED folded weight
                     c2=(w3 @ b + m.w3.bias.detach().float()).contiguous())
 
+    @staticmethod
+    def _folded_inner_ln(a, dt, unpadded):
+        """16-bit production mode (round 6): the attention's inner LayerNorm (vit_eva_clip.py:258-262, `inner_attn_ln` between the
+        attention and its output projection) folded into that projection exactly like the SwiGLU sub-LayerNorm below:
+        LN(o) Wp^T + bp = rstd (o W'^T) - rstd mean rowsum(W') + (Wp b_ln + bp)  with  W' = Wp diag(gamma).  The row statistics of the
+        stored attention output come from the projection's own launch (ops.gemm rowstats=): no LayerNorm launch, no second copy of o."""
+        if dt not in ops.HALF16 or not unpadded or not isinstance(a.inner_attn_ln, nn.LayerNorm) or os.environ.get("APE_NO_LNFOLD") == "1":
+            return {}
+        wp = a.proj.weight.detach().float()
+        g, b = a.inner_attn_ln.weight.detach().float(), a.inner_attn_ln.bias.detach().float()
+        wpf = pack_matrix(wp * g[None, :], dt)
+        return dict(wprojf=wpf, cp1=wpf.float().sum(dim=1).contiguous(),                 # row sums of the ROUNDED folded weight
+                    cp2=(wp @ b + a.proj.bias.detach().float()).contiguous())
+
     def _attention(self, xn, P, rope, nwin, ntok_win, vt_buf, images):
         """the attention branch on the normalised (pre-norm) or raw (post-norm) tokens xn [rows, E] -> [rows, Ep]"""
         nh = self.attn.num_heads
@@ -210,9 +225,15 @@ class Block(nn.Module):
             o = ops.attention(qk[:, :Ep], qk[:, Ep:], vt, batch=nwin, n=ntok_win, heads=nh, head_dim=hdp, scale=hd ** -0.5)
         else:
             o = ops.attention(qk[:, :Ep], qk[:, Ep:], vt, batch=images, n=xn.shape[0] // images, heads=nh, head_dim=hdp, scale=hd ** -0.5)
-        if self.subln:
+        if self.subln and "wprojf" not in P:
             o = ops.layernorm(o, P["nin"][0], P["nin"][1], P["nin"][2], out_dtype=xn.dtype)
         return o
+
+    def _out_proj(self, o, P, residual, out_dtype):
+        """the attention's output projection (+ residual), with the inner LayerNorm folded in when packed so"""
+        if "wprojf" in P:
+            return ops.gemm(o, P["wprojf"], P["cp2"], residual=residual, out_dtype=out_dtype, rowstats=(o.shape[1], P["nin"][2], P["cp1"]))
+        return ops.gemm(o, P["wproj"], P["bproj"], residual=residual, out_dtype=out_dtype)
 
     def _mlp(self, xn, P, dt, residual, out_dtype):
         """the MLP branch: residual + mlp(xn) (residual None: mlp(xn) alone) in out_dtype"""
@@ -220,8 +241,9 @@ class Block(nn.Module):
         if self.naiveswiglu:
             ops.gemm(xn, P["w12"], P["b12"], act=ops.ACT_SWIGLU, out=hbuf)
             if "w3f" in P:
-                stats = ops.row_stats(hbuf[:, :P["hid"]], P["nffn"][2])
-                return ops.gemm(hbuf, P["w3f"], P["c2"], residual=residual, rownorm=(stats[0], stats[1], P["c1"]), out_dtype=out_dtype)
+                # the row statistics of the stored hidden activation come from the down projection's own launch where the 256 x 128 tile
+                # kernel runs it (ops.gemm rowstats=; else a row_stats launch as in rounds 3-5): the K padding of hbuf is exact zeros
+                return ops.gemm(hbuf, P["w3f"], P["c2"], residual=residual, rowstats=(P["hid"], P["nffn"][2], P["c1"]), out_dtype=out_dtype)
             if self.subln:
                 hbuf = ops.layernorm(hbuf[:, :P["hid"]], P["nffn"][0], P["nffn"][1], P["nffn"][2], out_dtype=dt, cpad=P["hid_pad"])
             return ops.gemm(hbuf, P["w3"], P["b3"], residual=residual, out_dtype=out_dtype)
@@ -236,7 +258,7 @@ class Block(nn.Module):
         P = self.packed(dt)
         xn = ops.layernorm(x, P["n1"][0], P["n1"][1], P["n1"][2], out_dtype=dt)
         o = self._attention(xn, P, rope, nwin, ntok_win, vt_buf, images)
-        x = ops.gemm(o, P["wproj"], P["bproj"], residual=x, out_dtype=torch.float32)
+        x = self._out_proj(o, P, x, torch.float32)
         xn = ops.layernorm(x, P["n2"][0], P["n2"][1], P["n2"][2], out_dtype=dt)
         return self._mlp(xn, P, dt, x, dt if last else torch.float32)
 
@@ -246,7 +268,7 @@ class Block(nn.Module):
         P = self.packed(dt)
         cdt = None if dt == torch.float32 else dt
         o = self._attention(xb, P, rope, nwin, ntok_win, vt_buf, images)
-        t = ops.gemm(o, P["wproj"], P["bproj"], out_dtype=torch.float32)
+        t = self._out_proj(o, P, None, torch.float32)
         xb = ops.postnorm_residual(x32, t, P["n1"], copy_dtype=cdt)
         xb = x32 if xb is None else xb
         t = self._mlp(xb, P, dt, None, torch.float32)

@@ -92,8 +92,13 @@ def _auto_tiling(M, N, K, dtype, trans_out, act):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None,
+         rowstats=None):
     """C = epi(alpha * a @ w.T); see ApeGemmArgs in include/ape_hip.h for the epilogue order.
+
+    rowstats = (cols, eps, colvec [N]): the folded LayerNorm of `a` over its first `cols` columns (the rest is zero padding) with the row
+    statistics computed BY the GEMM launch (ApeGemmArgs.rowstat_cols: the 256 x 128 tile kernel); where that kernel does not apply
+    (`gemm_rowstats_fusable`) the statistics come from a `row_stats` launch and travel as `rownorm` -- same result up to fp32 summation order.
 
     norm = (weight [N], bias [N], eps): LayerNorm of the finished row (after bias / residual) in the same launch -- the K = N = 256,
     M >= 2048, 16-bit kernel only (`gemm_norm_fusable`); anything else is an argument error of the library.
@@ -149,6 +154,23 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
                 raise ValueError("ape_amd.ops.gemm: packed rope table must be contiguous float32 [rows, head_dim / 2, 2]")
             args.rope_cs = cs.data_ptr()
     args.alpha, args.clamp = float(alpha), float(clamp)
+    t64, sk = _auto_tiling(M, N, K, a.dtype, trans_out, act)
+    if rowstats is not None:
+        if rownorm is not None:
+            raise ValueError("ape_amd.ops.gemm: rowstats and rownorm are two ways of passing the same row terms")
+        cols, eps, cv = rowstats
+        _dev(cv)
+        if cv.numel() != N or not 0 < cols <= K:
+            raise ValueError("ape_amd.ops.gemm: rowstats = (cols <= K, eps, colvec [N])")
+        fusable = (t64 == 4 and tile64 in (None, 4) and splitk in (None, 1) and N % 128 == 0 and act == ACT_NONE and alpha == 1.0 and not clamp > 0.0
+                   and rowmask is None and rope is None and not trans_out and norm is None and os.environ.get("APE_NO_ROWSTAT") != "1"
+                   and (residual is None or (_ld(residual) % 8 == 0 and residual.data_ptr() % 16 == 0)) and out.data_ptr() % 16 == 0
+                   and (_ld(out) * out.element_size()) % 16 == 0)
+        if fusable:
+            args.colvec, args.rowstat_cols, args.rowstat_eps = _f32vec(cv, "colvec").data_ptr(), int(cols), float(eps)
+        else:
+            st = row_stats(a[:, :cols], eps)
+            rownorm = (st[0], st[1], cv)
     if rownorm is not None:
         rs, sh, cv = rownorm
         _dev(rs, sh, cv)
@@ -159,7 +181,6 @@ def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NO
     if norm is not None:
         _dev(norm[0], norm[1])
         args.ln_w, args.ln_b, args.ln_eps = _f32vec(norm[0], "norm weight").data_ptr(), _f32vec(norm[1], "norm bias").data_ptr(), float(norm[2])
-    t64, sk = _auto_tiling(M, N, K, a.dtype, trans_out, act)
     if splitk is not None:
         sk = int(splitk)
     if tile64 is not None:

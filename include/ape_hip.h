@@ -108,6 +108,17 @@ typedef struct ApeGemmArgs {
   const int32_t* conv_perm;
   const void* conv_zero;
   int32_t conv_h, conv_w;
+  /* Round 6: the row terms of the folded LayerNorm computed BY this launch (no ape_hip_row_stats launch, no second pass over A).
+   * rowstat_cols > 0 with rowscale == rowshift == NULL and colvec given: the kernel accumulates sum / sum of squares of every A row
+   * it stages (fp32, from the operand fragments the main loop reads anyway; columns >= rowstat_cols of A must be zero -- the K padding),
+   * and its epilogue applies  acc * rstd_m - rstd_m mean_m colvec[n] + bias[n]  with mean / var over rowstat_cols values and
+   * rstd = rsqrt(var + rowstat_eps).  The statistics are single-pass (var = E[x^2] - mean^2 in fp32): meant for activations whose
+   * mean is not large against their spread (the SwiGLU / attention outputs the ViT's sub-LayerNorms see, vit_eva_clip.py:129-131,
+   * 258-262).  Implemented by the 256 x 128 tile kernel only (tile64 == 4, 16-bit operands, K % 64 == 0, N % 128 == 0, plain
+   * epilogue: alpha 1, no mask / clamp / activation / RoPE / transpose); anything else is an argument error -- callers then launch
+   * ape_hip_row_stats and pass rowscale / rowshift.  0 = off. */
+  int32_t rowstat_cols;
+  float rowstat_eps;
 } ApeGemmArgs;
 int ape_hip_gemm(const ApeGemmArgs* args, void* stream);
 /* symbol of the kernel the calling thread's last ape_hip_gemm launched (measurement aid: bench.py's roofline) */

@@ -83,7 +83,7 @@ class RoundedApeOracle(ApeOracle):
     def vit_attention(self, xn, i, rope, key_order=None):
         """Attention.forward (vit_eva_clip.py:218-268) at the storage points of Block._attention (ape_amd/modeling/backbone/vit_eva_clip.py):
         q|k = store(rope(xn Wqk^T + b)), V^T = store(xn Wv^T + b), flash attention on 16-bit q, k, v with 16-bit probabilities, its
-        output stored, inner LayerNorm stored; the out projection is applied by the caller (fp32 residual epilogue)"""
+        output stored, then the out projection with the inner LayerNorm folded in (fp32; the caller adds the residual stream)"""
         pre = f"backbone.net.blocks.{i}.attn."
         B, H, W, C = xn.shape
         N = H * W
@@ -102,8 +102,18 @@ class RoundedApeOracle(ApeOracle):
             k, v = k[:, :, key_order], v[:, :, key_order]          # tile in the flash loop follows the STORED order
         o = self.attention16(q, k, v, q.shape[-1] ** -0.5)
         o = o.permute(0, 2, 1, 3).reshape(B, N, -1)
-        o = self.R(self.ln(o, pre + "inner_attn_ln", 1e-6))
-        return o.view(B, H, W, C)
+        # round 6: the inner LayerNorm is folded into the out projection (Block._folded_inner_ln): statistics of the STORED attention output,
+        # gamma inside the rounded weight -- no store between the attention and the projection any more
+        key = pre + "projf"
+        if key not in self._w:
+            wp, g, b = self.p(pre + "proj.weight"), self.p(pre + "inner_attn_ln.weight"), self.p(pre + "inner_attn_ln.bias")
+            wpf = self.R(wp * g[None, :])
+            self._w[key] = (wpf, wpf.sum(dim=1), wp @ b + self.p(pre + "proj.bias"))
+        wpf, c1, c2 = self._w[key]
+        mean = o.mean(dim=-1, keepdim=True)
+        rstd = torch.rsqrt(o.var(dim=-1, unbiased=False, keepdim=True) + 1e-6)
+        y = (o @ wpf.t()) * rstd + (-mean * rstd) * c1 + c2
+        return y.view(B, H, W, C)
 
     def attention16(self, q, k, v, scale, tile=64):
         """softmax(scale q k^T) v on 16-bit operands as csrc/attention.hip evaluates it: a flash loop over KEY TILES of 64 in the kernel's key
@@ -147,7 +157,7 @@ class RoundedApeOracle(ApeOracle):
             H, W = xn.shape[1], xn.shape[2]
             order = torch.arange(H * W).view(H // self.ws, self.ws, W // self.ws, self.ws).permute(0, 2, 1, 3).reshape(-1)
             o = self.vit_attention(xn, i, self.rope_glb, key_order=order)
-        x = x + self.rlin(o, pre + "attn.proj")                                         # fp32 residual epilogue, fp32 store
+        x = x + o                                                                        # (the folded out projection is inside vit_attention) fp32 residual epilogue, fp32 store
         h = self.R(self.ln(x, pre + "norm2", 1e-6))
         hidden = self.R(F.silu(self.rlin(h, pre + "mlp.w1")) * self.rlin(h, pre + "mlp.w2"))      # fused SwiGLU epilogue, one store
         # sub-LayerNorm folded into the down projection (Block._folded_subln): statistics of the STORED hidden activation

@@ -34,10 +34,15 @@ def _rotate_half(x):
 
 
 def gemm(a, w, bias=None, *, out=None, out_dtype=None, residual=None, act=ACT_NONE, alpha=1.0, clamp=0.0,
-         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None):
+         rowmask=None, mask_mode=MASK_NONE, trans_out=False, rope=None, m_pad=None, splitk=None, tile64=None, rownorm=None, norm=None,
+         rowstats=None):
     M, K = a.shape
     N = w.shape[0]
     x = (a.float() @ w.float().t()) * alpha
+    if rowstats is not None:                     # the folded LayerNorm's row terms from the operand itself (ApeGemmArgs.rowstat_cols)
+        cols, eps, cv = rowstats
+        st = row_stats(a[:, :cols], eps)
+        rownorm = (st[0], st[1], cv)
     if rownorm is not None:
         rs, sh, cv = rownorm
         x = x * rs.float()[:, None] + sh.float()[:, None] * cv.float()[None, :]

@@ -941,6 +941,63 @@ def test_gemm_folded_layernorm(ops, dtype):
         assert relerr(got2, got) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", H16)
+def test_gemm_rowstats_in_launch(ops, dtype, monkeypatch):
+    """gemm(rowstats=...): the folded LayerNorm's row statistics computed by the 256 x 128 tile kernel itself (ApeGemmArgs.rowstat_cols)
+    == row_stats + gemm(rownorm=...) up to fp32 summation order == LayerNorm(a) @ W^T + b; fp32 / 16-bit outputs, with and without
+    residual, a ragged last row tile, K padding, and the fallback where the tile kernel does not apply"""
+    eps = 1e-6
+    for M, C, Cp, N, mean in ((8192, 2730, 2752, 1024, 0.3), (8000, 1024, 1024, 1024, -0.2), (6500, 512, 512, 1280, 1.5)):
+        h = torch.zeros(M, Cp)
+        h[:, :C] = torch.randn(M, C, generator=torch.Generator().manual_seed(1)) * 2.0 + mean
+        h = h.to(dtype).to(DEV)
+        g = (1.0 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))).to(DEV)
+        b = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(3))).to(DEV)
+        w = (torch.randn(N, C, generator=torch.Generator().manual_seed(4)) / C ** 0.5).to(DEV)
+        bias = rnd(N, seed=5)
+        res = rnd(M, N, seed=6)
+        wf = torch.zeros(N, Cp, device=DEV)
+        wf[:, :C] = w * g[None, :]
+        wf = wf.to(dtype)
+        c1 = wf.float().sum(1).contiguous()
+        c2 = (w @ b + bias).contiguous()
+        rs, sh = ops.row_stats(h[:, :C], eps)
+        want = torch.nn.functional.layer_norm(h[:, :C].float(), (C,), g, b, eps) @ w.t() + bias
+        for residual, odt in ((res, torch.float32), (None, dtype), (None, torch.float32)):
+            two = ops.gemm(h, wf, c2, residual=residual, rownorm=(rs, sh, c1), out_dtype=odt, tile64=4)
+            got = ops.gemm(h, wf, c2, residual=residual, rowstats=(C, eps, c1), out_dtype=odt)
+            if not SELF:
+                from ape_amd import _lib
+                assert b"rowstat" in _lib.load().ape_hip_gemm_last_kernel(), (M, N, Cp)      # the case really took the in-launch path
+            e2, e = relerr(got, two), relerr(got, want + (residual if residual is not None else 0))
+            print(f"in-launch row statistics {dtype} {M}x{N}x{Cp} out {odt} residual {residual is not None}: vs row_stats path {e2:.2e}, vs LayerNorm definition {e:.2e}")
+            assert e2 < (2e-5 if odt == torch.float32 else 4e-3) and e < T16(dtype, 1.5e-2, 1e-4)
+    # where the tile kernel does not apply (few rows: another tiling) the statistics come from a row_stats launch -- same call, same result
+    M, C, N = 1000, 512, 256
+    h = (torch.randn(M, C, generator=torch.Generator().manual_seed(7)) + 0.5).to(dtype).to(DEV)
+    wf = (torch.randn(N, C, generator=torch.Generator().manual_seed(8)) / C ** 0.5).to(dtype).to(DEV)
+    c1, c2 = wf.float().sum(1).contiguous(), rnd(N, seed=9)
+    rs, sh = ops.row_stats(h, eps)
+    assert torch.equal(ops.gemm(h, wf, c2, rowstats=(C, eps, c1), out_dtype=torch.float32), ops.gemm(h, wf, c2, rownorm=(rs, sh, c1), out_dtype=torch.float32))
+    monkeypatch.setenv("APE_NO_ROWSTAT", "1")
+    M, C, N = 8192, 1024, 1024
+    h = (torch.randn(M, C, generator=torch.Generator().manual_seed(7)) + 0.5).to(dtype).to(DEV)
+    wf = (torch.randn(N, C, generator=torch.Generator().manual_seed(8)) / C ** 0.5).to(dtype).to(DEV)
+    c1, c2 = wf.float().sum(1).contiguous(), rnd(N, seed=9)
+    rs, sh = ops.row_stats(h, eps)
+    assert torch.equal(ops.gemm(h, wf, c2, rowstats=(C, eps, c1), out_dtype=torch.float32), ops.gemm(h, wf, c2, rownorm=(rs, sh, c1), out_dtype=torch.float32))
+    if not SELF:
+        # the C ABI refuses the mode where no kernel implements it (a caller must not get a GEMM without the row terms)
+        from ape_amd import _lib
+        import ctypes
+        a = _lib.GemmArgs()
+        out = torch.empty((M, N), dtype=torch.float32, device=DEV)
+        a.A, a.W, a.C, a.colvec = h.data_ptr(), wf.data_ptr(), out.data_ptr(), c1.data_ptr()
+        a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, C, C, C, N
+        a.in_dt, a.out_dt, a.alpha, a.rowstat_cols, a.rowstat_eps, a.tile64 = ops._dt(h), ops._dt(out), 1.0, C, eps, 0
+        assert _lib.load().ape_hip_gemm(ctypes.byref(a), None) != 0 and b"rowstat_cols" in _lib.load().ape_hip_last_error()
+
+
 @pytest.mark.parametrize("bf", H16)
 @pytest.mark.parametrize("stagger", [0, 1])
 @pytest.mark.parametrize("tile", [3, 4])

@@ -8,6 +8,7 @@
 #   ops            tests/test_ops_gpu.py (+ -k expression in $APE_K)
 #   model          tests/test_model_gpu.py tests/test_teacher_forced.py (+ -k expression in $APE_K)
 #   suite          the whole -m gpu suite with durations, measured regression values written to the tag directory
+#   pytest         python -m pytest $APE_PYTEST_ARGS -m gpu (+ -k expression in $APE_K), measured pins written to the tag directory
 #   smoke          __graft_entry__.smoke()
 #   bench          the driver's default bench (cpu_baseline + parity) -> bench_default.json
 #   benches        the other configurations / flavours (no CPU baseline)
@@ -49,6 +50,7 @@ PY
     ops)   timeout 900 python -m pytest tests/test_ops_gpu.py -q -s -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_ops.log; tail -4 $O/pytest_ops.log | cut -c1-300 ;;
     model) timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_teacher_forced.py -q -s -m gpu -x ${APE_K:+-k "$APE_K"} 2>&1 | grep -v Warning > $O/pytest_model.log; tail -4 $O/pytest_model.log | cut -c1-300 ;;
     suite) APE_WRITE_PINS=$O timeout 1700 python -m pytest tests -q -s -m gpu --durations=40 2>&1 | grep -v Warning > $O/pytest_gpu.log; tail -50 $O/pytest_gpu.log | cut -c1-200 ;;
+    pytest) APE_WRITE_PINS=$O timeout ${APE_PYTEST_TIMEOUT:-1700} python -m pytest ${APE_PYTEST_ARGS:-tests} -q -s -m gpu ${APE_K:+-k "$APE_K"} --durations=15 2>&1 | grep -v Warning > $O/pytest.log; grep -E "passed|failed|error" $O/pytest.log | tail -5 | cut -c1-300; grep -E "^FAILED|^ERROR|assert|Error" $O/pytest.log | head -20 | cut -c1-300 ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 | tee $O/smoke.log ;;
     bench) timeout 900 python bench.py ${APE_BENCH_ARGS} 2> $O/bench_default.err | tail -1 > $O/bench_default.json; cut -c1-300 $O/bench_default.json; python tools/bench_digest.py $O/bench_default.json | tee $O/bench_default_digest.txt ;;
     benches)
