@@ -73,6 +73,8 @@ SIGNATURES = {
     "ape_hip_argmax_labels": (c_int, [c_void_p, ctypes.c_size_t, c_int, ctypes.c_size_t, c_float, c_void_p, c_void_p]),
     "ape_hip_sdma_usable": (c_int, [c_void_p, c_void_p]),
     "ape_hip_sdma_d2h": (c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
+    "ape_hip_sdma_d2h_multi": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_size_t), c_int]),
+    "ape_hip_sdma_engines": (c_int, [c_void_p, c_void_p]),
     "ape_hip_row_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "ape_hip_gemv": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                              c_float, c_void_p]),

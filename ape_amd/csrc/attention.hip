@@ -419,7 +419,9 @@ static int attention_launch_h16(const AttnParams& p, dim3 grid, int B, int N, in
     // 256 queries per workgroup (4 query tiles per wave: every K / V^T fragment read from LDS feeds four MFMAs) when that still
     // leaves two workgroups per CU -- the 2-image ViT pass: 2 x 16 heads x 16 blocks (global), 8 windows x 16 heads x 4 blocks
     const char* qt4_env = getenv("APE_ATTN_QT4");
-    const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : false) && (size_t)ceil_div(N, 256) * nheads * B >= 512;
+    // round 6: ON by default (APE_ATTN_QT4=0 restores the 128-query kernel): bit-identical outputs (test_attention_four_query_tiles), the
+    // kernel alone - 5 % on the 2-image ViT launches (round 3), the driver command + 0.6-0.8 % on one box (profiles/r06_qt4_ab.txt)
+    const bool qt4 = (qt4_env ? atoi(qt4_env) != 0 : true) && (size_t)ceil_div(N, 256) * nheads * B >= 512;
     if (qt4) {
       grid.x = ceil_div(N, 256);
       APE_LAUNCH((attn_bf16_kernel<64, 4, false, true, 1, H>), grid, dim3(256), 0, s, p);

@@ -209,12 +209,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     }
   };
   // RSTAT: this wave's statistics fragments (row tile wc of the half-tile, both k steps) and its running sums per half
-  bf16x8_t sfr[2];
-  float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+  bf16x8_t sfr[2][2];
   auto read_S = [&](int stage, int h) __attribute__((always_inline)) {
     const unsigned char* base = smem + stage * STG + (h ? OFF_A1 : OFF_A0) + wr * (64 * 128) + wc * 2048;
-    sfr[0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd0));
-    sfr[1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd1));
+    sfr[h][0] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd0));
+    sfr[h][1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const short8_t*>(base + rd1));
   };
   auto read_B = [&](int stage, int h) __attribute__((always_inline)) {
     const unsigned char* base = smem + stage * STG + (h ? OFF_B1 : OFF_B0) + wc * ((WN / 2) * 128);
@@ -288,30 +287,41 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
               h16<H>::mfma(wf[hb][j][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH + j]);
     __builtin_amdgcn_s_setprio(0);
   };
-  // RSTAT: the phase's 8 MFMAs with the half-tile's 16 statistics instructions BETWEEN them (two per MFMA, pinned by the schedule groups:
-  // issued behind the MFMAs they were 2 x 128 cycles on top of every K tile -- measured +9 us on the 43 K tiles of the down projection)
-  auto mma_stat = [&](int ha, int hb, int h) __attribute__((always_inline)) {
-    static_assert(!RSTAT || TNH == 1, "one MFMA per statistics dword");
-    __builtin_amdgcn_s_setprio(1);
-    const uint4 u0 = __builtin_bit_cast(uint4, sfr[0]), u1 = __builtin_bit_cast(uint4, sfr[1]);
-    const uint32_t w8[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-    uint32_t ones = ones2<H>::v;
-    asm volatile("" : "+v"(ones));
+  // RSTAT: the statistics of half-tile h -- x . 1 and x . x of the lane's 16 values, 8 + 8 v_dot2c_f32 -- written behind the MFMAs of
+  // the phase that read the fragments and deliberately NOT pinned: the builtins are pure arithmetic, and hipcc moves all 32 of a K tile
+  // into phase 4, between the counted wait for the next K tile and that phase's barrier.  Every pinned placement measured worse on the
+  // down projection's 43 K tiles (gemm alone 60.7 us; profiles/r06_rowstat_probe.txt): this one + 9 us; volatile-asm v_dot2c between
+  // the MFMAs of the reading phase (schedule groups, 1 MFMA : 2 dot) + 15 us; under the B1 fragment reads of phase 2 and the DMA wait of
+  // phase 4 + 15 us; the same places with unpack + v_pk_add_f32 + v_pk_fma_f32 instead of the dot instructions + 20 us.  The loop's
+  // phases are 8 MFMAs = 128 matrix cycles long and the two wave rows of a SIMD alternate between them: ANY vector work lengthens a
+  // phase by about its own issue time.  Taking the fragments from the MFMA operand registers through a wave-uniform branch instead of
+  // reading them from LDS once more (-DAPE_P8_RSTAT_REGS): + 15 us.  The two-launch alternative costs more still (row_stats + gemm 75.5 us, layernorm + gemm 45.5 vs 35.9).
+  float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
+  auto stat_frag = [&](int h, const bf16x8_t (&f)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 u = __builtin_bit_cast(uint4, f[ks]);
+      const uint32_t w4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc[ha * 4 + i][hb * TNH] = h16<H>::mfma(wf[hb][0][ks], af[ha][i][ks], acc[ha * 4 + i][hb * TNH]);
-        dot2acc_pinned<H>(st1[h], w8[ks * 4 + i], ones);
-        dot2acc_pinned<H>(st2[h], w8[ks * 4 + i], w8[ks * 4 + i]);
+      for (int d = 0; d < 4; ++d) {
+        st1[h] = dot2acc<H>(w4[d], ones2<H>::v, st1[h]);
+        st2[h] = dot2acc<H>(w4[d], w4[d], st2[h]);
       }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU (v_dot2c_f32) in its shadow
     }
-    __builtin_amdgcn_s_setprio(0);
   };
+#ifndef APE_P8_RSTAT_REGS
+  auto stat = [&](int h) __attribute__((always_inline)) { stat_frag(h, sfr[h]); };
+#else
+  // (-DAPE_P8_RSTAT_REGS, measured and NOT kept: 74.6 us against 69.8) the wave's row tile (i = wc) straight from the fragments the MFMAs
+  // use -- a wave-UNIFORM four-way branch instead of a dynamic register index, no second LDS read of the fragments
+  const int wcs = __builtin_amdgcn_readfirstlane(wc);
+  auto stat = [&](int h) __attribute__((always_inline)) {
+    if (wcs == 0) stat_frag(h, af[h][0]);
+    else if (wcs == 1) stat_frag(h, af[h][1]);
+    else if (wcs == 2) stat_frag(h, af[h][2]);
+    else stat_frag(h, af[h][3]);
+  };
+#endif
   auto barrier = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -419,7 +429,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
   for (int t = 0; t < nk; ++t) {
     const int s = t & 1;
     // ---- phase 1
+#ifndef APE_P8_RSTAT_REGS
     if (RSTAT) read_S(s, 0);                 // in front of the B0 reads: the counted lgkm wait below retires it with them
+#endif
     read_B(s, 0);
     __builtin_amdgcn_sched_barrier(0);
     read_A(s, 0);
@@ -428,7 +440,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // the B0 reads (issued first) are complete: B0 may be re-staged next phase
     barrier();
     lgkm0();
-    if (RSTAT) mma_stat(0, 0, 0); else mma(0, 0);
+    mma(0, 0);
+    if (RSTAT) stat(0);
     barrier();
     // ---- phase 2
     read_B(s, 1);
@@ -440,13 +453,16 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_p8_kernel(const GemmParams p
     mma(0, 1);
     barrier();
     // ---- phase 3
+#ifndef APE_P8_RSTAT_REGS
     if (RSTAT) read_S(s, 1);
+#endif
     read_A(s, 1);
     if (t + 2 < nk) { if (CONV) { conv_issue(t + 2, 0, ia0); conv_read(t + 2, 1, ia1); } else issue_A(t + 2, 0); }   // ia1: next iteration's phase 1
     if (BN == 256 && rope_lds && t == nk - 1) { issue_rope(4); issue_rope(5); issue_rope(6); issue_rope(7); }
     barrier();
     lgkm0();
-    if (RSTAT) mma_stat(1, 1, 1); else mma(1, 1);
+    mma(1, 1);
+    if (RSTAT) stat(1);
     barrier();
     // ---- phase 4: every load of K tile t+1 must have landed before the next phase reads it
     if (t + 2 < nk) {

@@ -31,6 +31,7 @@ are copied into fixed `StaticGeometry` buffers before the replay, and the rescal
 vector.  One graph then serves every size -- including different sizes inside one step -- with the results of the
 per-size path (tests/test_model_gpu.py::test_any_size_runtime).
 """
+import ctypes
 import os
 import queue
 import threading
@@ -85,9 +86,19 @@ class _DmaTransfer:
             ev, copies, done, err = job
             try:
                 ev.synchronize()                              # the paste kernels of this slot have finished (host-side wait)
-                for dst, src, n in copies:
-                    if lib.ape_hip_sdma_d2h(dst, src, n) != 0:
-                        raise RuntimeError("ape_amd.runtime: " + (lib.ape_hip_last_error() or b"ape_hip_sdma_d2h failed").decode())
+                # every image's copy in flight at once, each in pieces over the free copy engines (one blocking copy after the other keeps
+                # one engine busy: the 2 x 1.18 GB per step of the 1536^2 / top-500 configuration then take longer than the step's kernels)
+                m = len(copies)
+                if os.environ.get("APE_SDMA_MULTI") == "0":   # A/B: one blocking copy after the other (the first round-6 form)
+                    for dst, src, n in copies:
+                        if lib.ape_hip_sdma_d2h(dst, src, n) != 0:
+                            raise RuntimeError("ape_amd.runtime: " + (lib.ape_hip_last_error() or b"ape_hip_sdma_d2h failed").decode())
+                    continue
+                dsts = (ctypes.c_void_p * m)(*[c[0] for c in copies])
+                srcs = (ctypes.c_void_p * m)(*[c[1] for c in copies])
+                sizes = (ctypes.c_size_t * m)(*[c[2] for c in copies])
+                if lib.ape_hip_sdma_d2h_multi(m, dsts, srcs, sizes, 0) != 0:
+                    raise RuntimeError("ape_amd.runtime: " + (lib.ape_hip_last_error() or b"ape_hip_sdma_d2h_multi failed").decode())
             except BaseException as exc:                      # surfaced by result()
                 err.append(exc)
             finally:

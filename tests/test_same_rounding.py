@@ -5,7 +5,8 @@ rounding flip those cause -- not a rounding point the pipeline has and the refer
 
 CPU: the harness on the tiny model with the torch definitions of the ops (tests/ref_ops.py) -- pins the ROUNDING STRUCTURE of the host code.
 GPU (-m gpu): the HIP kernels at BASELINE's configurations (APE-L_D 1024^2 square / padded, 1536^2 + semantic branch), both 16-bit flavours,
-every stage <= TOL relative rms; exceptions are listed in KNOWN with their cause.
+every stage <= TOL relative rms; exceptions are listed in KNOWN with their cause.  (The 1536^2 case and the f16 repetitions beyond L_D_coco80
+are opt-in -- APE_TEST_SLOW=1 / APE_TEST_ALL_F16=1 -- because the oracle runs on the host and the driver's GPU suite has 1200 s.)
 """
 import os
 import time
@@ -95,8 +96,14 @@ def test_host_pipeline_has_the_rounded_oracles_rounding_points(fake_ops, case, d
 def test_hip_pipeline_vs_same_rounding_oracle(case, dt):
     """GPU: every stage of the 16-bit HIP pipeline <= 2e-3 relative rms from the oracle at the same rounding points"""
     tag = "bf16" if dt == torch.bfloat16 else "f16"
-    if case == "L_D_1536_sseg" and dt == torch.float16 and os.environ.get("APE_TEST_ALL_F16") != "1":
-        pytest.skip("f16 at 1536^2 under APE_TEST_ALL_F16=1 (suite time: the oracle forward takes minutes on the host cores)")
+    # suite time: the driver gives `pytest -m gpu` 1200 s on the GPU box.  The rounded oracle's forward runs on the HOST cores: 55-65 s at
+    # 1024^2, 330 s at 1536^2 + semantic branch (390 s for that one case; the whole suite took 1295 s with it, profiles/r06_gpu_suite_all_cases.log).
+    # Default run: both flavours at L_D_coco80, bf16 (the timed flavour) at L_D_padded; APE_TEST_SLOW=1 adds 1536^2 + semantic (bf16),
+    # APE_TEST_ALL_F16=1 the f16 repetitions.  Last full run of every case: profiles/r06_same_rounding_gpu.log.
+    if case == "L_D_1536_sseg" and os.environ.get("APE_TEST_SLOW") != "1":
+        pytest.skip("1536^2 + semantic under APE_TEST_SLOW=1 (the oracle forward alone takes 330 s of host time; the suite has 1200 s)")
+    if case != "L_D_coco80" and dt == torch.float16 and os.environ.get("APE_TEST_ALL_F16") != "1":
+        pytest.skip("f16 at this configuration under APE_TEST_ALL_F16=1 (suite time)")
     dist, extras = run_case(case, "cuda", dt)
     report(f"{case} {tag}", dist, extras)
     check(case, tag, dist, extras, 60)
