@@ -9,7 +9,7 @@ void ape_set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
-extern "C" int ape_hip_abi_version(void) { return 4; }   // 2: ApeGemmArgs.rope_cs, ffn_fused / head_gemv dtype arguments; 3: ape_hip_meter_*; 4: ape_hip_sdma_*
+extern "C" int ape_hip_abi_version(void) { return 5; }   // 2: ApeGemmArgs.rope_cs, ffn_fused / head_gemv dtype arguments; 3: ape_hip_meter_*; 4: ape_hip_sdma_*; 5: ApeGemmArgs.rowstat_cols / rowstat_eps (struct grew at its end), ape_hip_sdma_d2h_multi
 
 // layout self-check for FFI bindings: sizeof the argument structs (0 = ApeGemmArgs, 1 = ApeLayerNormArgs, 2 = ApeGroupNormArgs)
 #include "../../include/ape_hip.h"

@@ -177,7 +177,10 @@ class GemmMeter:
         implicit 3 x 3 convolution (`..., conv3x3>`: same tile, schedule and MFMA stream, the A rows staged from shifted input rows): the
         roofline object is about the tile kernel as a whole = the sum over these instantiations (rocprofv3 lists them as separate rows)"""
         import re
-        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), (?:\d+|conv3x3|persistent)>$", r"\1>", name)
+        # round 6: `..., rowstat>` (the 256 x 128 tile kernel computing the folded LayerNorm's row statistics in its main loop) folds into
+        # its tile family like the other instantiations do -- which makes the two families nearly equal in total time (DESIGN.md section 0);
+        # `roofline.tile_kernel_families` carries both, whichever is larger
+        return re.sub(r"^(gemm_(?:bf16|f16)_p8_kernel<\d+, \w+), (?:\d+|conv3x3|persistent|rowstat)>$", r"\1>", name)
 
     def launch(self, i):
         """(kernel expression at the launch site, milliseconds) of launch i of the metering session"""
@@ -794,6 +797,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_note, "launches_per_image": dom_n / reps,
                          "avg_launch_us": 1e6 * dom_t / max(dom_n, 1), "kernel_ms_per_image": 1e3 * dom_t / reps,
                          "flops_per_launch": dom_fl / max(dom_n, 1),
+                         # every family of the eight-wave tile kernel (template gemm_bf16_p8_kernel, folded by tile width): the figures of the
+                         # family the object is NOT about stay on the line
+                         "tile_kernel_families": {k: {"kernel_ms_per_image": round(1e3 * v[1] / reps, 3), "launches_per_image": round(v[0] / reps, 2),
+                                                      "avg_launch_us": round(1e6 * v[1] / max(v[0], 1), 2), "tflops": round(v[2] / v[1] / 1e12, 1),
+                                                      "frac": round(v[2] / v[1] / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+                                                  for k, v in groups if "_p8_kernel<" in k},
                          "avg_launch_us_event_pair": 1e6 * dom_pair / max(dom_n, 1), "frac_event_pair": dom_fl / dom_pair / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                          "metering": "an eager pass of the step's composition, every branch inline (one kernel at a time, stand-alone launch "
                                      "durations); each launch carries its OWN (start, stop) HIP events (hipExtLaunchKernelGGL through the library's "

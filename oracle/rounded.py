@@ -18,8 +18,10 @@ override cites BOTH the reference lines it restates and the host / kernel code w
   * GEMM operands: activations and weights are 16-bit (ape_amd/packing.py pack_matrix); accumulation, bias, RoPE, activation, residual
     in fp32; ONE rounding at the store (include/ape_hip.h "epilogue order").  Biases, norm parameters, RoPE tables, position embeddings of
     the ViT stay fp32.
-  * ViT residual stream fp32 (the last block's output is stored 16-bit); LayerNorm outputs 16-bit; attention probabilities are rounded
+  * ViT residual stream fp32 (the last block's output is stored 16-bit); the outputs of norm1 / norm2 16-bit; attention probabilities are rounded
     before P.V and the row sum is taken over the ROUNDED probabilities (csrc/attention.hip: the sum is an MFMA of the packed tile with ones).
+  * the attention's inner LayerNorm folded into its output projection the same way (round 6, Block._folded_inner_ln): statistics of the
+    STORED attention output, gamma inside the rounded weight; no store between attention and projection.
   * SwiGLU sub-LayerNorm folded into the down projection: LN(h) W3^T = rstd (h W'^T) - rstd mean rowsum(W') + W3 beta with W' = W3 diag(gamma)
     ROUNDED to 16 bits and rowsum taken of the rounded W' (vit_eva_clip.py Block._folded_subln).
   * encoder / decoder streams 16-bit (post-norm layers: the residual is the LayerNorm output); the deformable attention's value projection

@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.ape_hip_abi_version() == 4
+    assert lib.ape_hip_abi_version() == 5
 
 
 def test_argument_struct_layouts_match_ctypes():

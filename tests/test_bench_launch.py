@@ -116,3 +116,5 @@ def test_kernel_family_folds_the_tile_kernels_instantiations():
     assert fam("gemm_bf16_p8_kernel<256, true, conv3x3>") == fam("gemm_bf16_p8_kernel<256, true, persistent>") == "gemm_bf16_p8_kernel<256, true>"
     assert fam("gemm_bf16_p8_kernel<256, true>") == "gemm_bf16_p8_kernel<256, true>" and fam("gemm_f16_p8_kernel<128, true, conv3x3>") == "gemm_f16_p8_kernel<128, true>"
     assert fam("gemm_bf16_kres_kernel<0, false, true>") == "gemm_bf16_kres_kernel<0, false, true>"
+    # round 6: the in-launch-statistics flavour of the 256 x 128 tile kernel belongs to ITS family, not to the 256 x 256 one and not to none
+    assert fam("gemm_bf16_p8_kernel<128, true, rowstat>") == "gemm_bf16_p8_kernel<128, true>" != fam("gemm_bf16_p8_kernel<256, true, persistent>")
