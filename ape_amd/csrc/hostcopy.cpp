@@ -67,9 +67,9 @@ extern "C" int ape_hip_sdma_d2h(void* host_dst, const void* dev_src, size_t nbyt
   return 0;
 }
 
-// Several device -> pinned-host copies in flight at once, each split into `parts` pieces spread over the copy engines the runtime reports
-// free for this direction (hsa_amd_memory_copy_engine_status + hsa_amd_memory_async_copy_on_engine; plain concurrent async copies when the
-// runtime offers no choice).  One blocking copy after the other keeps ONE engine busy: 36-38 GB/s measured on the 1.18 GB per image of
+// Several device -> pinned-host copies in flight at once, each split into `parts` pieces: concurrent hsa_amd_memory_async_copy calls the
+// runtime spreads over its copy engines (APE_SDMA_ENGINES=1: placed explicitly on the engines hsa_amd_memory_copy_engine_status reports
+// free, through hsa_amd_memory_async_copy_on_engine).  One blocking copy after the other keeps ONE engine busy: 36-38 GB/s measured on the 1.18 GB per image of
 // BASELINE's 1536^2 / top-500 configuration while kernels run (that configuration's step was bound by exactly this transfer:
 // profiles/r06_config5_transfer.txt).  parts <= 0: APE_SDMA_PARTS or 2.  Returns when every byte has landed (0 = ok).
 extern "C" int ape_hip_sdma_d2h_multi(int n, void* const* host_dst, const void* const* dev_src, const size_t* nbytes, int parts) {
@@ -105,8 +105,10 @@ extern "C" int ape_hip_sdma_d2h_multi(int n, void* const* host_dst, const void* 
     if (hsa_amd_memory_copy_engine_status(dst_agent, src_agent, &mask) == HSA_STATUS_SUCCESS)
       for (uint32_t b = 1; b != 0 && b <= 0x8000u; b <<= 1)
         if (mask & b) engines.push_back((hsa_amd_sdma_engine_id_t)b);
-    const char* e = getenv("APE_SDMA_ENGINES");          // 0: let the runtime place the concurrent copies itself
-    if (e != nullptr && atoi(e) == 0) engines.clear();
+    // Default: the runtime places the concurrent copies itself (measured identical to explicit placement on a 1-GPU box, 57 GB/s either
+    // way; on a multi-GPU node some engines serve the xGMI links and an explicit pick could land on one).  APE_SDMA_ENGINES=1: place them.
+    const char* e = getenv("APE_SDMA_ENGINES");
+    if (e == nullptr || atoi(e) == 0) engines.clear();
   }
   static thread_local std::vector<hsa_signal_t> sigs;
   while (sigs.size() < pieces.size()) {

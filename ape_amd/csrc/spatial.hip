@@ -146,27 +146,49 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ 
   st8<T>(out + (size_t)r * ldo + cc * 8, v);
 }
 
-extern "C" int ape_hip_gather_rows(const void* x, int ldx, const int* idx, int n, int C, void* out, int ldo, int dt, void* stream) {
-  APE_CHECK_ARG(x && idx && out && n > 0 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "ape_hip_gather_rows: bad args");
-  const size_t total = (size_t)n * (C / 8);
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+// rows of any width / stride (class-score rows [Q, K] with K = 133, 1203 ...: the panoptic branch gathers its kept queries' logits): one
+// element per thread
+template <typename T, typename TI>
+__global__ __launch_bounds__(256) void gather_rows_any_kernel(const T* __restrict__ x, int ldx, const TI* __restrict__ idx, int n,
+                                                              int C, T* __restrict__ out, int ldo) {
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (size_t)n * C) return;
+  const int c = (int)(gid % C), r = (int)(gid / C);
+  out[(size_t)r * ldo + c] = x[(size_t)idx[r] * ldx + c];
+}
+
+template <typename TI>
+static int gather_rows_launch(const char* what, const void* x, int ldx, const TI* idx, int n, int C, void* out, int ldo, int dt, void* stream) {
+  APE_CHECK_ARG(x && idx && out && n > 0 && C > 0 && ldx >= C && ldo >= C, "%s: bad args", what);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) APE_LAUNCH((gather_rows_kernel<f16_t, int>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) APE_LAUNCH((gather_rows_kernel<bf16_t, int>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
-  else APE_LAUNCH((gather_rows_kernel<float, int>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  const int esz = dt == APE_DT_F32 ? 4 : 2;
+  const bool vec = C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)x) % 16 == 0 && ((uintptr_t)out) % 16 == 0 && ((size_t)ldx * esz) % 16 == 0;
+  if (vec) {
+    const size_t total = (size_t)n * (C / 8);
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dt == APE_DT_F16) APE_LAUNCH((gather_rows_kernel<f16_t, TI>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
+    else if (dt == APE_DT_BF16) APE_LAUNCH((gather_rows_kernel<bf16_t, TI>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
+    else APE_LAUNCH((gather_rows_kernel<float, TI>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  } else {
+    const size_t total = (size_t)n * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dt == APE_DT_F32) APE_LAUNCH((gather_rows_any_kernel<float, TI>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+    else APE_LAUNCH((gather_rows_any_kernel<uint16_t, TI>), grid, block, 0, s, (const uint16_t*)x, ldx, idx, n, C, (uint16_t*)out, ldo);   // either 16-bit type: a copy
+  }
+  return 0;
+}
+
+extern "C" int ape_hip_gather_rows(const void* x, int ldx, const int* idx, int n, int C, void* out, int ldo, int dt, void* stream) {
+  const int rc = gather_rows_launch<int>("ape_hip_gather_rows", x, ldx, idx, n, C, out, ldo, dt, stream);
+  if (rc != 0) return rc;
   APE_CHECK_LAUNCH("ape_hip_gather_rows");
   return 0;
 }
 
 // the same with int64 row indices (what the selection kernels hand out: torch's index dtype)
 extern "C" int ape_hip_gather_rows_i64(const void* x, int ldx, const int64_t* idx, int n, int C, void* out, int ldo, int dt, void* stream) {
-  APE_CHECK_ARG(x && idx && out && n > 0 && C % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0, "ape_hip_gather_rows_i64: bad args");
-  const size_t total = (size_t)n * (C / 8);
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (dt == APE_DT_F16) APE_LAUNCH((gather_rows_kernel<f16_t, int64_t>), grid, block, 0, s, (const f16_t*)x, ldx, idx, n, C, (f16_t*)out, ldo);
-  else if (dt == APE_DT_BF16) APE_LAUNCH((gather_rows_kernel<bf16_t, int64_t>), grid, block, 0, s, (const bf16_t*)x, ldx, idx, n, C, (bf16_t*)out, ldo);
-  else APE_LAUNCH((gather_rows_kernel<float, int64_t>), grid, block, 0, s, (const float*)x, ldx, idx, n, C, (float*)out, ldo);
+  const int rc = gather_rows_launch<int64_t>("ape_hip_gather_rows_i64", x, ldx, idx, n, C, out, ldo, dt, stream);
+  if (rc != 0) return rc;
   APE_CHECK_LAUNCH("ape_hip_gather_rows_i64");
   return 0;
 }

@@ -94,6 +94,9 @@ class _DmaTransfer:
                         if lib.ape_hip_sdma_d2h(dst, src, n) != 0:
                             raise RuntimeError("ape_amd.runtime: " + (lib.ape_hip_last_error() or b"ape_hip_sdma_d2h failed").decode())
                     continue
+                # pieces placed on the copy engines the runtime reports free for device -> host (the form measured inside the pipeline:
+                # profiles/r06_config5_transfer.txt); APE_SDMA_ENGINES=0 leaves the placement of the concurrent copies to the runtime
+                os.environ.setdefault("APE_SDMA_ENGINES", "1")
                 dsts = (ctypes.c_void_p * m)(*[c[0] for c in copies])
                 srcs = (ctypes.c_void_p * m)(*[c[1] for c in copies])
                 sizes = (ctypes.c_size_t * m)(*[c[2] for c in copies])

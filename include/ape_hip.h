@@ -145,8 +145,8 @@ int ape_hip_zero(void* ptr, size_t nbytes, void* stream);
  * ape_hip_sdma_usable: 1 when the pointer pair qualifies. */
 int ape_hip_sdma_usable(const void* host_dst, const void* dev_src);
 int ape_hip_sdma_d2h(void* host_dst, const void* dev_src, size_t nbytes);
-/* n such copies in flight at once, each split into `parts` pieces placed on the copy engines the runtime reports free for the direction
- * (parts <= 0: APE_SDMA_PARTS or 2): the 1.18 GB of masks per image of the 1536^2 / top-500 configuration move at one engine's
+/* n such copies in flight at once, each split into `parts` pieces the runtime spreads over its copy engines (APE_SDMA_ENGINES=1: placed
+ * explicitly on the engines it reports free for the direction; parts <= 0: APE_SDMA_PARTS or 2): the 1.18 GB of masks per image of the 1536^2 / top-500 configuration move at one engine's
  * 36-38 GB/s otherwise, and that transfer bounds the step.  Blocking like ape_hip_sdma_d2h.  ape_hip_sdma_engines: engines free now (-1 unknown). */
 int ape_hip_sdma_d2h_multi(int n, void* const* host_dst, const void* const* dev_src, const size_t* nbytes, int parts);
 int ape_hip_sdma_engines(const void* host_dst, const void* dev_src);

@@ -864,6 +864,13 @@ def test_gather_rows_int64_indices(ops, bf):
     order = torch.randperm(100, generator=torch.Generator().manual_seed(4)).to(torch.int32).to(DEV)
     got = ops.gather_rows(m.view(100, -1).view(torch.float32), order).view(torch.uint8).view(m.shape)
     assert torch.equal(got, m[order.long()])                               # byte rows moved as 16-byte pieces: a pure copy
+    # rows of any width (class-score rows [Q, K] with K = 133 / 1203: the panoptic branch gathers its kept queries' logits) and strided views
+    for dt in (torch.float32, bf):
+        for C in (133, 1203, 7):
+            y = rnd(900, C, dtype=dt, seed=5)
+            assert torch.equal(ops.gather_rows(y, idx[:300] % 900), y[idx[:300] % 900])
+        z = rnd(900, 144, dtype=dt, seed=6)[:, :133]                              # row stride 144, 133 columns
+        assert torch.equal(ops.gather_rows(z, idx[:300] % 900), z[idx[:300] % 900])
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16, torch.float32])
