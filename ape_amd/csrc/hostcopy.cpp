@@ -105,8 +105,11 @@ extern "C" int ape_hip_sdma_d2h_multi(int n, void* const* host_dst, const void* 
     if (hsa_amd_memory_copy_engine_status(dst_agent, src_agent, &mask) == HSA_STATUS_SUCCESS)
       for (uint32_t b = 1; b != 0 && b <= 0x8000u; b <<= 1)
         if (mask & b) engines.push_back((hsa_amd_sdma_engine_id_t)b);
-    // Default: the runtime places the concurrent copies itself (measured identical to explicit placement on a 1-GPU box, 57 GB/s either
-    // way; on a multi-GPU node some engines serve the xGMI links and an explicit pick could land on one).  APE_SDMA_ENGINES=1: place them.
+    // APE_SDMA_ENGINES=1 (what ape_amd/runtime.py sets): the pieces go to DIFFERENT engines.  Unset / 0: plain concurrent
+    // hsa_amd_memory_async_copy calls, which the runtime queues on ONE engine -- as fast as placed copies on an idle GPU (57 GB/s either
+    // way, tools/gpu_sdma_multi_probe.py), but inside the running pipeline one engine moves ~37 GB/s and the 1536^2 / top-500 step stalls
+    // exactly like the sequential form (profiles/r06_config5_transfer.txt: 29.9 vs 37.1 images/s).  The library's own default stays
+    // "unplaced" because an explicit pick is a policy of the caller (on a multi-GPU node the caller may want to leave engines to xGMI).
     const char* e = getenv("APE_SDMA_ENGINES");
     if (e == nullptr || atoi(e) == 0) engines.clear();
   }

@@ -145,9 +145,11 @@ int ape_hip_zero(void* ptr, size_t nbytes, void* stream);
  * ape_hip_sdma_usable: 1 when the pointer pair qualifies. */
 int ape_hip_sdma_usable(const void* host_dst, const void* dev_src);
 int ape_hip_sdma_d2h(void* host_dst, const void* dev_src, size_t nbytes);
-/* n such copies in flight at once, each split into `parts` pieces the runtime spreads over its copy engines (APE_SDMA_ENGINES=1: placed
- * explicitly on the engines it reports free for the direction; parts <= 0: APE_SDMA_PARTS or 2): the 1.18 GB of masks per image of the 1536^2 / top-500 configuration move at one engine's
- * 36-38 GB/s otherwise, and that transfer bounds the step.  Blocking like ape_hip_sdma_d2h.  ape_hip_sdma_engines: engines free now (-1 unknown). */
+/* n such copies in flight at once, each split into `parts` pieces (parts <= 0: APE_SDMA_PARTS or 2).  With APE_SDMA_ENGINES=1 in the environment
+ * (ape_amd/runtime.py sets it) the pieces are placed on DIFFERENT copy engines (hsa_amd_memory_async_copy_on_engine over the engines
+ * hsa_amd_memory_copy_engine_status reports free for the direction); otherwise they are plain concurrent copies, which the runtime queues on one
+ * engine.  Inside a running pipeline one engine moves ~37 GB/s: the 2 x 1.18 GB of masks per step of the 1536^2 / top-500 configuration need two
+ * (profiles/r06_config5_transfer.txt).  Blocking like ape_hip_sdma_d2h.  ape_hip_sdma_engines: engines free now (-1 unknown). */
 int ape_hip_sdma_d2h_multi(int n, void* const* host_dst, const void* const* dev_src, const size_t* nbytes, int parts);
 int ape_hip_sdma_engines(const void* host_dst, const void* dev_src);
 
