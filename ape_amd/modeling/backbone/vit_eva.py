@@ -41,15 +41,36 @@ def ext_width(hd, hk, wk):
                      "(token grids beyond 96 x 96 at a head width of 88 need a wider attention tile)")
 
 
-def resized_rel_pos(rel_pos, size):
-    """get_rel_pos (utils_eva.py:65-129, interp_type "vitdet") for q_size == k_size == size: the table with 2 size - 1 rows (linear
-    interpolation when the checkpoint's differs); row (q - k) + size - 1 belongs to the offset q - k"""
+BEIT_RATIO = 1.0903078          # growth of the node spacing in the BEiT-style table resize (utils_eva.py:91)
+
+
+def resized_rel_pos(rel_pos, size, interp_type="vitdet"):
+    """get_rel_pos (utils_eva.py:65-129) for q_size == k_size == size: the table with 2 size - 1 rows; row (q - k) + size - 1 belongs to
+    the offset q - k.  A checkpoint table of another length is resized ONCE, at weight-packing time:
+      "vitdet": linear interpolation over the row index (:81-91);
+      "beit"  : (:92-118) the source rows sit at the geometric-progression offsets 0, +-1, +-(1 + r), +-(1 + r + r^2), ... (r = 1.0903078),
+                a cubic spline through them (scipy interp1d, extrapolating) is read at the integer offsets -(size - 1) .. size - 1 --
+                a host-side weight transform exactly as in the reference, which imports scipy for it too."""
     want = 2 * size - 1
     rel_pos = rel_pos.detach().float()
-    if rel_pos.shape[0] != want:
+    if rel_pos.shape[0] == want:
+        return rel_pos.contiguous()
+    if interp_type == "vitdet":
         rel_pos = F.interpolate(rel_pos.reshape(1, rel_pos.shape[0], -1).permute(0, 2, 1), size=want, mode="linear")
-        rel_pos = rel_pos.reshape(-1, want).permute(1, 0)
-    return rel_pos.contiguous()
+        return rel_pos.reshape(-1, want).permute(1, 0).contiguous()
+    if interp_type != "beit":
+        raise NotImplementedError(f"ape_amd vit_eva: interp_type {interp_type!r} (the reference knows 'vitdet' and 'beit')")
+    import numpy as np
+    from scipy import interpolate
+    src = rel_pos.shape[0]
+    half = src // 2
+    steps = BEIT_RATIO ** np.arange(half, dtype=np.float64)                 # 1, r, r^2, ...: distance between neighbouring source rows
+    right = 1.0 + np.concatenate([[0.0], np.cumsum(steps[1:])]) if half else np.zeros(0)      # 1, 1 + r, 1 + r + r^2, ...
+    nodes = np.concatenate([-right[::-1], [0.0], right])                    # positions of the src rows (src is odd: 2 * half + 1)
+    reach = want // 2.0
+    at = np.arange(-reach, reach + 0.1, 1.0)                                # the integer offsets of the resized table
+    spline = interpolate.interp1d(nodes, rel_pos.cpu().numpy(), kind="cubic", axis=0, fill_value="extrapolate")
+    return torch.from_numpy(np.ascontiguousarray(spline(at))).to(dtype=torch.float32, device=rel_pos.device).contiguous()
 
 
 class Mlp(nn.Module):
@@ -67,9 +88,8 @@ class Attention(nn.Module):
     def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True, input_size=None,
                  beit_like_qkv_bias=False, interp_type="vitdet"):
         super().__init__()
-        if interp_type != "vitdet":
-            raise NotImplementedError("ape_amd vit_eva: interp_type 'beit' (the geometric-progression table resize of utils_eva.py:"
-                                      "80-118, scipy) is not implemented; every APE config uses 'vitdet'")
+        if interp_type not in ("vitdet", "beit"):
+            raise NotImplementedError(f"ape_amd vit_eva: interp_type {interp_type!r} (the reference knows 'vitdet' and 'beit')")
         self.num_heads = num_heads
         head_dim = dim // num_heads
         self.scale = head_dim ** -0.5
@@ -162,7 +182,7 @@ class Block(nn.Module):
                 n2=(f32(self.norm2.weight), f32(self.norm2.bias), self.norm2.eps),
                 w1=pack_matrix(w1, dt), b1=b1, hid_pad=hid_pad, w2=pack_matrix(w2, dt, kpad=64), b2=b2.contiguous())
             if a.use_rel_pos:
-                rh, rw = resized_rel_pos(a.rel_pos_h, group), resized_rel_pos(a.rel_pos_w, group)
+                rh, rw = resized_rel_pos(a.rel_pos_h, group, a.interp_type), resized_rel_pos(a.rel_pos_w, group, a.interp_type)
                 nr = rh.shape[0] + rw.shape[0]
                 # [Rh ; Rw] as the weight of the q . R^T GEMM: K = the padded head width (q's padding columns are zero), N padded to 64
                 P.update(rcat=pack_matrix(torch.cat([rh, rw], 0), dt, kpad=hdp, rows=round_up(nr, 64)), ext=ext_width(hd, group, group))

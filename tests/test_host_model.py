@@ -2,6 +2,8 @@
 for their torch definitions (fixture `fake_ops`, tests/ref_ops.py) and the result is compared with the oracle and
 with the reference-generated golden fixtures.  This pins everything EXCEPT the kernels themselves, which the
 -m gpu tests pin against the same torch definitions."""
+import os
+
 import pytest
 import torch
 
@@ -471,7 +473,15 @@ def test_eva01_mim_vitg_relative_positions(fake_ops):
     with pytest.raises(ValueError):
         vit_eva.ext_width(88, 128, 128)
     with pytest.raises(NotImplementedError):
-        vit_eva.Attention(64, 2, use_rel_pos=True, input_size=(4, 4), interp_type="beit")
+        vit_eva.Attention(64, 2, use_rel_pos=True, input_size=(4, 4), interp_type="bicubic")
+    # get_rel_pos "beit" (utils_eva.py:92-118: cubic spline over geometric-progression nodes, scipy): against vectors produced by the
+    # reference's own function (tests/golden/make_relpos_beit.py) -- the resized table, gathered the way get_rel_pos hands it out
+    for table, size, want in torch.load(os.path.join(os.path.dirname(__file__), "golden", "relpos_beit.pt")):
+        got = vit_eva.resized_rel_pos(table, size, "beit")
+        idx = (torch.arange(size)[:, None] - torch.arange(size)[None, :]) + size - 1
+        assert got.shape == (2 * size - 1, table.shape[1]) and torch.allclose(got[idx], want, rtol=0, atol=1e-6)
+    blk = vit_eva.Attention(64, 2, use_rel_pos=True, rel_pos_zero_init=False, input_size=(4, 4), interp_type="beit")
+    assert blk.interp_type == "beit"
     # get_rel_pos "vitdet" (utils_eva.py:65-129): a checkpoint table of another length is resized linearly
     tbl = torch.randn(9, 8)
     assert torch.equal(vit_eva.resized_rel_pos(tbl, 5), tbl)
