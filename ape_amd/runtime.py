@@ -96,7 +96,11 @@ class _DmaTransfer:
                     continue
                 # pieces placed on the copy engines the runtime reports free for device -> host (the form measured inside the pipeline:
                 # profiles/r06_config5_transfer.txt); APE_SDMA_ENGINES=0 leaves the placement of the concurrent copies to the runtime
-                os.environ.setdefault("APE_SDMA_ENGINES", "1")
+                # ... in a single-process run.  With several ranks on one node (torch.distributed) the copies stay unplaced unless the
+                # environment says otherwise: explicit engine picks were only ever measured on 1-GPU boxes, and at 1024^2 (105 MB per
+                # image) one engine is enough
+                multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+                os.environ.setdefault("APE_SDMA_ENGINES", "0" if multi else "1")
                 dsts = (ctypes.c_void_p * m)(*[c[0] for c in copies])
                 srcs = (ctypes.c_void_p * m)(*[c[1] for c in copies])
                 sizes = (ctypes.c_size_t * m)(*[c[2] for c in copies])
